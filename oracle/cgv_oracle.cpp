@@ -1,0 +1,593 @@
+// cgv_oracle.cpp — CPU ORACLE for the codegraph-vector brute-force kNN hot path.
+//
+// *** TEST INFRASTRUCTURE, NOT PRODUCT CODE. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load
+// this library. The product (libcgvec_hip.so) never links, imports or calls it.
+//
+// What this is: a faithful restatement, in C++ with the same AVX2/FMA intrinsics
+// and the same operation order, of the arithmetic in the reference's Rust sources
+// (paths relative to /root/reference/):
+//   O2  crates/codegraph-vector/src/simd_ops.rs    (AVX2 cosine/dot/L2/normalise,
+//                                                   rayon brute-force top-k)
+//   O1  crates/codegraph-vector/src/optimization.rs:376-418 (search_baseline)
+//   RS  crates/codegraph-vector/src/search.rs:113,119-137,519-533,574-592
+//       (prefetch rule, exact re-score formula, min-max normalise)
+//   HE  crates/codegraph-vector/src/search.rs:178-205,535-541 (hash embedder;
+//       identical copies at codegraph-core/src/integration/graph_vector.rs:78-95,
+//       codegraph-vector/src/embedding.rs:700-734)
+//   Q8  crates/codegraph-vector/src/optimization.rs:63-150,212-224 (int8 scan)
+// Every function cites the lines it follows.
+//
+// Pinning status: the reference is Rust and cannot be built here (no cargo/rustc,
+// un-vendored dependency tree), so it cannot be executed to generate vectors.
+// The oracle is pinned against every known-answer test the reference's own test
+// modules hold for this path (tests/test_oracle_kats.py lists them with
+// file:line): simd_ops.rs:429-447, :450-459, :462-472; rag/context_retriever.rs:
+// 505-512; rag/result_ranker.rs:598-605; ml/features.rs:481-489. Those KATs are
+// loose (1e-6 tolerances, `len()==10`), so beyond them the source arithmetic
+// restated here IS the contract.
+//
+// Build: g++ -O2 -mavx2 -mfma -mf16c -ffp-contract=off -fopenmp (see Makefile).
+// -ffp-contract=off matters: Rust never contracts a*b+c, so the scalar formulas
+// below must round the product and the sum separately; the AVX2 paths use explicit
+// _mm256_fmadd_ps exactly where the reference does.
+
+#include <immintrin.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+#include <utility>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// O2: SIMDVectorOps
+// ---------------------------------------------------------------------------
+
+// simd_ops.rs:227-242 horizontal_sum_avx2:
+//   v_perm = permute2f128(v,v,0x01); v_add1 = v + v_perm;
+//   hadd(hadd(v_add1)) -> ((l0+l4)+(l1+l5)) + ((l2+l6)+(l3+l7))
+static inline float hsum_avx2(__m256 v) {
+    __m256 v_perm = _mm256_permute2f128_ps(v, v, 0x01);
+    __m256 v_add1 = _mm256_add_ps(v, v_perm);
+    __m256 v_hadd1 = _mm256_hadd_ps(v_add1, v_add1);
+    __m256 v_hadd2 = _mm256_hadd_ps(v_hadd1, v_hadd1);
+    return _mm256_cvtss_f32(v_hadd2);
+}
+
+// simd_ops.rs:15-78 cosine_similarity_avx2 (len mismatch is the caller's error;
+// len == 0 -> 0.0).
+float cgo_cosine_avx2(const float* a, const float* b, size_t len) {
+    if (len == 0) return 0.0f;
+    __m256 dot = _mm256_setzero_ps();
+    __m256 na = _mm256_setzero_ps();
+    __m256 nb = _mm256_setzero_ps();
+    size_t chunks = len / 8;
+    for (size_t i = 0; i < chunks; ++i) {
+        __m256 va = _mm256_loadu_ps(a + i * 8);
+        __m256 vb = _mm256_loadu_ps(b + i * 8);
+        dot = _mm256_fmadd_ps(va, vb, dot);
+        na = _mm256_fmadd_ps(va, va, na);
+        nb = _mm256_fmadd_ps(vb, vb, nb);
+    }
+    float dp = hsum_avx2(dot);
+    float na_sq = hsum_avx2(na);
+    float nb_sq = hsum_avx2(nb);
+    float dp_r = 0.0f, na_r = 0.0f, nb_r = 0.0f;
+    for (size_t i = chunks * 8; i < len; ++i) {
+        float va = a[i], vb = b[i];
+        dp_r += va * vb;  // separate mul/add rounding (-ffp-contract=off)
+        na_r += va * va;
+        nb_r += vb * vb;
+    }
+    float final_dp = dp + dp_r;
+    float final_na = na_sq + na_r;
+    float final_nb = nb_sq + nb_r;
+    float norm_product = sqrtf(final_na * final_nb);
+    if (norm_product == 0.0f) return 0.0f;
+    return final_dp / norm_product;
+}
+
+// simd_ops.rs:257-278 cosine_similarity_scalar.
+float cgo_cosine_scalar(const float* a, const float* b, size_t len) {
+    float dot = 0.0f, na = 0.0f, nb = 0.0f;
+    for (size_t i = 0; i < len; ++i) {
+        float va = a[i], vb = b[i];
+        dot += va * vb;
+        na += va * va;
+        nb += vb * vb;
+    }
+    float norm_product = sqrtf(na * nb);
+    if (norm_product == 0.0f) return 0.0f;
+    return dot / norm_product;
+}
+
+// simd_ops.rs:281-295 adaptive_cosine_similarity: AVX2 iff avx2&&fma (true on
+// every x86_64 host this runs on; the build requires -mavx2 -mfma) && len >= 32.
+float cgo_cosine_adaptive(const float* a, const float* b, size_t len) {
+    if (len >= 32) return cgo_cosine_avx2(a, b, len);
+    return cgo_cosine_scalar(a, b, len);
+}
+
+// simd_ops.rs:149-183 dot_product_avx2.
+float cgo_dot_avx2(const float* a, const float* b, size_t len) {
+    if (len == 0) return 0.0f;
+    __m256 dot = _mm256_setzero_ps();
+    size_t chunks = len / 8;
+    for (size_t i = 0; i < chunks; ++i) {
+        __m256 va = _mm256_loadu_ps(a + i * 8);
+        __m256 vb = _mm256_loadu_ps(b + i * 8);
+        dot = _mm256_fmadd_ps(va, vb, dot);
+    }
+    float dp = hsum_avx2(dot);
+    float r = 0.0f;
+    for (size_t i = chunks * 8; i < len; ++i) r += a[i] * b[i];
+    return dp + r;
+}
+
+// simd_ops.rs:105-143 l2_distance_avx2.
+float cgo_l2_avx2(const float* a, const float* b, size_t len) {
+    if (len == 0) return 0.0f;
+    __m256 acc = _mm256_setzero_ps();
+    size_t chunks = len / 8;
+    for (size_t i = 0; i < chunks; ++i) {
+        __m256 va = _mm256_loadu_ps(a + i * 8);
+        __m256 vb = _mm256_loadu_ps(b + i * 8);
+        __m256 d = _mm256_sub_ps(va, vb);
+        acc = _mm256_fmadd_ps(d, d, acc);
+    }
+    float s = hsum_avx2(acc);
+    float r = 0.0f;
+    for (size_t i = chunks * 8; i < len; ++i) {
+        float d = a[i] - b[i];
+        r += d * d;
+    }
+    return sqrtf(s + r);
+}
+
+// simd_ops.rs:189-222 normalize_avx2 (in place; zero vector untouched;
+// multiplies by the reciprocal 1.0/norm, not a divide).
+void cgo_normalize_avx2(float* v, size_t len) {
+    if (len == 0) return;
+    float nsq = cgo_dot_avx2(v, v, len);
+    if (nsq == 0.0f) return;
+    float norm = sqrtf(nsq);
+    float inv = 1.0f / norm;
+    __m256 vinv = _mm256_set1_ps(inv);
+    size_t chunks = len / 8;
+    for (size_t i = 0; i < chunks; ++i) {
+        __m256 x = _mm256_loadu_ps(v + i * 8);
+        _mm256_storeu_ps(v + i * 8, _mm256_mul_ps(x, vinv));
+    }
+    for (size_t i = chunks * 8; i < len; ++i) v[i] *= inv;
+}
+
+// simd_ops.rs:85-99 batch_cosine_similarity_avx2: one query vs many rows, serial.
+void cgo_batch_cosine_avx2(const float* q, const float* const* rows, size_t n, size_t len,
+                           float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = cgo_cosine_avx2(q, rows[i], len);
+}
+
+// ---------------------------------------------------------------------------
+// O2: ParallelVectorOps::parallel_top_k_search  (simd_ops.rs:361-383)
+//   scores: rows.par_iter().enumerate().map(adaptive_cosine(q,row).unwrap_or(0.0))
+//   sort:   par_sort_unstable_by(|a,b| b.1.partial_cmp(&a.1).unwrap())  (desc)
+//   truncate(k)
+// rayon's unstable sort leaves tie order unspecified; the oracle fixes
+// (score desc, row index asc), a valid outcome of it. NaN makes the reference
+// panic (partial_cmp().unwrap()); the oracle returns -1 in that case.
+// metric: 0 = cosine (adaptive), 1 = dot product (dot_product_avx2; the reference
+// exposes it as a building block, simd_ops.rs:149-183 — BASELINE C4's metric).
+// ---------------------------------------------------------------------------
+
+struct Pair {
+    float s;
+    uint64_t i;
+};
+
+static inline bool pair_before(const Pair& x, const Pair& y) {
+    if (x.s > y.s) return true;
+    if (x.s < y.s) return false;
+    return x.i < y.i;
+}
+
+static void parallel_sort_pairs(std::vector<Pair>& v, int threads) {
+    size_t n = v.size();
+    if (threads <= 1 || n < 4096) {
+        std::sort(v.begin(), v.end(), pair_before);
+        return;
+    }
+    // full parallel sort (not a k-select): chunk sorts + pairwise merges, the
+    // same O(N log N / P) shape as rayon's par_sort_unstable_by.
+    int T = 1;
+    while (T * 2 <= threads) T *= 2;
+    std::vector<size_t> bnd(T + 1);
+    for (int t = 0; t <= T; ++t) bnd[t] = n * (size_t)t / (size_t)T;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; ++t) std::sort(v.begin() + bnd[t], v.begin() + bnd[t + 1], pair_before);
+    for (int w = 1; w < T; w *= 2) {
+        int nm = T / (2 * w);
+#pragma omp parallel for num_threads(nm > 0 ? nm : 1) schedule(static, 1)
+        for (int m = 0; m < nm; ++m) {
+            size_t lo = bnd[2 * w * m], mid = bnd[2 * w * m + w], hi = bnd[2 * w * m + 2 * w];
+            std::inplace_merge(v.begin() + lo, v.begin() + mid, v.begin() + hi, pair_before);
+        }
+    }
+}
+
+int cgo_parallel_top_k(const float* query, const float* const* rows, uint64_t n, uint64_t dim,
+                       uint64_t k, int metric, int threads, uint64_t* out_idx, float* out_score) {
+    if (threads <= 0) {
+#ifdef _OPENMP
+        threads = omp_get_max_threads();
+#else
+        threads = 1;
+#endif
+    }
+    std::vector<Pair> sims(n);
+    int has_nan = 0;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(| : has_nan)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        float s = metric == 1 ? cgo_dot_avx2(query, rows[i], dim)
+                              : cgo_cosine_adaptive(query, rows[i], dim);
+        if (s != s) has_nan |= 1;
+        sims[i].s = s;
+        sims[i].i = (uint64_t)i;
+    }
+    if (has_nan) return -1;  // reference panics (simd_ops.rs:379)
+    parallel_sort_pairs(sims, threads);
+    uint64_t m = k < n ? k : n;
+    for (uint64_t j = 0; j < m; ++j) {
+        out_idx[j] = sims[j].i;
+        out_score[j] = sims[j].s;
+    }
+    for (uint64_t j = m; j < k; ++j) {
+        out_idx[j] = UINT64_MAX;
+        out_score[j] = -std::numeric_limits<float>::infinity();
+    }
+    return (int)m;
+}
+
+// Same, over a flat row-major matrix (convenience for tests; identical results).
+int cgo_parallel_top_k_flat(const float* query, const float* flat, uint64_t n, uint64_t dim,
+                            uint64_t k, int metric, int threads, uint64_t* out_idx,
+                            float* out_score) {
+    std::vector<const float*> rows(n);
+    for (uint64_t i = 0; i < n; ++i) rows[i] = flat + i * dim;
+    return cgo_parallel_top_k(query, rows.data(), n, dim, k, metric, threads, out_idx, out_score);
+}
+
+// The CPU-baseline layout: N separately heap-allocated rows, like the reference's
+// &[Vec<f32>] (simd_ops.rs:363). Returns an opaque handle.
+struct RowSet {
+    std::vector<float*> rows;
+    uint64_t dim;
+};
+void* cgo_rowset_create(const float* flat, uint64_t n, uint64_t dim) {
+    RowSet* rs = new RowSet();
+    rs->dim = dim;
+    rs->rows.resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        rs->rows[i] = (float*)malloc(sizeof(float) * (dim ? dim : 1));
+        memcpy(rs->rows[i], flat + i * dim, sizeof(float) * dim);
+    }
+    return rs;
+}
+void cgo_rowset_destroy(void* h) {
+    RowSet* rs = (RowSet*)h;
+    if (!rs) return;
+    for (float* p : rs->rows) free(p);
+    delete rs;
+}
+int cgo_rowset_top_k(void* h, const float* query, uint64_t k, int metric, int threads,
+                     uint64_t* out_idx, float* out_score) {
+    RowSet* rs = (RowSet*)h;
+    return cgo_parallel_top_k(query, rs->rows.data(), rs->rows.size(), rs->dim, k, metric,
+                              threads, out_idx, out_score);
+}
+
+// ---------------------------------------------------------------------------
+// RS: search.rs re-score arithmetic
+// ---------------------------------------------------------------------------
+
+// search.rs:519-533 cosine_similarity: sequential iterator sums (no FMA),
+// dot / (sqrt(na) * sqrt(nb)); zero norm -> 0.0. (The length-mismatch -> 0.0 branch
+// is the caller's concern here.) Also the formula of InMemoryVectorStore's cosine
+// (codegraph-core/src/integration/graph_vector.rs:504-516) and of the KAT helpers
+// in rag/context_retriever.rs, rag/result_ranker.rs, ml/features.rs.
+float cgo_search_cosine(const float* a, const float* b, size_t len) {
+    float dot = 0.0f, na = 0.0f, nb = 0.0f;
+    for (size_t i = 0; i < len; ++i) dot += a[i] * b[i];
+    for (size_t i = 0; i < len; ++i) na += a[i] * a[i];
+    for (size_t i = 0; i < len; ++i) nb += b[i] * b[i];
+    float norm_a = sqrtf(na), norm_b = sqrtf(nb);
+    if (norm_a == 0.0f || norm_b == 0.0f) return 0.0f;
+    return dot / (norm_a * norm_b);
+}
+
+// search.rs:113 prefetch_k = max(3*limit (saturating), limit + 10).
+uint64_t cgo_prefetch_k(uint64_t limit) {
+    uint64_t t = limit > UINT64_MAX / 3 ? UINT64_MAX : limit * 3;
+    uint64_t u = limit + 10;
+    return t > u ? t : u;
+}
+
+// search.rs:574-592 normalize_scores: min-max to [0,1], range floored at 1e-12.
+void cgo_normalize_scores(float* s, size_t n) {
+    if (n == 0) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        if (s[i] < mn) mn = s[i];
+        if (s[i] > mx) mx = s[i];
+    }
+    float range = mx - mn;
+    if (!(range > 1e-12f)) range = 1e-12f;  // f32::max(1e-12): NaN range -> 1e-12
+    for (size_t i = 0; i < n; ++i) s[i] = (s[i] - mn) / range;
+}
+
+// search.rs:119-138: exact re-score of candidate rows, STABLE sort desc
+// (partial_cmp -> Equal on NaN), truncate(limit). cand[] is the order
+// search_similar returned. Writes the surviving candidate positions and scores
+// (scores NOT yet min-max normalised). Returns count.
+uint64_t cgo_rescore_sort(const float* query, const float* const* cand_rows, uint64_t ncand,
+                          uint64_t dim, uint64_t limit, uint64_t* out_pos, float* out_score) {
+    std::vector<std::pair<float, uint64_t>> r(ncand);
+    for (uint64_t j = 0; j < ncand; ++j)
+        r[j] = {cand_rows[j] ? cgo_search_cosine(query, cand_rows[j], dim) : 0.0f, j};
+    std::stable_sort(r.begin(), r.end(),
+                     [](const std::pair<float, uint64_t>& x, const std::pair<float, uint64_t>& y) {
+                         return x.first > y.first;  // desc; NaN compares "equal"
+                     });
+    uint64_t m = limit < ncand ? limit : ncand;
+    for (uint64_t j = 0; j < m; ++j) {
+        out_pos[j] = r[j].second;
+        out_score[j] = r[j].first;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------
+// O1: ModelOptimizer::search_baseline / cosine_distance (optimization.rs:376-418)
+//   distance = 1 - dot/(sqrt(na)*sqrt(nb)); +inf on zero norm;
+//   STABLE ascending sort (ties keep input order = index asc); take(limit).
+// ---------------------------------------------------------------------------
+float cgo_cosine_distance(const float* a, const float* b, size_t len) {
+    float dot = 0.0f, na = 0.0f, nb = 0.0f;
+    for (size_t i = 0; i < len; ++i) dot += a[i] * b[i];
+    for (size_t i = 0; i < len; ++i) na += a[i] * a[i];
+    for (size_t i = 0; i < len; ++i) nb += b[i] * b[i];
+    float norm_a = sqrtf(na), norm_b = sqrtf(nb);
+    if (norm_a == 0.0f || norm_b == 0.0f) return INFINITY;
+    return 1.0f - (dot / (norm_a * norm_b));
+}
+
+uint64_t cgo_search_baseline(const float* query, const float* flat, uint64_t n, uint64_t dim,
+                             uint64_t limit, uint64_t* out_idx, float* out_dist) {
+    if (n == 0) return 0;
+    std::vector<std::pair<float, uint64_t>> d(n);
+    for (uint64_t i = 0; i < n; ++i) d[i] = {cgo_cosine_distance(query, flat + i * dim, dim), i};
+    std::stable_sort(d.begin(), d.end(),
+                     [](const std::pair<float, uint64_t>& x, const std::pair<float, uint64_t>& y) {
+                         return x.first < y.first;
+                     });
+    uint64_t m = limit < n ? limit : n;
+    for (uint64_t j = 0; j < m; ++j) {
+        out_idx[j] = d[j].second;
+        if (out_dist) out_dist[j] = d[j].first;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------
+// HE: deterministic hash embedder (search.rs:178-205 + simple_hash :535-541).
+//   djb2: h = h*33 + byte (u32 wrap, seed 5381)
+//   LCG : s = s*1103515245 + 12345 (u32 wrap) per component
+//   x   = ((s as f32 / u32::MAX as f32) - 0.5) * 2.0 ; then divide by sqrt(sum x^2)
+// `s as f32` rounds to nearest-even; `u32::MAX as f32` == 4294967296.0f.
+// ---------------------------------------------------------------------------
+uint32_t cgo_simple_hash(const uint8_t* text, size_t len) {
+    uint32_t h = 5381u;
+    for (size_t i = 0; i < len; ++i) h = h * 33u + (uint32_t)text[i];
+    return h;
+}
+
+void cgo_hash_embed(const uint8_t* text, size_t len, uint32_t dim, float* out) {
+    uint32_t s = cgo_simple_hash(text, len);
+    const float umax = (float)UINT32_MAX;  // 4294967296.0f
+    for (uint32_t i = 0; i < dim; ++i) {
+        s = s * 1103515245u + 12345u;
+        out[i] = (((float)s / umax) - 0.5f) * 2.0f;
+    }
+    float nsq = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) nsq += out[i] * out[i];
+    float norm = sqrtf(nsq);
+    if (norm > 0.0f)
+        for (uint32_t i = 0; i < dim; ++i) out[i] /= norm;
+}
+
+// ---------------------------------------------------------------------------
+// Q8: int8 path (optimization.rs:212-224 quantize_unit_range_symmetric,
+// :226-283 quantize_batch (u8 = q + 128), :63-150 search_optimized).
+// f32::round is round-half-away-from-zero == roundf.
+// ---------------------------------------------------------------------------
+void cgo_quantize_u8(const float* v, size_t len, uint8_t* out) {
+    for (size_t i = 0; i < len; ++i) {
+        float c = v[i] < -1.0f ? -1.0f : (v[i] > 1.0f ? 1.0f : v[i]);
+        int q = (int)roundf(c * 127.0f);
+        if (q < -127) q = -127;
+        if (q > 127) q = 127;
+        out[i] = (uint8_t)(q + 128);
+    }
+}
+
+uint64_t cgo_search_optimized_u8(const float* query, const uint8_t* data, uint64_t n, uint64_t dim,
+                                 uint64_t limit_in, uint64_t* out_idx) {
+    uint64_t limit = limit_in < 1 ? 1 : limit_in;
+    if (dim == 0 || n == 0) return 0;
+    std::vector<int8_t> qq(dim);
+    for (uint64_t i = 0; i < dim; ++i) {
+        float c = query[i] < -1.0f ? -1.0f : (query[i] > 1.0f ? 1.0f : query[i]);
+        int q = (int)roundf(c * 127.0f);
+        if (q < -127) q = -127;
+        if (q > 127) q = 127;
+        qq[i] = (int8_t)q;
+    }
+    float nq = 0.0f;
+    for (uint64_t i = 0; i < dim; ++i) nq += (float)qq[i] * (float)qq[i];
+    nq = sqrtf(nq);
+    if (nq == 0.0f) return 0;
+    std::vector<std::pair<uint64_t, float>> best;
+    auto asc = [](const std::pair<uint64_t, float>& x, const std::pair<uint64_t, float>& y) {
+        return x.second < y.second;
+    };
+    for (uint64_t idx = 0; idx < n; ++idx) {
+        const uint8_t* row = data + idx * dim;
+        int32_t dot = 0, nv = 0;
+        for (uint64_t j = 0; j < dim; ++j) {
+            int32_t v = (int32_t)row[j] - 128;
+            dot += v * (int32_t)qq[j];
+            nv += v * v;
+        }
+        if (nv == 0) continue;
+        float score = (float)dot / (nq * sqrtf((float)nv));
+        if (best.size() < limit) {
+            best.push_back({idx, score});
+            if (best.size() == limit) std::stable_sort(best.begin(), best.end(), asc);
+        } else if (score > best[0].second) {
+            best[0] = {idx, score};
+            std::stable_sort(best.begin(), best.end(), asc);
+        }
+    }
+    std::stable_sort(best.begin(), best.end(),
+                     [](const std::pair<uint64_t, float>& x, const std::pair<uint64_t, float>& y) {
+                         return x.second > y.second;
+                     });
+    for (size_t j = 0; j < best.size(); ++j) out_idx[j] = best[j].first;
+    return best.size();
+}
+
+// ---------------------------------------------------------------------------
+// Storage-dtype rounding (the reference has f32 only; SURVEY.md §8(c): the oracle
+// for bf16/fp16/fp8 configs is the O2 arithmetic on the rounded-then-upcast
+// values). All conversions are round-to-nearest-even.
+// ---------------------------------------------------------------------------
+static inline uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+static inline float u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+uint16_t cgo_f32_to_bf16(float f) {
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // quiet NaN
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+float cgo_bf16_to_f32(uint16_t h) { return u2f((uint32_t)h << 16); }
+
+uint16_t cgo_f32_to_f16(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT); }
+float cgo_f16_to_f32(uint16_t h) { return _cvtsh_ss(h); }
+
+// OCP FP8 E4M3FN (gfx950's format; bias 7, no inf, NaN = S.1111.111, max 448),
+// RNE, saturating to +-448 for finite inputs beyond range; NaN -> 0x7f|sign.
+uint8_t cgo_f32_to_e4m3(float f) {
+    uint32_t u = f2u(f);
+    uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint8_t)(sign | 0x7fu);  // NaN
+    float af = u2f(a);
+    if (af >= 464.0f) return (uint8_t)(sign | 0x7eu);     // >= midpoint(448,512) saturates; inf too
+    if (af < 0.0009765625f) return sign;                  // < 2^-10 = half of min subnormal 2^-9
+    // scale so that the quantum is an integer: subnormal quantum 2^-9, normal 2^(e-3)
+    int e;
+    (void)frexpf(af, &e);  // af = m * 2^e, m in [0.5,1)
+    int exp = e - 1;       // af in [2^exp, 2^(exp+1))
+    if (exp < -6) exp = -6;
+    float q = ldexpf(1.0f, exp - 3);     // quantum
+    float r = af / q;                    // exact (power of two)
+    float rr = nearbyintf(r);            // RNE under default rounding mode
+    float v = rr * q;
+    if (v > 448.0f) v = 448.0f;
+    if (v == 0.0f) return sign;
+    // encode v
+    int e2;
+    float m = frexpf(v, &e2);  // v = m*2^e2, m in [0.5,1)
+    int ex = e2 - 1;
+    if (ex < -6) {  // subnormal: v = k * 2^-9, k in 1..7
+        int k = (int)(v * 512.0f);
+        return (uint8_t)(sign | (uint8_t)k);
+    }
+    int mant = (int)((m * 2.0f - 1.0f) * 8.0f);  // exact
+    return (uint8_t)(sign | (uint8_t)((ex + 7) << 3) | (uint8_t)mant);
+}
+float cgo_e4m3_to_f32(uint8_t b) {
+    int sign = b & 0x80;
+    int ex = (b >> 3) & 0xf;
+    int mant = b & 7;
+    float v;
+    if (ex == 0xf && mant == 7)
+        v = NAN;
+    else if (ex == 0)
+        v = ldexpf((float)mant, -9);
+    else
+        v = ldexpf(1.0f + (float)mant / 8.0f, ex - 7);
+    return sign ? -v : v;
+}
+
+// Round an f32 array to `dtype` and back (0=f32 identity, 1=bf16, 2=fp16, 3=fp8e4m3).
+void cgo_round_trip(const float* in, size_t n, int dtype, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        switch (dtype) {
+            case 1: out[i] = cgo_bf16_to_f32(cgo_f32_to_bf16(in[i])); break;
+            case 2: out[i] = cgo_f16_to_f32(cgo_f32_to_f16(in[i])); break;
+            case 3: out[i] = cgo_e4m3_to_f32(cgo_f32_to_e4m3(in[i])); break;
+            default: out[i] = in[i];
+        }
+    }
+}
+
+// Merge of per-shard partial top-k lists (no reference
+// counterpart): G lists of k (score, global idx), select top-k by
+// (score desc, idx asc). Padding entries (idx == UINT64_MAX) sort last.
+void cgo_merge_topk(const uint64_t* idx, const float* score, uint64_t g, uint64_t k,
+                    uint64_t* out_idx, float* out_score) {
+    std::vector<Pair> all;
+    all.reserve(g * k);
+    for (uint64_t j = 0; j < g * k; ++j)
+        if (idx[j] != UINT64_MAX) all.push_back({score[j], idx[j]});
+    std::sort(all.begin(), all.end(), pair_before);
+    for (uint64_t j = 0; j < k; ++j) {
+        if (j < all.size()) {
+            out_idx[j] = all[j].i;
+            out_score[j] = all[j].s;
+        } else {
+            out_idx[j] = UINT64_MAX;
+            out_score[j] = -std::numeric_limits<float>::infinity();
+        }
+    }
+}
+
+int cgo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/cgv_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg — never by the product package. See the header of
+cgv_oracle.cpp for the reference file:line each function restates and for the
+pinning status of the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+F32, BF16, FP16, FP8 = 0, 1, 2, 3
+COSINE, DOT = 0, 1
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cgv_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        u64p = C.POINTER(C.c_uint64)
+        u8p = C.POINTER(C.c_uint8)
+        for name in ("cgo_cosine_avx2", "cgo_cosine_scalar", "cgo_cosine_adaptive", "cgo_dot_avx2",
+                     "cgo_l2_avx2", "cgo_search_cosine", "cgo_cosine_distance"):
+            f = getattr(L, name)
+            f.restype = C.c_float
+            f.argtypes = [fp, fp, C.c_size_t]
+        L.cgo_normalize_avx2.restype = None
+        L.cgo_normalize_avx2.argtypes = [fp, C.c_size_t]
+        L.cgo_parallel_top_k_flat.restype = C.c_int
+        L.cgo_parallel_top_k_flat.argtypes = [fp, fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                              C.c_int, u64p, fp]
+        L.cgo_rowset_create.restype = C.c_void_p
+        L.cgo_rowset_create.argtypes = [fp, C.c_uint64, C.c_uint64]
+        L.cgo_rowset_destroy.restype = None
+        L.cgo_rowset_destroy.argtypes = [C.c_void_p]
+        L.cgo_rowset_top_k.restype = C.c_int
+        L.cgo_rowset_top_k.argtypes = [C.c_void_p, fp, C.c_uint64, C.c_int, C.c_int, u64p, fp]
+        L.cgo_prefetch_k.restype = C.c_uint64
+        L.cgo_prefetch_k.argtypes = [C.c_uint64]
+        L.cgo_normalize_scores.restype = None
+        L.cgo_normalize_scores.argtypes = [fp, C.c_size_t]
+        L.cgo_search_baseline.restype = C.c_uint64
+        L.cgo_search_baseline.argtypes = [fp, fp, C.c_uint64, C.c_uint64, C.c_uint64, u64p, fp]
+        L.cgo_simple_hash.restype = C.c_uint32
+        L.cgo_simple_hash.argtypes = [C.c_char_p, C.c_size_t]
+        L.cgo_hash_embed.restype = None
+        L.cgo_hash_embed.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, fp]
+        L.cgo_quantize_u8.restype = None
+        L.cgo_quantize_u8.argtypes = [fp, C.c_size_t, u8p]
+        L.cgo_search_optimized_u8.restype = C.c_uint64
+        L.cgo_search_optimized_u8.argtypes = [fp, u8p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]
+        L.cgo_round_trip.restype = None
+        L.cgo_round_trip.argtypes = [fp, C.c_size_t, C.c_int, fp]
+        L.cgo_f32_to_e4m3.restype = C.c_uint8
+        L.cgo_f32_to_e4m3.argtypes = [C.c_float]
+        L.cgo_e4m3_to_f32.restype = C.c_float
+        L.cgo_e4m3_to_f32.argtypes = [C.c_uint8]
+        L.cgo_f32_to_bf16.restype = C.c_uint16
+        L.cgo_f32_to_bf16.argtypes = [C.c_float]
+        L.cgo_merge_topk.restype = None
+        L.cgo_merge_topk.argtypes = [u64p, fp, C.c_uint64, C.c_uint64, u64p, fp]
+        L.cgo_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pairfn(name):
+    def fn(a, b):
+        a, pa = _f(a)
+        b, pb = _f(b)
+        if a.shape != b.shape:
+            raise ValueError("dimension mismatch")  # VectorError::DimensionMismatch
+        return float(getattr(lib(), name)(pa, pb, a.size))
+    fn.__name__ = name
+    return fn
+
+
+cosine_avx2 = _pairfn("cgo_cosine_avx2")          # simd_ops.rs:15-78
+cosine_scalar = _pairfn("cgo_cosine_scalar")      # simd_ops.rs:257-278
+cosine_adaptive = _pairfn("cgo_cosine_adaptive")  # simd_ops.rs:281-295
+dot_avx2 = _pairfn("cgo_dot_avx2")                # simd_ops.rs:149-183
+l2_avx2 = _pairfn("cgo_l2_avx2")                  # simd_ops.rs:105-143
+search_cosine = _pairfn("cgo_search_cosine")      # search.rs:519-533
+cosine_distance = _pairfn("cgo_cosine_distance")  # optimization.rs:404-418
+
+
+def normalize_avx2(v):
+    """simd_ops.rs:189-222 (returns a normalised copy)."""
+    v = np.array(v, dtype=np.float32, copy=True)
+    lib().cgo_normalize_avx2(v.ctypes.data_as(C.POINTER(C.c_float)), v.size)
+    return v
+
+
+def normalize_rows(m):
+    """simd_ops.rs:386-419 parallel_normalize_vectors (AVX2 branch), row by row."""
+    m = np.array(m, dtype=np.float32, copy=True)
+    for r in m:
+        lib().cgo_normalize_avx2(r.ctypes.data_as(C.POINTER(C.c_float)), r.size)
+    return m
+
+
+def parallel_top_k(query, rows, k, metric=COSINE, threads=0):
+    """simd_ops.rs:361-383 -> (idx uint64[k], score f32[k]); ties: index asc.
+    Pads with (UINT64_MAX, -inf) when len(rows) < k. Raises on NaN (reference panics)."""
+    q, pq = _f(query)
+    r, pr = _f(rows)
+    n, d = r.shape
+    if q.size != d:
+        raise ValueError("dimension mismatch")
+    idx = np.empty(k, dtype=np.uint64)
+    sc = np.empty(k, dtype=np.float32)
+    rc = lib().cgo_parallel_top_k_flat(pq, pr, n, d, k, metric, threads,
+                                       idx.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       sc.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc < 0:
+        raise FloatingPointError("NaN similarity (reference panics at simd_ops.rs:379)")
+    return idx, sc
+
+
+def batch_top_k(queries, rows, k, metric=COSINE, threads=0, dtype=F32):
+    """N independent single-query searches (the reference's only 'batch' shape,
+    search.rs:358-361) on rounded-then-upcast inputs."""
+    qs = round_trip(queries, dtype)
+    rs = round_trip(rows, dtype)
+    idx = np.empty((qs.shape[0], k), dtype=np.uint64)
+    sc = np.empty((qs.shape[0], k), dtype=np.float32)
+    for i in range(qs.shape[0]):
+        idx[i], sc[i] = parallel_top_k(qs[i], rs, k, metric, threads)
+    return idx, sc
+
+
+class RowSet:
+    """N separately allocated f32 rows (the reference's &[Vec<f32>]); CPU-baseline layout."""
+
+    def __init__(self, rows):
+        r, pr = _f(rows)
+        self.n, self.d = r.shape
+        self._h = lib().cgo_rowset_create(pr, self.n, self.d)
+
+    def top_k(self, query, k, metric=COSINE, threads=0):
+        q, pq = _f(query)
+        idx = np.empty(k, dtype=np.uint64)
+        sc = np.empty(k, dtype=np.float32)
+        rc = lib().cgo_rowset_top_k(self._h, pq, k, metric, threads,
+                                    idx.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    sc.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc < 0:
+            raise FloatingPointError("NaN similarity")
+        return idx, sc
+
+    def close(self):
+        if self._h:
+            lib().cgo_rowset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def prefetch_k(limit):
+    return int(lib().cgo_prefetch_k(limit))  # search.rs:113
+
+
+def normalize_scores(s):
+    s = np.array(s, dtype=np.float32, copy=True)  # search.rs:574-592
+    lib().cgo_normalize_scores(s.ctypes.data_as(C.POINTER(C.c_float)), s.size)
+    return s
+
+
+def search_baseline(query, rows, limit):
+    """optimization.rs:376-402 -> (idx, distance)."""
+    q, pq = _f(query)
+    r, pr = _f(rows)
+    n, d = r.shape if r.ndim == 2 else (0, q.size)
+    idx = np.empty(max(limit, 1), dtype=np.uint64)
+    dist = np.empty(max(limit, 1), dtype=np.float32)
+    m = lib().cgo_search_baseline(pq, pr, n, d, limit, idx.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  dist.ctypes.data_as(C.POINTER(C.c_float)))
+    return idx[:m], dist[:m]
+
+
+def simple_hash(text):
+    b = text.encode("utf-8")
+    return int(lib().cgo_simple_hash(b, len(b)))  # search.rs:535-541
+
+
+def hash_embed(text, dim=384):
+    b = text.encode("utf-8")
+    out = np.empty(dim, dtype=np.float32)
+    lib().cgo_hash_embed(b, len(b), dim, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out  # search.rs:178-205
+
+
+def quantize_u8(v):
+    v, pv = _f(v)
+    out = np.empty(v.size, dtype=np.uint8)
+    lib().cgo_quantize_u8(pv, v.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.reshape(v.shape)  # optimization.rs:212-283
+
+
+def search_optimized_u8(query, data_u8, limit):
+    q, pq = _f(query)
+    d = np.ascontiguousarray(data_u8, dtype=np.uint8)
+    n, dim = d.shape
+    idx = np.empty(max(limit, 1), dtype=np.uint64)
+    m = lib().cgo_search_optimized_u8(pq, d.ctypes.data_as(C.POINTER(C.c_uint8)), n, dim, limit,
+                                      idx.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return idx[:m]  # optimization.rs:63-150
+
+
+def round_trip(a, dtype):
+    """f32 -> storage dtype (RNE) -> f32."""
+    a, pa = _f(a)
+    if dtype == F32:
+        return a
+    out = np.empty_like(a)
+    lib().cgo_round_trip(pa, a.size, dtype, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def merge_topk(idx, score, k):
+    """Merge G partial top-k lists (G,k) -> top-k by (score desc, idx asc)."""
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    g = idx.size // k
+    oi = np.empty(k, dtype=np.uint64)
+    os_ = np.empty(k, dtype=np.float32)
+    lib().cgo_merge_topk(idx.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         score.ctypes.data_as(C.POINTER(C.c_float)), g, k,
+                         oi.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         os_.ctypes.data_as(C.POINTER(C.c_float)))
+    return oi, os_
+
+
+def max_threads():
+    return int(lib().cgo_max_threads())

@@ -1,0 +1,234 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for the
+kNN hot path, and against an independent exact-rational
+restatement of the AVX2 lane order. Paths are relative to /root/reference/."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+
+# --- exact-rational emulation of f32 arithmetic (independent of the C++ oracle) ---
+def _rne_f32(fr):
+    """Round a Fraction to the nearest float32 (ties to even), exactly."""
+    if fr == 0:
+        return np.float32(0.0)
+    sign = -1 if fr < 0 else 1
+    a = abs(fr)
+    # find e with 2^e <= a < 2^(e+1)
+    e = a.numerator.bit_length() - a.denominator.bit_length()
+    if Fraction(2) ** e > a:
+        e -= 1
+    if Fraction(2) ** (e + 1) <= a:
+        e += 1
+    e = max(e, -126)
+    q = Fraction(2) ** (e - 23)  # quantum
+    n = a / q
+    fl = n.numerator // n.denominator
+    rem = n - fl
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+        fl += 1
+    return np.float32(sign * float(Fraction(fl) * q))
+
+
+def _fma(a, b, c):
+    return _rne_f32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def _add(a, b):
+    return np.float32(np.float32(a) + np.float32(b))
+
+
+def _hsum(l):  # simd_ops.rs:227-242
+    return _add(_add(_add(l[0], l[4]), _add(l[1], l[5])), _add(_add(l[2], l[6]), _add(l[3], l[7])))
+
+
+def cosine_avx2_exact(a, b):  # simd_ops.rs:15-78, restated with exact-rational FMA
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    n = len(a)
+    dp = [np.float32(0)] * 8
+    na = [np.float32(0)] * 8
+    nb = [np.float32(0)] * 8
+    for i in range(n // 8):
+        for l in range(8):
+            x, y = a[8 * i + l], b[8 * i + l]
+            dp[l] = _fma(x, y, dp[l])
+            na[l] = _fma(x, x, na[l])
+            nb[l] = _fma(y, y, nb[l])
+    d, p, q = _hsum(dp), _hsum(na), _hsum(nb)
+    dr = pr = qr = np.float32(0)
+    for i in range(n // 8 * 8, n):
+        dr = _add(dr, np.float32(a[i] * b[i]))
+        pr = _add(pr, np.float32(a[i] * a[i]))
+        qr = _add(qr, np.float32(b[i] * b[i]))
+    d, p, q = _add(d, dr), _add(p, pr), _add(q, qr)
+    npd = np.sqrt(np.float32(p * q))
+    return np.float32(0) if npd == 0 else np.float32(d / npd)
+
+
+def test_kat_simd_cosine_similarity(oracle):
+    # crates/codegraph-vector/src/simd_ops.rs:429-447 (a=[1..8], b=[8..1]; scalar vs AVX2 1e-6)
+    a = np.arange(1, 9, dtype=np.float32)
+    b = a[::-1].copy()
+    s = oracle.cosine_scalar(a, b)
+    v = oracle.cosine_avx2(a, b)
+    assert abs(s - v) <= 1e-6
+    assert abs(s - 120.0 / 204.0) <= 1e-6
+
+
+def test_kat_adaptive_similarity(oracle):
+    # simd_ops.rs:450-459 (range only)
+    a = np.arange(100, dtype=np.float32)
+    b = (100 - np.arange(100)).astype(np.float32)
+    r = oracle.cosine_adaptive(a, b)
+    assert -1.0 <= r <= 1.0
+    # adaptive dispatch rule (simd_ops.rs:281-295): AVX2 iff len >= 32
+    assert r == oracle.cosine_avx2(a, b)
+    assert oracle.cosine_adaptive(a[:31], b[:31]) == oracle.cosine_scalar(a[:31], b[:31])
+
+
+def test_kat_parallel_operations(oracle):
+    # simd_ops.rs:462-472: query=[1.0;256], rows[i][j]=(i+j), k=10 -> reference asserts len()==10;
+    # the derivable true answer is rows 999..990 (cosine = mean/rms grows with i).
+    q = np.ones(256, dtype=np.float32)
+    rows = (np.arange(1000)[:, None] + np.arange(256)[None, :]).astype(np.float32)
+    idx, sc = oracle.parallel_top_k(q, rows, 10)
+    assert len(idx) == 10
+    assert idx.tolist() == list(range(999, 989, -1))
+    assert np.all(np.diff(sc) <= 0)
+
+
+@pytest.mark.parametrize("fn", ["search_cosine", "cosine_scalar", "cosine_avx2"])
+def test_kat_basis_vectors(oracle, fn):
+    # rag/context_retriever.rs:505-512, rag/result_ranker.rs:598-605, ml/features.rs:481-489
+    v1 = np.array([1, 0, 0], np.float32)
+    v3 = np.array([0, 1, 0], np.float32)
+    f = getattr(oracle, fn)
+    assert abs(f(v1, v1) - 1.0) < 1e-6
+    assert abs(f(v1, v3) - 0.0) < 1e-6
+
+
+def test_avx2_lane_order_vs_exact_rational(oracle):
+    rng = np.random.default_rng(7)
+    for n in (8, 32, 40, 77, 384):
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        assert oracle.cosine_avx2(a, b) == float(cosine_avx2_exact(a, b)), n
+
+
+def test_scalar_vs_avx2_differ_only_in_last_bits(oracle):
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal(768).astype(np.float32)
+    b = rng.standard_normal(768).astype(np.float32)
+    assert abs(oracle.cosine_scalar(a, b) - oracle.cosine_avx2(a, b)) < 1e-6
+    assert abs(oracle.search_cosine(a, b) - oracle.cosine_avx2(a, b)) < 1e-6
+
+
+def test_zero_and_empty(oracle):
+    z = np.zeros(64, np.float32)
+    x = np.ones(64, np.float32)
+    assert oracle.cosine_avx2(z, x) == 0.0        # simd_ops.rs:73-74
+    assert oracle.cosine_scalar(z, x) == 0.0
+    assert oracle.search_cosine(z, x) == 0.0      # search.rs:528-529
+    assert oracle.cosine_distance(z, x) == float("inf")  # optimization.rs:413-415
+    assert oracle.cosine_avx2(np.zeros(0, np.float32), np.zeros(0, np.float32)) == 0.0
+
+
+def test_nan_panics(oracle):
+    q = np.ones(32, np.float32)
+    rows = np.ones((4, 32), np.float32)
+    rows[2, 5] = np.nan
+    with pytest.raises(FloatingPointError):
+        oracle.parallel_top_k(q, rows, 2)     # simd_ops.rs:379 partial_cmp().unwrap()
+
+
+def test_top_k_ties_index_ascending_and_padding(oracle):
+    q = np.ones(32, np.float32)
+    rows = np.ones((5, 32), np.float32)
+    idx, sc = oracle.parallel_top_k(q, rows, 8)
+    assert idx[:5].tolist() == [0, 1, 2, 3, 4]
+    assert np.all(idx[5:] == np.uint64(2**64 - 1)) and np.all(np.isneginf(sc[5:]))
+
+
+def test_normalize_avx2(oracle):
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(100).astype(np.float32)
+    n = oracle.normalize_avx2(v)
+    assert abs(float(np.sqrt((n.astype(np.float64) ** 2).sum())) - 1.0) < 1e-6
+    assert np.array_equal(oracle.normalize_avx2(np.zeros(16, np.float32)), np.zeros(16, np.float32))
+    # reciprocal-multiply (simd_ops.rs:203-214), not divide
+    nsq = np.float32(oracle.dot_avx2(v, v))
+    inv = np.float32(1.0) / np.sqrt(nsq)
+    assert np.array_equal(n, v * inv)
+
+
+def test_prefetch_rule_and_minmax(oracle):
+    assert oracle.prefetch_k(10) == 30 and oracle.prefetch_k(1) == 11 and oracle.prefetch_k(5) == 15
+    s = oracle.normalize_scores([0.2, 0.5, 0.8])
+    assert s[0] == 0.0 and s[2] == 1.0 and abs(s[1] - 0.5) < 1e-6
+    assert np.array_equal(oracle.normalize_scores([0.3, 0.3]), np.zeros(2, np.float32))  # range floor 1e-12
+
+
+def test_search_baseline_stable(oracle):
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((50, 16)).astype(np.float32)
+    rows[7] = rows[3]
+    q = rows[3].copy()
+    idx, dist = oracle.search_baseline(q, rows, 5)
+    assert idx[0] == 3 and idx[1] == 7  # stable: equal distances keep index order
+    assert np.all(np.diff(dist) >= 0)
+
+
+def test_hash_embedder(oracle):
+    # search.rs:535-541 djb2; known value: "a" -> 5381*33+97
+    assert oracle.simple_hash("a") == (5381 * 33 + 97) & 0xFFFFFFFF
+    e = oracle.hash_embed("sum two numbers", 384)
+    assert e.shape == (384,)
+    assert abs(float(np.sqrt((e.astype(np.float64) ** 2).sum())) - 1.0) < 1e-5
+    assert np.array_equal(e, oracle.hash_embed("sum two numbers", 384))
+    # independent restatement of the LCG
+    s = oracle.simple_hash("node_1")
+    xs = []
+    for _ in range(8):
+        s = (s * 1103515245 + 12345) & 0xFFFFFFFF
+        xs.append((np.float32(np.float32(s) / np.float32(4294967295)) - np.float32(0.5)) * np.float32(2.0))
+    raw = np.array(xs, np.float32)
+    e8 = oracle.hash_embed("node_1", 8)
+    nsq = np.float32(0)
+    for x in raw:
+        nsq = np.float32(nsq + np.float32(x * x))
+    assert np.array_equal(e8, raw / np.sqrt(nsq))
+
+
+def test_int8_path_agreement(oracle):
+    # tests/model_optimization_tests.rs:347-427 gate: int8 search_optimized vs search_baseline
+    # top-10 positional agreement >= 0.8 on 1000x128 vectors in [-1,1]
+    rng = np.random.default_rng(42)
+    rows = rng.uniform(-1, 1, (1000, 128)).astype(np.float32)
+    q = rows[17] + 0.05 * rng.standard_normal(128).astype(np.float32)
+    base, _ = oracle.search_baseline(q, rows, 10)
+    opt = oracle.search_optimized_u8(q, oracle.quantize_u8(rows), 10)
+    agree = sum(int(a == b) for a, b in zip(base, opt)) / 10.0
+    assert agree >= 0.8
+
+
+def test_dtype_round_trips(oracle):
+    import torch
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 0.05,
+                        rng.standard_normal(512).astype(np.float32) * 100,
+                        np.array([0.0, -0.0, 1.0, 448.0, 449.0, 463.9, 464.0, 1e9, 2.0**-9, 2.0**-10,
+                                  1.5 * 2.0**-10, 2.0**-7, 0.017, 1e-30], np.float32)])
+    t = torch.from_numpy(x)
+    assert np.array_equal(oracle.round_trip(x, oracle.BF16), t.to(torch.bfloat16).float().numpy())
+    assert np.array_equal(oracle.round_trip(x, oracle.FP16), t.to(torch.float16).float().numpy())
+    got = oracle.round_trip(x, oracle.FP8)
+    ref = t.clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()  # torch cast: RNE, no saturation
+    assert np.array_equal(got, ref)
+
+
+def test_merge_topk(oracle):
+    idx = np.array([[5, 9, 2**64 - 1], [1, 7, 3]], dtype=np.uint64)
+    sc = np.array([[0.9, 0.5, -np.inf], [0.9, 0.6, 0.1]], dtype=np.float32)
+    oi, os_ = oracle.merge_topk(idx, sc, 3)
+    assert oi.tolist() == [1, 5, 7] and np.allclose(os_, [0.9, 0.9, 0.6])
