@@ -1,0 +1,243 @@
+"""ctypes binding of libcgvec_hip.so (C ABI in include/cgvec.h).
+
+Plumbing only: device memory comes from PyTorch tensors (or the library's own staging
+for host arrays); all compute is in the HIP library. There is no CPU fallback — if the
+shared library is missing or no MI355X is visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcgvec_hip.so")
+
+METRICS = {"cosine": 0, "dot": 1}
+DTYPES = {"f32": 0, "bf16": 1, "fp16": 2}
+
+CGV_OK = 0
+CGV_ERR_INVALID_ARG, CGV_ERR_DIM_MISMATCH, CGV_ERR_HIP, CGV_ERR_OOM = 1, 2, 3, 4
+CGV_ERR_NONFINITE, CGV_ERR_OUT_OF_RANGE, CGV_ERR_INTERNAL = 5, 6, 7
+PAD_IDX = np.uint64(2**64 - 1)
+
+
+class CgvError(RuntimeError):
+    """Mirrors CodeGraphError::Vector(String) (crates/codegraph-core/src/error.rs:17-18)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"cgvec status {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_uint64), ("device_bytes", C.c_uint64), ("searches", C.c_uint64),
+        ("queries", C.c_uint64), ("fallback_queries", C.c_uint64), ("overflow_queries", C.c_uint64),
+        ("last_eps", C.c_float), ("max_observed_err", C.c_float), ("last_coarse_ms", C.c_float),
+        ("last_total_ms", C.c_float), ("coarse_rows", C.c_uint64), ("last_kprime", C.c_uint32),
+        ("last_path", C.c_uint32),
+    ]
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))
+    else:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not built. Run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for this library.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.cgv_version.restype = u32
+    L.cgv_last_error.restype = C.c_char_p
+    L.cgv_device_count.restype = i32
+    L.cgv_create.argtypes = [u32, i32, i32, i32, C.POINTER(vp)]
+    L.cgv_destroy.argtypes = [vp]
+    L.cgv_reserve.argtypes = [vp, u64]
+    L.cgv_add_f32.argtypes = [vp, vp, u64]
+    L.cgv_add_f32_dev.argtypes = [vp, vp, u64]
+    L.cgv_count.argtypes = [vp]
+    L.cgv_count.restype = u64
+    L.cgv_dim.argtypes = [vp]
+    L.cgv_dim.restype = u32
+    L.cgv_set_index_base.argtypes = [vp, u64]
+    L.cgv_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
+    L.cgv_search_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp]
+    L.cgv_get_row_f32.argtypes = [vp, u64, vp]
+    L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.cgv_set_stream.argtypes = [vp, vp]
+    L.cgv_synchronize.argtypes = [vp]
+    L.cgv_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.cgv_set_profiling.argtypes = [vp, i32]
+    L.cgv_set_force_exact.argtypes = [vp, i32]
+    L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
+    for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
+                 "cgv_set_index_base", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
+                 "cgv_merge_topk_dev", "cgv_set_stream", "cgv_synchronize", "cgv_get_stats",
+                 "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != CGV_OK:
+        raise CgvError(rc, lib().cgv_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(lib().cgv_device_count())
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class HipKnnIndex:
+    """One device-resident corpus shard + batched kNN over it.
+
+    Host mirror of what the reference's `SurrealVectorBackend` / `VectorStore` seam needs from
+    a backend (crates/codegraph-vector/src/surreal_store.rs:11-22; crates/codegraph-core/src/
+    traits.rs:11-16): add rows (store_embeddings/upsert_nodes), search (search_similar/
+    vector_knn), get_row (get_embedding/get_node_embedding). Row id = insertion index.
+    """
+
+    def __init__(self, dim, metric="cosine", dtype="bf16", device=0):
+        self._h = C.c_void_p()
+        self.dim, self.metric, self.dtype, self.device = int(dim), metric, dtype, int(device)
+        _check(lib().cgv_create(self.dim, METRICS[metric], DTYPES[dtype], self.device, C.byref(self._h)))
+
+    # -- lifecycle ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().cgv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib().cgv_count(self._h))
+
+    def reserve(self, n):
+        _check(lib().cgv_reserve(self._h, int(n)))
+
+    def set_index_base(self, base):
+        _check(lib().cgv_set_index_base(self._h, int(base)))
+
+    def set_stream(self, stream_ptr):
+        _check(lib().cgv_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_profiling(self, on=True):
+        _check(lib().cgv_set_profiling(self._h, 1 if on else 0))
+
+    def set_force_exact(self, on=True):
+        _check(lib().cgv_set_force_exact(self._h, 1 if on else 0))
+
+    def synchronize(self):
+        _check(lib().cgv_synchronize(self._h))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().cgv_get_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    # -- data --------------------------------------------------------------------
+    def add(self, rows):
+        if _is_torch(rows):
+            import torch
+            if rows.dim() != 2 or rows.shape[1] != self.dim:
+                raise CgvError(CGV_ERR_DIM_MISMATCH, f"expected [n,{self.dim}] rows, got {tuple(rows.shape)}")
+            if not rows.is_cuda:
+                return self.add(rows.detach().float().numpy())
+            r = rows.detach().to(torch.float32).contiguous()
+            self.use_torch_stream()
+            _check(lib().cgv_add_f32_dev(self._h, C.c_void_p(r.data_ptr()), r.shape[0]))
+            return
+        r = np.ascontiguousarray(rows, dtype=np.float32)
+        if r.ndim != 2 or r.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"expected [n,{self.dim}] rows, got {r.shape}")
+        _check(lib().cgv_add_f32(self._h, r.ctypes.data_as(C.c_void_p), r.shape[0]))
+
+    def get_row(self, i):
+        out = np.empty(self.dim, dtype=np.float32)
+        _check(lib().cgv_get_row_f32(self._h, int(i), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def search(self, queries, k):
+        """queries [nq, dim] -> (idx uint64 [nq,k], score f32 [nq,k]); numpy in -> numpy out,
+        CUDA tensor in -> CUDA tensors out (idx as int64 view of the uint64 ids)."""
+        k = int(k)
+        if _is_torch(queries) and queries.is_cuda:
+            import torch
+            if queries.dim() != 2 or queries.shape[1] != self.dim:
+                raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {tuple(queries.shape)} != {self.dim}")
+            q = queries.detach().to(torch.float32).contiguous()
+            nq = q.shape[0]
+            self.use_torch_stream()  # same stream as the producer of `queries`
+            idx = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            sc = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            if nq and k:
+                _check(lib().cgv_search_f32_dev(self._h, C.c_void_p(q.data_ptr()), nq, k,
+                                                C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr())))
+            return idx, sc
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {q.shape} != {self.dim}")
+        nq = q.shape[0]
+        idx = np.empty((nq, k), dtype=np.uint64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        if nq and k:
+            _check(lib().cgv_search_f32(self._h, q.ctypes.data_as(C.c_void_p), nq, k,
+                                        idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
+        return idx, sc
+
+    def debug_coarse_scores(self, queries):
+        """Dense approximate (MFMA) scores [nq, n] as a CUDA tensor — test hook."""
+        import torch
+        q = queries.detach().to(torch.float32).contiguous()
+        out = torch.full((q.shape[0], len(self)), float("nan"), dtype=torch.float32, device=q.device)
+        self.use_torch_stream()
+        _check(lib().cgv_debug_coarse_scores_dev(self._h, C.c_void_p(q.data_ptr()), q.shape[0],
+                                                 C.c_void_p(out.data_ptr())))
+        return out
+
+
+def merge_topk(idx, score, device=None):
+    """[g, nq, k] CUDA tensors (idx int64 view of uint64 ids) -> merged [nq, k]."""
+    import torch
+    if device is None:
+        device = idx.device.index or 0
+    g, nq, k = idx.shape
+    idx = idx.contiguous()
+    score = score.contiguous()
+    oi = torch.empty((nq, k), dtype=torch.int64, device=idx.device)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=idx.device)
+    stream = torch.cuda.current_stream(idx.device).cuda_stream
+    _check(lib().cgv_merge_topk_dev(device, C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()), g, nq, k,
+                                    C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(stream)))
+    return oi, os_

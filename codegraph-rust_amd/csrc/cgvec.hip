@@ -1,0 +1,811 @@
+// cgvec.hip — C ABI (include/cgvec.h) + host orchestration of the kNN pipeline.
+//
+// Pipeline of one batched search (bf16/fp16 corpus):
+//   prep_rows(queries)                         round queries to the storage dtype, norms
+//   [stage 1] coarse(tiles [0,T1), tau=-inf) -> select      k' candidates + first tau
+//   [stage 2] coarse(strided sample, tau)    -> select      tighter tau from ~3% of the rows
+//   [stage 3] coarse(all other tiles, tau)   -> select      DOMINANT KERNEL (MFMA GEMM)
+//   rescore                                    exact reference arithmetic on k' candidates,
+//                                              (score desc, row asc), guarantee check
+//   [fallback] exact full scan for queries whose candidate set could not be proven.
+// f32 corpora (the reference's native layout) take the exact full-scan path directly.
+//
+// There is NO CPU fallback anywhere in this file: without a HIP device every entry
+// point that needs one fails with CGV_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cgvec.h"
+#include "common.h"
+#include "kernels_coarse.h"
+#include "kernels_exact.h"
+#include "kernels_prep.h"
+#include "kernels_select.h"
+
+using namespace cgv;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(_e == hipErrorOutOfMemory ? CGV_ERR_OOM : CGV_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return CGV_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e != hipSuccess) return fail(CGV_ERR_OOM, "hipMalloc scratch: " + std::string(hipGetErrorString(e)));
+        bytes = want;
+        return CGV_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_COUNT = 8 };
+
+constexpr int BM = 256, BN = 256;  // coarse tile (corpus rows x queries)
+
+uint32_t esize_of(int dtype) { return dtype == CGV_DTYPE_F32 ? 4u : (dtype == CGV_DTYPE_FP8E4M3 ? 1u : 2u); }
+
+uint32_t kprime_of(uint32_t k) {
+    uint32_t m = std::max<uint32_t>(6u, k / 8u);
+    return ((k + m + 7u) / 8u) * 8u;
+}
+
+}  // namespace
+
+struct cgv_index {
+    int device = 0;
+    uint32_t D = 0, ld = 0;
+    int metric = 0, dtype = 0;
+    uint32_t esize = 2;
+    uint64_t n = 0, cap = 0, index_base = 0;
+    char* rows = nullptr;
+    float* norm = nullptr;
+    float* invn = nullptr;
+    float* blk_min = nullptr;
+    float* blk_max = nullptr;
+    uint32_t* flags = nullptr;    // device, F_COUNT words
+    float* max_norm_dev = nullptr;
+    uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_cu = 256;
+    bool corpus_nonfinite = false;
+    float max_norm_c = 0.0f;
+    DevBuf qstage, qrows, qnorm, qinvn, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt,
+        scores, keysA, keysB, outidx, outscore, addstage, dump;
+    std::mutex mu;
+    bool profiling = false, force_exact = false;
+    cgv_stats st;
+    uint64_t last_coarse_rows = 0;
+    cgv_index() { memset(&st, 0, sizeof(st)); }
+};
+
+namespace {
+
+size_t device_bytes(const cgv_index* h) {
+    size_t b = 0;
+    if (h->rows) b += (size_t)h->cap * h->ld * h->esize + (size_t)h->cap * 8 + ((size_t)h->cap / 32 + 1) * 8;
+    const DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best,
+                            &h->overflow, &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores,
+                            &h->keysA, &h->keysB, &h->outidx, &h->outscore, &h->addstage, &h->dump};
+    for (const DevBuf* d : bufs) b += d->bytes;
+    return b;
+}
+
+template <int DT>
+void launch_prep(const float* in, uint64_t n, uint32_t D, uint32_t ld, char* out, float* norm,
+                 float* invn, uint32_t* nonfinite, hipStream_t s) {
+    if (n == 0) return;
+    uint64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(prep_rows_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, s, in, n, D, ld, out,
+                       norm, invn, nonfinite);
+}
+
+int prep_dispatch(int dtype, const float* in, uint64_t n, uint32_t D, uint32_t ld, char* out,
+                  float* norm, float* invn, uint32_t* nonfinite, hipStream_t s) {
+    switch (dtype) {
+        case CGV_DTYPE_F32: launch_prep<DT_F32>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_BF16: launch_prep<DT_BF16>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_FP16: launch_prep<DT_FP16>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
+        default: return fail(CGV_ERR_INVALID_ARG, "dtype not supported by this build");
+    }
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+int grow(cgv_index* h, uint64_t need) {
+    if (need <= h->cap) return CGV_OK;
+    if (need > 0xFFFFFF00ull) return fail(CGV_ERR_INVALID_ARG, "more than 2^32-256 rows per device index");
+    uint64_t ncap = std::max<uint64_t>(need, h->cap + h->cap / 2);
+    ncap = std::max<uint64_t>(ncap, 1024);
+    ncap = (ncap + 255) / 256 * 256;
+    char* rows = nullptr;
+    float *norm = nullptr, *invn = nullptr, *bmin = nullptr, *bmax = nullptr;
+    size_t rb = (size_t)ncap * h->ld * h->esize;
+    size_t nblk = (size_t)ncap / 32 + 1;
+    HIPCHK(hipMalloc((void**)&rows, rb));
+    HIPCHK(hipMalloc((void**)&norm, ncap * 4));
+    HIPCHK(hipMalloc((void**)&invn, ncap * 4));
+    HIPCHK(hipMalloc((void**)&bmin, nblk * 4));
+    HIPCHK(hipMalloc((void**)&bmax, nblk * 4));
+    if (h->n) {
+        HIPCHK(hipMemcpyAsync(rows, h->rows, (size_t)h->n * h->ld * h->esize, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(norm, h->norm, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(invn, h->invn, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
+        size_t ob = (size_t)(h->n + 31) / 32;
+        HIPCHK(hipMemcpyAsync(bmin, h->blk_min, ob * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(bmax, h->blk_max, ob * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (h->rows) {
+        (void)hipFree(h->rows);
+        (void)hipFree(h->norm);
+        (void)hipFree(h->invn);
+        (void)hipFree(h->blk_min);
+        (void)hipFree(h->blk_max);
+    }
+    h->rows = rows;
+    h->norm = norm;
+    h->invn = invn;
+    h->blk_min = bmin;
+    h->blk_max = bmax;
+    h->cap = ncap;
+    return CGV_OK;
+}
+
+int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
+    if (cnt == 0) return CGV_OK;
+    int rc = grow(h, h->n + cnt);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->rows + (size_t)h->n * h->ld * h->esize,
+                       h->norm + h->n, h->invn + h->n, h->flags + F_NONFINITE_C, s);
+    if (rc) return rc;
+    const uint64_t n_new = h->n + cnt;
+    const uint64_t b0 = h->n / 32, b1 = (n_new + 31) / 32;
+    hipLaunchKernelGGL(block_norm_stats_kernel, dim3((unsigned)((b1 - b0 + 255) / 256)), dim3(256), 0, s,
+                       h->norm, n_new, b0, b1, h->blk_min, h->blk_max);
+    hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, h->n, n_new, h->max_norm_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->n = n_new;
+    memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
+    if (h->h_flags[F_NONFINITE_C]) {
+        h->corpus_nonfinite = true;
+        return fail(CGV_ERR_NONFINITE,
+                    "corpus rows contain NaN/Inf (the reference panics on NaN at simd_ops.rs:379)");
+    }
+    return CGV_OK;
+}
+
+template <int DT, int TBM, int TBN, int WM, int WN, bool DUMP>
+int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(TBM + TBN) * 128 + (size_t)TBN * 4;
+    static bool attr_set = false;
+    auto kern = coarse_kernel<DT, TBM, TBN, WM, WN, DUMP>;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(W), dim3(WM * WN * 64), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    if (dtype == CGV_DTYPE_BF16)
+        return dump ? launch_coarse_t<DT_BF16, BM, BN, 2, 4, true>(a, W, s)
+                    : launch_coarse_t<DT_BF16, BM, BN, 2, 4, false>(a, W, s);
+    if (dtype == CGV_DTYPE_FP16)
+        return dump ? launch_coarse_t<DT_FP16, BM, BN, 2, 4, true>(a, W, s)
+                    : launch_coarse_t<DT_FP16, BM, BN, 2, 4, false>(a, W, s);
+    return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
+}
+
+int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime, hipStream_t s) {
+    SelectArgs sa;
+    sa.cand = h->cand.as<uint2>();
+    sa.cand_cnt = h->candcnt.as<uint32_t>();
+    sa.best = h->best.as<uint64_t>();
+    sa.nbest = h->nbest.as<uint32_t>();
+    sa.tau = h->tau.as<float>();
+    sa.overflow = h->overflow.as<uint32_t>();
+    sa.nq = nq;
+    sa.nqt = nqt;
+    sa.nsplit = nsplit;
+    sa.bn = BN;
+    sa.kprime = kprime;
+    const size_t lds = (size_t)SELECT_LDS_KEYS * 8 + ((size_t)nsplit + 1) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(SELECT_LDS_KEYS * 8 + 65536)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), lds, s, sa);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+template <int DT>
+void launch_exact_scores(cgv_index* h, const uint32_t* qlist, uint32_t nql, float* scores, hipStream_t s) {
+    uint64_t gx = ((uint64_t)h->n + 31) / 32;
+    if (gx > 16384) gx = 16384;
+    hipLaunchKernelGGL(exact_scores_kernel<DT>, dim3((unsigned)gx, nql), dim3(256), 0, s, h->rows,
+                       h->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, h->metric, scores);
+}
+
+// Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
+int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
+                 float* out_score, hipStream_t s) {
+    const uint64_t n = h->n;
+    const uint32_t K = next_pow2(std::max<uint32_t>(k, 2));
+    uint64_t qg = std::max<uint64_t>(1, (512ull << 20) / (n * 4));
+    qg = std::min<uint64_t>(qg, nql);
+    qg = std::min<uint64_t>(qg, 65535);
+    int rc;
+    if ((rc = h->scores.ensure((size_t)qg * n * 4))) return rc;
+    const uint32_t nch0 = (uint32_t)((n + TOPK_CHUNK - 1) / TOPK_CHUNK);
+    if ((rc = h->keysA.ensure((size_t)qg * nch0 * K * 8))) return rc;
+    if ((rc = h->keysB.ensure((size_t)qg * ((size_t)nch0 * K / TOPK_CHUNK + 1) * K * 8))) return rc;
+    for (uint32_t q0 = 0; q0 < nql; q0 += (uint32_t)qg) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(qg, nql - q0);
+        const uint32_t* ql = qlist_dev + q0;
+        float* sc = h->scores.as<float>();
+        switch (h->dtype) {
+            case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, ql, g, sc, s); break;
+            case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, ql, g, sc, s); break;
+            case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, ql, g, sc, s); break;
+            default: return fail(CGV_ERR_INTERNAL, "exact path: unsupported dtype");
+        }
+        uint64_t* cur = h->keysA.as<uint64_t>();
+        uint64_t* nxt = h->keysB.as<uint64_t>();
+        uint32_t nch = nch0;
+        hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch, g), dim3(256), 0, s, sc, (const uint64_t*)nullptr,
+                           (uint32_t)n, K, cur, h->flags + F_NAN);
+        while (nch > 1) {
+            const uint32_t M = nch * K;
+            const uint32_t nch2 = (M + TOPK_CHUNK - 1) / TOPK_CHUNK;
+            hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch2, g), dim3(256), 0, s, (const float*)nullptr,
+                               (const uint64_t*)cur, M, K, nxt, h->flags + F_NAN);
+            std::swap(cur, nxt);
+            nch = nch2;
+        }
+        hipLaunchKernelGGL(emit_topk_kernel, dim3((g * k + 255) / 256), dim3(256), 0, s, (const uint64_t*)cur,
+                           K, k, ql, g, h->index_base, out_idx, out_score);
+        HIPCHK(hipGetLastError());
+    }
+    return CGV_OK;
+}
+
+__global__ void iota_kernel(uint32_t* p, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        idx[i] = UINT64_MAX;
+        sc[i] = -INFINITY;
+    }
+}
+
+struct StagePlan {
+    uint32_t ntiles, T1, stride, cnt2, cnt3;
+};
+
+StagePlan plan_stages(uint64_t n, uint32_t kprime) {
+    StagePlan p;
+    p.ntiles = (uint32_t)((n + BM - 1) / BM);
+    p.T1 = std::min<uint32_t>((kprime + BM - 1) / BM, p.ntiles);
+    const uint32_t R = p.ntiles - p.T1;
+    if (R >= 96) {
+        p.stride = 32;
+        p.cnt2 = (R + p.stride - 1) / p.stride;
+        p.cnt3 = R - p.cnt2;
+    } else {
+        p.stride = 0;
+        p.cnt2 = 0;
+        p.cnt3 = R;
+    }
+    return p;
+}
+
+int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, uint64_t* out_idx,
+                      float* out_score) {
+    hipStream_t s = h->stream;
+    int rc;
+    h->st.searches++;
+    h->st.queries += nq;
+    if (h->n == 0) {
+        uint64_t tot = (uint64_t)nq * k;
+        hipLaunchKernelGGL(pad_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, out_idx,
+                           out_score, tot);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return CGV_OK;
+    }
+    if (h->corpus_nonfinite)
+        return fail(CGV_ERR_NONFINITE, "index holds NaN/Inf rows (the reference panics at simd_ops.rs:379)");
+
+    if (h->profiling) HIPCHK(hipEventRecord(h->ev[0], s));
+    // --- queries: round to storage dtype, norms ---
+    if ((rc = h->qrows.ensure((size_t)nq * h->ld * h->esize))) return rc;
+    if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->fbflag.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->qlist.ensure((size_t)nq * 4))) return rc;
+    HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
+    rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, h->qrows.as<char>(), h->qnorm.as<float>(),
+                       h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+    if (rc) return rc;
+
+    const uint32_t kprime = kprime_of(k);
+    const bool mfma = !h->force_exact && (h->dtype == CGV_DTYPE_BF16 || h->dtype == CGV_DTYPE_FP16) &&
+                      kprime <= CAND_CAPS;
+    h->st.last_path = mfma ? 1u : 0u;
+    h->st.last_kprime = mfma ? kprime : 0u;
+    h->st.last_coarse_ms = 0.0f;
+    h->last_coarse_rows = 0;
+    bool timed_coarse = false;
+
+    if (mfma) {
+        const uint32_t nqt = (nq + BN - 1) / BN;
+        const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
+        const StagePlan p = plan_stages(h->n, kprime);
+        const uint32_t Wmax = nqt * nsplit_max;
+        if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
+        if ((rc = h->nbest.ensure((size_t)nq * 4))) return rc;
+        if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
+        if ((rc = h->best.ensure((size_t)nq * kprime * 8))) return rc;
+        if ((rc = h->cand.ensure((size_t)Wmax * BN * CAND_CAPS * 8))) return rc;
+        if ((rc = h->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->tau.as<float>(),
+                           -INFINITY, nq);
+        HIPCHK(hipMemsetAsync(h->nbest.p, 0, (size_t)nq * 4, s));
+        HIPCHK(hipMemsetAsync(h->overflow.p, 0, (size_t)nq * 4, s));
+
+        CoarseArgs a;
+        a.rows = h->rows;
+        a.qrows = h->qrows.as<char>();
+        a.invn_c = h->invn;
+        a.invn_q = h->qinvn.as<float>();
+        a.blk_min = h->blk_min;
+        a.blk_max = h->blk_max;
+        a.tau = h->tau.as<float>();
+        a.cand = h->cand.as<uint2>();
+        a.cand_cnt = h->candcnt.as<uint32_t>();
+        a.overflow = h->overflow.as<uint32_t>();
+        a.dump = nullptr;
+        a.n = (uint32_t)h->n;
+        a.nq = nq;
+        a.ld = h->ld;
+        a.kc = h->ld / 64;
+        a.T1 = p.T1;
+        a.stride = p.stride;
+        a.nqt = nqt;
+        a.metric = h->metric;
+        const uint32_t counts[3] = {p.T1, p.cnt2, p.cnt3};
+        for (int st = 1; st <= 3; ++st) {
+            const uint32_t cnt = counts[st - 1];
+            if (cnt == 0) continue;
+            a.stage = (uint32_t)st;
+            a.cnt = cnt;
+            a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
+            const bool dominant = (st == 3) || (p.cnt3 == 0 && st == 1);
+            if (h->profiling && dominant) HIPCHK(hipEventRecord(h->ev[1], s));
+            if ((rc = launch_coarse(h->dtype, false, a, nqt * a.nsplit, s))) return rc;
+            if (h->profiling && dominant) {
+                HIPCHK(hipEventRecord(h->ev[2], s));
+                timed_coarse = true;
+                h->last_coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
+            }
+            if ((rc = launch_select(h, nq, nqt, a.nsplit, kprime, s))) return rc;
+        }
+        RescoreArgs r;
+        r.best = h->best.as<uint64_t>();
+        r.nbest = h->nbest.as<uint32_t>();
+        r.tau = h->tau.as<float>();
+        r.rows = h->rows;
+        r.qrows = h->qrows.as<char>();
+        r.norm_q = h->qnorm.as<float>();
+        r.overflow = h->overflow.as<uint32_t>();
+        r.out_idx = out_idx;
+        r.out_score = out_score;
+        r.fb_flag = h->fbflag.as<uint32_t>();
+        r.fb_count = h->flags + F_FB_COUNT;
+        r.stat_maxerr = h->flags + F_MAXERR;
+        r.index_base = h->index_base;
+        r.nq = nq;
+        r.n = (uint32_t)h->n;
+        r.D = h->D;
+        r.ld = h->ld;
+        r.kprime = kprime;
+        r.k = k;
+        r.metric = h->metric;
+        r.eps_scale = 8.0f * (float)h->D * 5.9604645e-8f + 1e-7f;
+        r.max_norm_c = h->max_norm_c;
+        h->st.last_eps = r.eps_scale;
+        if (h->dtype == CGV_DTYPE_BF16)
+            hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), 0, s, r);
+        else
+            hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), 0, s, r);
+        HIPCHK(hipGetLastError());
+    }
+    if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
+    HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->h_flags[F_NONFINITE_Q])
+        return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
+
+    if (!mfma) {
+        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->qlist.as<uint32_t>(), nq);
+        if ((rc = exact_search(h, h->qlist.as<uint32_t>(), nq, k, out_idx, out_score, s))) return rc;
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        float me;
+        memcpy(&me, &h->h_flags[F_MAXERR], 4);
+        h->st.max_observed_err = std::max(h->st.max_observed_err, me);
+        const uint32_t nfb = h->h_flags[F_FB_COUNT];
+        if (nfb > 0) {
+            h->st.fallback_queries += nfb;
+            hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
+                               h->fbflag.as<uint32_t>(), nq, h->qlist.as<uint32_t>(), h->flags + F_COMPACT);
+            if ((rc = exact_search(h, h->qlist.as<uint32_t>(), nfb, k, out_idx, out_score, s))) return rc;
+            if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+    if (h->profiling) {
+        float ms = 0.0f;
+        if (timed_coarse && hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->st.last_coarse_ms = ms;
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[3]) == hipSuccess) h->st.last_total_ms = ms;
+    }
+    return CGV_OK;
+}
+
+float host_f16_to_f32(uint16_t b) {
+    uint32_t sign = (uint32_t)(b & 0x8000u) << 16;
+    uint32_t ex = (b >> 10) & 0x1f, man = b & 0x3ffu;
+    uint32_t u;
+    if (ex == 0) {
+        if (man == 0) {
+            u = sign;
+        } else {
+            int e = -1;
+            do {
+                man <<= 1;
+                ++e;
+            } while (!(man & 0x400u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (ex == 31) {
+        u = sign | 0x7f800000u | (man << 13);
+    } else {
+        u = sign | ((ex + 112) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t cgv_version(void) { return (0u << 16) | 1u; }
+
+const char* cgv_last_error(void) { return g_err.c_str(); }
+
+int cgv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** out) {
+    if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (dim == 0 || dim > 8192) return fail(CGV_ERR_INVALID_ARG, "dim must be in 1..=8192");
+    if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT) return fail(CGV_ERR_INVALID_ARG, "bad metric");
+    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16)
+        return fail(CGV_ERR_INVALID_ARG, "dtype not supported by this build (f32, bf16, fp16)");
+    int ndev = cgv_device_count();
+    if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(CGV_ERR_INVALID_ARG, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    cgv_index* h = new cgv_index();
+    h->device = device_id;
+    h->D = dim;
+    h->ld = (dim + 63) / 64 * 64;
+    h->metric = metric;
+    h->dtype = dtype;
+    h->esize = esize_of(dtype);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        h->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->flags, F_COUNT * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->max_norm_dev, 4);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, (F_COUNT + 1) * 4);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+    if (e == hipSuccess) e = hipMemset(h->flags, 0, F_COUNT * 4);
+    if (e == hipSuccess) e = hipMemset(h->max_norm_dev, 0, 4);
+    if (e != hipSuccess) {
+        std::string m = hipGetErrorString(e);
+        cgv_destroy(h);
+        return fail(CGV_ERR_HIP, "cgv_create: " + m);
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return CGV_OK;
+}
+
+int cgv_destroy(cgv_index* h) {
+    if (!h) return CGV_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->rows) {
+        (void)hipFree(h->rows);
+        (void)hipFree(h->norm);
+        (void)hipFree(h->invn);
+        (void)hipFree(h->blk_min);
+        (void)hipFree(h->blk_max);
+    }
+    DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best, &h->overflow,
+                      &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores, &h->keysA, &h->keysB,
+                      &h->outidx, &h->outscore, &h->addstage, &h->dump};
+    for (DevBuf* d : bufs) d->release();
+    if (h->flags) (void)hipFree(h->flags);
+    if (h->max_norm_dev) (void)hipFree(h->max_norm_dev);
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return CGV_OK;
+}
+
+int cgv_reserve(cgv_index* h, uint64_t n_rows) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    return grow(h, n_rows);
+}
+
+int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (n && !rows_dev) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    return add_dev_locked(h, rows_dev, n);
+}
+
+int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (n && !rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    int rc = grow(h, h->n + n);
+    if (rc) return rc;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)h->D * 4));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
+        if ((rc = h->addstage.ensure((size_t)c * h->D * 4))) return rc;
+        HIPCHK(hipMemcpyAsync(h->addstage.p, rows_host + r0 * h->D, (size_t)c * h->D * 4, hipMemcpyHostToDevice,
+                              h->stream));
+        if ((rc = add_dev_locked(h, h->addstage.as<float>(), c))) return rc;
+    }
+    return CGV_OK;
+}
+
+uint64_t cgv_count(const cgv_index* h) { return h ? h->n : 0; }
+uint32_t cgv_dim(const cgv_index* h) { return h ? h->D : 0; }
+
+int cgv_set_index_base(cgv_index* h, uint64_t base) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    h->index_base = base;
+    return CGV_OK;
+}
+
+int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint64_t* out_idx_dev,
+                       float* out_score_dev) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || k == 0) return CGV_OK;  // surreal_store.rs:62-64
+    if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
+    if (!queries_dev || !out_idx_dev || !out_score_dev) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    return search_dev_locked(h, queries_dev, nq, k, out_idx_dev, out_score_dev);
+}
+
+int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
+                   float* out_score_host) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || k == 0) return CGV_OK;
+    if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
+    if (!queries_host || !out_idx_host || !out_score_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->qstage.ensure((size_t)nq * h->D * 4))) return rc;
+    if ((rc = h->outidx.ensure((size_t)nq * k * 8))) return rc;
+    if ((rc = h->outscore.ensure((size_t)nq * k * 4))) return rc;
+    HIPCHK(hipMemcpyAsync(h->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, h->stream));
+    if ((rc = search_dev_locked(h, h->qstage.as<float>(), nq, k, h->outidx.as<uint64_t>(), h->outscore.as<float>())))
+        return rc;
+    HIPCHK(hipMemcpyAsync(out_idx_host, h->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out_score_host, h->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGV_OK;
+}
+
+int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
+    if (!h || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<char> tmp((size_t)h->D * h->esize);
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->rows + (size_t)id * h->ld * h->esize, tmp.size(), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < h->D; ++i) {
+        if (h->dtype == CGV_DTYPE_F32)
+            out_host[i] = ((const float*)tmp.data())[i];
+        else if (h->dtype == CGV_DTYPE_BF16)
+            out_host[i] = bf16_to_f32(((const uint16_t*)tmp.data())[i]);
+        else
+            out_host[i] = host_f16_to_f32(((const uint16_t*)tmp.data())[i]);
+    }
+    return CGV_OK;
+}
+
+int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t g, uint32_t nq,
+                       uint32_t k, uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
+    if (nq == 0 || k == 0) return CGV_OK;
+    if (!idx_dev || !score_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
+    if ((uint64_t)g * k > 4096) return fail(CGV_ERR_INVALID_ARG, "g*k exceeds 4096");
+    HIPCHK(hipSetDevice(device_id));
+    const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream, idx_dev,
+                       score_dev, g, nq, k, out_idx_dev, out_score_dev);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+int cgv_set_stream(cgv_index* h, void* stream) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return CGV_OK;
+}
+
+int cgv_synchronize(cgv_index* h) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGV_OK;
+}
+
+int cgv_get_stats(cgv_index* h, cgv_stats* out) {
+    if (!h || !out) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->st.n_rows = h->n;
+    h->st.device_bytes = device_bytes(h);
+    *out = h->st;
+    out->coarse_rows = h->last_coarse_rows;
+    return CGV_OK;
+}
+
+int cgv_set_profiling(cgv_index* h, int enabled) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    h->profiling = enabled != 0;
+    return CGV_OK;
+}
+
+int cgv_set_force_exact(cgv_index* h, int enabled) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    h->force_exact = enabled != 0;
+    return CGV_OK;
+}
+
+int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t nq, float* out_dev) {
+    if (!h || !queries_dev || !out_dev) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    if (h->dtype != CGV_DTYPE_BF16 && h->dtype != CGV_DTYPE_FP16)
+        return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16 index");
+    if (nq == 0 || h->n == 0) return CGV_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = h->qrows.ensure((size_t)nq * h->ld * h->esize))) return rc;
+    if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
+    rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, h->qrows.as<char>(), h->qnorm.as<float>(),
+                       h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+    if (rc) return rc;
+    const uint32_t nqt = (nq + BN - 1) / BN;
+    const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
+    const uint32_t ntiles = (uint32_t)((h->n + BM - 1) / BM);
+    const uint32_t nsplit = std::min(ntiles, nsplit_max);
+    if ((rc = h->cand.ensure((size_t)nqt * nsplit * BN * CAND_CAPS * 8))) return rc;
+    if ((rc = h->candcnt.ensure((size_t)nqt * nsplit * BN * 4))) return rc;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->tau.as<float>(), -INFINITY, nq);
+    CoarseArgs a;
+    a.rows = h->rows;
+    a.qrows = h->qrows.as<char>();
+    a.invn_c = h->invn;
+    a.invn_q = h->qinvn.as<float>();
+    a.blk_min = h->blk_min;
+    a.blk_max = h->blk_max;
+    a.tau = h->tau.as<float>();
+    a.cand = h->cand.as<uint2>();
+    a.cand_cnt = h->candcnt.as<uint32_t>();
+    a.overflow = h->overflow.as<uint32_t>();
+    a.dump = out_dev;
+    a.n = (uint32_t)h->n;
+    a.nq = nq;
+    a.ld = h->ld;
+    a.kc = h->ld / 64;
+    a.stage = 1;
+    a.T1 = ntiles;
+    a.stride = 0;
+    a.cnt = ntiles;
+    a.nsplit = nsplit;
+    a.nqt = nqt;
+    a.metric = h->metric;
+    if ((rc = launch_coarse(h->dtype, true, a, nqt * nsplit, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    return CGV_OK;
+}
+
+}  // extern "C"

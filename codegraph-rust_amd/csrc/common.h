@@ -1,0 +1,199 @@
+// common.h — shared device helpers for libcgvec_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cgv {
+
+constexpr int DT_F32 = 0, DT_BF16 = 1, DT_FP16 = 2, DT_FP8 = 3;
+constexpr int METRIC_COSINE = 0, METRIC_DOT = 1;
+
+// ---- sortable keys: larger key == better (score desc, row asc) -----------------
+__host__ __device__ inline uint32_t f2ord(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline uint64_t make_key(float s, uint32_t row) {
+    s = s + 0.0f;  // -0.0 -> +0.0 so that equal scores tie-break on the row id
+    return ((uint64_t)f2ord(s) << 32) | (uint64_t)(uint32_t)(~row);
+}
+__host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
+__host__ __device__ inline uint32_t key_row(uint64_t k) { return ~(uint32_t)k; }
+
+// ---- storage dtype conversion (round-to-nearest-even) ---------------------------
+__host__ __device__ inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__device__ inline uint16_t f32_to_f16_rne(float f) {
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE, overflow -> inf
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+__device__ inline float f16_to_f32(uint16_t b) {
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+template <int DT>
+struct Elem;
+template <>
+struct Elem<DT_F32> {
+    static constexpr int bytes = 4;
+    static __device__ inline float load(const char* p, uint32_t i) { return ((const float*)p)[i]; }
+    static __device__ inline void store(char* p, uint32_t i, float x) { ((float*)p)[i] = x; }
+    static __device__ inline float round_trip(float x) { return x; }
+};
+template <>
+struct Elem<DT_BF16> {
+    static constexpr int bytes = 2;
+    static __device__ inline float load(const char* p, uint32_t i) {
+        return bf16_to_f32(((const uint16_t*)p)[i]);
+    }
+    static __device__ inline void store(char* p, uint32_t i, float x) {
+        ((uint16_t*)p)[i] = f32_to_bf16_rne(x);
+    }
+    static __device__ inline float round_trip(float x) { return bf16_to_f32(f32_to_bf16_rne(x)); }
+};
+template <>
+struct Elem<DT_FP16> {
+    static constexpr int bytes = 2;
+    static __device__ inline float load(const char* p, uint32_t i) {
+        return f16_to_f32(((const uint16_t*)p)[i]);
+    }
+    static __device__ inline void store(char* p, uint32_t i, float x) {
+        ((uint16_t*)p)[i] = f32_to_f16_rne(x);
+    }
+    static __device__ inline float round_trip(float x) { return f16_to_f32(f32_to_f16_rne(x)); }
+};
+
+// ---- the reference's exact f32 arithmetic ---------------------------------------
+// One similarity is evaluated by a group of 8 consecutive lanes; lane l of the group
+// plays AVX2 lane l of the reference's __m256 accumulators
+// (crates/codegraph-vector/src/simd_ops.rs:15-78): it sums elements i == l (mod 8)
+// sequentially with fused FMA; the group then reproduces horizontal_sum_avx2
+// (simd_ops.rs:227-242): ((l0+l4)+(l1+l5))+((l2+l6)+(l3+l7)); lane 0 adds the
+// scalar tail (D mod 8, separate mul/add rounding) and finishes
+// dp / sqrt(na_sq*nb_sq). The library is compiled with -ffp-contract=off so only the
+// explicit fmaf() calls fuse; sqrt and divide are IEEE correctly rounded
+// (-fhip-fp32-correctly-rounded-divide-sqrt).
+// The result is valid on lane 0 of each group.
+__device__ inline float group8_hsum(float v) {
+    float x = v + __shfl_down(v, 4, 8);   // lanes 0..3: l0+l4, l1+l5, l2+l6, l3+l7
+    float y = x + __shfl_down(x, 1, 8);   // lane 0: (l0+l4)+(l1+l5); lane 2: (l2+l6)+(l3+l7)
+    float z = y + __shfl_down(y, 2, 8);   // lane 0: full tree
+    return z;
+}
+
+template <int DT>
+__device__ inline float exact_cosine_group8(const char* q, const char* c, uint32_t D, int l) {
+    float result = 0.0f;
+    if (D >= 32) {  // adaptive_cosine_similarity dispatch, simd_ops.rs:281-295
+        float dp = 0.0f, na = 0.0f, nb = 0.0f;
+        const uint32_t chunks = D / 8;
+        for (uint32_t j = 0; j < chunks; ++j) {
+            float x = Elem<DT>::load(q, 8 * j + l);
+            float y = Elem<DT>::load(c, 8 * j + l);
+            dp = fmaf(x, y, dp);
+            na = fmaf(x, x, na);
+            nb = fmaf(y, y, nb);
+        }
+        dp = group8_hsum(dp);
+        na = group8_hsum(na);
+        nb = group8_hsum(nb);
+        if (l == 0) {
+            float dr = 0.0f, ar = 0.0f, br = 0.0f;
+            for (uint32_t i = chunks * 8; i < D; ++i) {
+                float x = Elem<DT>::load(q, i), y = Elem<DT>::load(c, i);
+                dr = dr + x * y;
+                ar = ar + x * x;
+                br = br + y * y;
+            }
+            float fd = dp + dr, fa = na + ar, fb = nb + br;
+            float np = sqrtf(fa * fb);
+            result = (np == 0.0f) ? 0.0f : fd / np;
+        }
+    } else if (l == 0) {  // cosine_similarity_scalar, simd_ops.rs:257-278
+        float dp = 0.0f, na = 0.0f, nb = 0.0f;
+        for (uint32_t i = 0; i < D; ++i) {
+            float x = Elem<DT>::load(q, i), y = Elem<DT>::load(c, i);
+            dp = dp + x * y;
+            na = na + x * x;
+            nb = nb + y * y;
+        }
+        float np = sqrtf(na * nb);
+        result = (np == 0.0f) ? 0.0f : dp / np;
+    }
+    return result;
+}
+
+template <int DT>
+__device__ inline float exact_dot_group8(const char* q, const char* c, uint32_t D, int l) {
+    // dot_product_avx2, simd_ops.rs:149-183
+    float dp = 0.0f;
+    const uint32_t chunks = D / 8;
+    for (uint32_t j = 0; j < chunks; ++j)
+        dp = fmaf(Elem<DT>::load(q, 8 * j + l), Elem<DT>::load(c, 8 * j + l), dp);
+    dp = group8_hsum(dp);
+    float result = 0.0f;
+    if (l == 0) {
+        float r = 0.0f;
+        for (uint32_t i = chunks * 8; i < D; ++i) r = r + Elem<DT>::load(q, i) * Elem<DT>::load(c, i);
+        result = (D == 0) ? 0.0f : dp + r;
+    }
+    return result;
+}
+
+template <int DT>
+__device__ inline float exact_score_group8(int metric, const char* q, const char* c, uint32_t D,
+                                           int l) {
+    return metric == METRIC_DOT ? exact_dot_group8<DT>(q, c, D, l)
+                                : exact_cosine_group8<DT>(q, c, D, l);
+}
+
+// In-LDS bitonic sort, descending, P a power of two, NT threads.
+template <int NT>
+__device__ inline void bitonic_sort_desc(uint64_t* keys, uint32_t P, int tid) {
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P; i += NT) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = keys[i], b = keys[ixj];
+                    bool desc_blk = ((i & k2) == 0);
+                    if (desc_blk ? (a < b) : (a > b)) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__host__ __device__ inline uint32_t next_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace cgv

@@ -1,0 +1,93 @@
+// kernels_exact.h — exact full-scan path: every (query, row) similarity evaluated with
+// the reference's own f32 operation order (common.h), then an exact top-k.
+// Used (a) for CGV_DTYPE_F32 corpora — the reference's native Vec<f32> layout
+// (BASELINE config C1), (b) as the fallback when the coarse pass cannot PROVE its
+// candidate set (guarantee check in rescore_kernel), (c) for tiny corpora.
+// HBM/L2-bound VALU work; deliberately not reshaped into a GEMM: the serial FMA chain
+// per AVX lane is the contract.
+#pragma once
+#include "common.h"
+
+namespace cgv {
+
+// scores[qi][row] for qi in [0, nql): query index = qlist ? qlist[qi] : qi.
+// Block = 256 threads = 32 groups of 8 lanes; group <-> one corpus row per step.
+template <int DT>
+__global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restrict__ rows,
+                                                           const char* __restrict__ qrows,
+                                                           const uint32_t* __restrict__ qlist,
+                                                           uint32_t nql, uint32_t n, uint32_t D,
+                                                           uint32_t ld, int metric,
+                                                           float* __restrict__ scores) {
+    const int tid = threadIdx.x;
+    const int grp = tid >> 3, l = tid & 7;
+    const uint64_t eb = (uint64_t)Elem<DT>::bytes * ld;
+    const uint32_t qi = blockIdx.y;
+    const uint32_t q = qlist ? qlist[qi] : qi;
+    const char* qp = qrows + (uint64_t)q * eb;
+    for (uint64_t row = (uint64_t)blockIdx.x * 32 + grp; row < n; row += (uint64_t)gridDim.x * 32) {
+        const float s = exact_score_group8<DT>(metric, qp, rows + row * eb, D, l);
+        if (l == 0) scores[(uint64_t)qi * n + row] = s;
+    }
+}
+
+constexpr uint32_t TOPK_CHUNK = 4096;
+
+// Level-0: chunk of f32 scores -> sorted top-K keys. Level>0: chunk of keys -> top-K keys.
+// grid = (nchunks, nql). out[qi][chunk][K].
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ scores,
+                                                         const uint64_t* __restrict__ in_keys,
+                                                         uint32_t M, uint32_t K,
+                                                         uint64_t* __restrict__ out,
+                                                         uint32_t* __restrict__ nan_flag) {
+    __shared__ uint64_t keys[TOPK_CHUNK];
+    const int tid = threadIdx.x;
+    const uint32_t chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x;
+    const uint64_t base = (uint64_t)chunk * TOPK_CHUNK;
+    for (uint32_t i = tid; i < TOPK_CHUNK; i += 256) {
+        const uint64_t e = base + i;
+        uint64_t key = 0ull;
+        if (e < M) {
+            if (scores) {
+                const float s = scores[(uint64_t)qi * M + e];
+                if (s != s) *nan_flag = 1u;
+                key = make_key(s, (uint32_t)e);
+            } else {
+                key = in_keys[(uint64_t)qi * M + e];
+            }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc<256>(keys, TOPK_CHUNK, tid);
+    for (uint32_t j = tid; j < K; j += 256) out[((uint64_t)qi * nchunks + chunk) * K + j] = keys[j];
+}
+
+// Final keys [nql][K] -> caller's out arrays at query slot qlist[qi] (or qi).
+__global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, uint32_t k,
+                                 const uint32_t* __restrict__ qlist, uint32_t nql,
+                                 uint64_t index_base, uint64_t* __restrict__ out_idx,
+                                 float* __restrict__ out_score) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nql * k) return;
+    const uint32_t qi = i / k, j = i % k;
+    const uint32_t q = qlist ? qlist[qi] : qi;
+    const uint64_t key = keys[(uint64_t)qi * K + j];
+    uint64_t oi = UINT64_MAX;
+    float os = -INFINITY;
+    if (key != 0ull) {
+        oi = index_base + key_row(key);
+        os = key_score(key);
+    }
+    out_idx[(uint64_t)q * k + j] = oi;
+    out_score[(uint64_t)q * k + j] = os;
+}
+
+// Compact the flagged query ids: qlist[0..count) (order irrelevant).
+__global__ void compact_flags_kernel(const uint32_t* __restrict__ flag, uint32_t nq,
+                                     uint32_t* __restrict__ qlist, uint32_t* __restrict__ count) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq && flag[q]) qlist[atomicAdd(count, 1u)] = q;
+}
+
+}  // namespace cgv

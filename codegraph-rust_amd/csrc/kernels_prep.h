@@ -1,0 +1,89 @@
+// kernels_prep.h — ingest: f32 rows -> storage dtype (RNE) + per-row norms.
+// HBM-bound streaming kernels: one wave per row, coalesced 4-byte lanes.
+// Replaces the host-side work of store_embeddings / upload_vectors
+// (crates/codegraph-core/src/traits.rs:13; crates/codegraph-vector/src/gpu.rs:221-246)
+// and the normalise step of parallel_normalize_vectors (simd_ops.rs:386-419) — the
+// corpus is NOT rewritten to unit length (chunk-mean rows are left
+// un-normalised by the reference), the inverse norm is kept beside it instead.
+#pragma once
+#include "common.h"
+
+namespace cgv {
+
+// in: [n][D] f32. out rows: [n][ld] storage dtype, zero padded to ld (multiple of 64).
+// norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
+// coarse pass), invn[r] = 1/norm or 0. nonfinite: set to 1 if any input is NaN/Inf.
+template <int DT>
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ in, uint64_t n,
+                                                        uint32_t D, uint32_t ld,
+                                                        char* __restrict__ out,
+                                                        float* __restrict__ norm,
+                                                        float* __restrict__ invn,
+                                                        uint32_t* __restrict__ nonfinite) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* src = in + row * (uint64_t)D;
+    char* dst = out + row * (uint64_t)ld * Elem<DT>::bytes;
+    float ss = 0.0f;
+    int bad = 0;
+    for (uint32_t i = lane; i < ld; i += 64) {
+        float x = (i < D) ? src[i] : 0.0f;
+        if (!(fabsf(x) <= 3.402823466e38f)) bad = 1;  // NaN or Inf
+        Elem<DT>::store(dst, i, x);
+        float xr = Elem<DT>::round_trip(x);
+        ss = fmaf(xr, xr, ss);
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) {
+        float nr = sqrtf(ss);
+        norm[row] = nr;
+        invn[row] = nr > 0.0f ? 1.0f / nr : 0.0f;
+    }
+    if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
+}
+
+// Per aligned 32-row block: min and max row norm over the valid rows (used by the
+// conservative fast filter of the coarse kernel's epilogue).
+__global__ __launch_bounds__(256) void block_norm_stats_kernel(const float* __restrict__ norm,
+                                                               uint64_t n, uint64_t blk0,
+                                                               uint64_t blk1,
+                                                               float* __restrict__ blk_min,
+                                                               float* __restrict__ blk_max) {
+    uint64_t b = blk0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= blk1) return;
+    float mn = 3.402823466e38f, mx = 0.0f;
+    for (int i = 0; i < 32; ++i) {
+        uint64_t r = b * 32 + i;
+        if (r < n) {
+            float v = norm[r];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    }
+    blk_min[b] = mn;
+    blk_max[b] = mx;
+}
+
+// max over all rows of norm (dot-product error bound); single block, grid-stride.
+__global__ __launch_bounds__(1024) void max_norm_kernel(const float* __restrict__ norm, uint64_t n0,
+                                                        uint64_t n1, float* __restrict__ out_max) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (uint64_t i = n0 + threadIdx.x; i < n1; i += 1024) m = fmaxf(m, norm[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = *out_max;
+        for (int i = 0; i < 16; ++i) r = fmaxf(r, red[i]);
+        *out_max = r;
+    }
+}
+
+__global__ void fill_f32_kernel(float* p, float v, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace cgv

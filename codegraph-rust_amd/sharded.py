@@ -1,0 +1,55 @@
+"""Row-sharded kNN across ranks (one process per GPU, torch.distributed; backend "nccl"
+is RCCL on ROCm). SURVEY.md §8(e): the corpus is split into contiguous row ranges, every
+rank searches its shard with the full query batch, the per-shard partial top-k
+(nq*k (id, score) records per rank) are exchanged with ONE all-gather, and every rank
+merges G*k candidates per query with (score desc, id asc). Exact: the global top-k is a
+subset of the union of the local top-k.
+
+The reference has no distributed path (no collective anywhere); this is the
+multi-GPU extension BASELINE.json's north_star asks for.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous rows [lo, hi) of rank `rank`: ceil(N/G) rows per rank (last may be short)."""
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+class ShardedKnn:
+    """`local` is any object with search(queries, k) -> (idx int64[nq,k], score f32[nq,k]) whose
+    ids are already GLOBAL (HipKnnIndex.set_index_base(lo)); `merge` maps gathered
+    [G,nq,k] tensors to [nq,k] (default: the HIP merge kernel through the C ABI)."""
+
+    def __init__(self, local, rank=None, world=None, group=None, merge=None):
+        self.local = local
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        if merge is None:
+            from .cgvec import merge_topk
+            merge = merge_topk
+        self.merge = merge
+
+    def search(self, queries, k):
+        idx, score = self.local.search(queries, k)
+        if self.world == 1:
+            return idx, score
+        nq = idx.shape[0]
+        # ONE all-gather of nq*k packed 12-byte records (8 B id + 4 B score) per rank:
+        # latency-bound (<= 1 MiB per rank at nq=8192, k=10), so a single collective.
+        rec = torch.cat([idx.contiguous().view(torch.int32).reshape(nq, 2 * k),
+                         score.contiguous().view(torch.int32).reshape(nq, k)], dim=1).contiguous()
+        gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=rec.device)
+        if dist.get_backend(self.group) == "gloo":  # CPU tests
+            parts = [gathered[r] for r in range(self.world)]
+            dist.all_gather(parts, rec, group=self.group)
+        else:
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+        g_idx = gathered[:, :, : 2 * k].contiguous().view(torch.int64).reshape(self.world, nq, k)
+        g_score = gathered[:, :, 2 * k:].contiguous().view(torch.float32).reshape(self.world, nq, k)
+        return self.merge(g_idx, g_score)

@@ -1,0 +1,176 @@
+/* cgvec.h — C ABI of libcgvec_hip.so: MI355X-native brute-force kNN for CodeGraph.
+ *
+ * This is the drop-in boundary for the CPU kNN of the reference's `codegraph-vector`
+ * crate. The reference is pure Rust with no FFI; these entry points
+ * are what a Rust `HipKnnBackend: SurrealVectorBackend + VectorStore` shim binds (the
+ * shim source is in INTEGRATION.md). Each entry cites the reference interface it
+ * replaces (paths relative to the reference repo).
+ *
+ * Conventions (mirroring codegraph_core::Result / CodeGraphError::Vector(String),
+ * crates/codegraph-core/src/error.rs:17-18):
+ *   - every call returns an int status (CGV_OK == 0); cgv_last_error() returns a
+ *     thread-local, NUL-terminated message for the last non-zero status;
+ *   - degenerate inputs succeed with empty results (nq == 0, k == 0, empty index),
+ *     as surreal_store.rs:62-64 does; dimension mismatch is an error
+ *     (simd_ops.rs:16-18);
+ *   - the caller owns every host/device buffer passed in or out; the handle owns all
+ *     device memory it allocates; nothing panics or aborts across the boundary;
+ *   - row id = insertion index (0-based, + index_base); the NodeId<->row-id map stays
+ *     on the caller's side (cf. persistent.rs:492 vector_id_mapping);
+ *   - results are ordered (score desc, row id asc) — a valid outcome of the
+ *     reference's unstable parallel sort (simd_ops.rs:379) and of its stable sorts
+ *     (optimization.rs:395, search.rs:132);
+ *   - scores are the reference's own f32 arithmetic (simd_ops.rs:15-78 cosine /
+ *     :149-183 dot) evaluated on the stored (rounded-to-dtype, then upcast) values,
+ *     reproduced bit-for-bit by the exact re-score kernel;
+ *   - short results are padded with (UINT64_MAX, -inf).
+ *
+ * Threading: cgv_search_* may be called concurrently on one handle (serialised
+ * internally); cgv_add_* / cgv_reserve / cgv_destroy need exclusive access — the same
+ * contract as the reference's `tokio::sync::Mutex<SurrealDbStorage>` (surreal_store.rs:
+ * 45-47) plus `&mut self` on store_embeddings (traits.rs:13).
+ */
+#ifndef CGVEC_H
+#define CGVEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cgv_index cgv_index; /* opaque handle */
+
+/* similarity metric */
+#define CGV_METRIC_COSINE 0 /* SIMDVectorOps::adaptive_cosine_similarity, simd_ops.rs:281-295 */
+#define CGV_METRIC_DOT 1    /* SIMDVectorOps::dot_product_avx2, simd_ops.rs:149-183 */
+
+/* storage dtype of the corpus in HBM (queries are rounded to the same dtype) */
+#define CGV_DTYPE_F32 0     /* the reference's own Vec<f32> (node.rs:14) */
+#define CGV_DTYPE_BF16 1
+#define CGV_DTYPE_FP16 2
+#define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale */
+
+/* status codes */
+#define CGV_OK 0
+#define CGV_ERR_INVALID_ARG 1
+#define CGV_ERR_DIM_MISMATCH 2 /* VectorError::DimensionMismatch, error.rs:5-6 */
+#define CGV_ERR_HIP 3          /* HIP runtime failure / no MI355X visible */
+#define CGV_ERR_OOM 4
+#define CGV_ERR_NONFINITE 5    /* NaN/Inf in corpus or query: the reference panics (simd_ops.rs:379) */
+#define CGV_ERR_OUT_OF_RANGE 6 /* VectorError::IndexOutOfBounds, error.rs:14-15 */
+#define CGV_ERR_INTERNAL 7
+
+#define CGV_MAX_K 256u
+
+/* Library/ABI version (major<<16 | minor). */
+uint32_t cgv_version(void);
+
+/* Thread-local message for the last failing call on this thread ("" if none). */
+const char* cgv_last_error(void);
+
+/* Number of HIP devices visible (0 when none; never fails). */
+int cgv_device_count(void);
+
+/* Create an empty index on one device.
+ * Replaces: GpuAcceleration::new + set_device (gpu.rs:109-131,…; a mock in the
+ * reference) and the construction of a SurrealVectorBackend (surreal_store.rs:32-34).
+ * dim in 1..=8192 (config.rs:221-224). */
+int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** out);
+
+/* Free all device memory. Replaces GpuAcceleration::deallocate (gpu.rs). */
+int cgv_destroy(cgv_index* h);
+
+/* Pre-size the corpus allocation for n_rows rows (optional; add grows geometrically). */
+int cgv_reserve(cgv_index* h, uint64_t n_rows);
+
+/* Append n rows (flat row-major f32 [n][dim], HOST memory). Rows are rounded
+ * (RNE) to the storage dtype on device; per-row inverse norms are computed there.
+ * Replaces: VectorStore::store_embeddings (traits.rs:13) /
+ * SurrealVectorBackend::upsert_nodes (surreal_store.rs:13) /
+ * GpuAcceleration::upload_vectors (gpu.rs:221-246: flat &[f32] + dimension). */
+int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n);
+
+/* Same, rows already in DEVICE memory of this index's device. */
+int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n);
+
+/* Number of rows stored / dimension / dtype / metric. */
+uint64_t cgv_count(const cgv_index* h);
+uint32_t cgv_dim(const cgv_index* h);
+
+/* Added to every row id this index reports (global id = index_base + local row);
+ * used when the corpus is row-sharded across devices. */
+int cgv_set_index_base(cgv_index* h, uint64_t base);
+
+/* Batched kNN: nq queries (flat f32 [nq][dim], HOST), top-k each.
+ * out_idx / out_score: HOST arrays of nq*k entries, row-major per query.
+ * Replaces: ParallelVectorOps::parallel_top_k_search (simd_ops.rs:361-383) per query;
+ * SurrealVectorBackend::vector_knn (surreal_store.rs:14-20) — the shim reports
+ * distance = 1 - score; and the N-independent-searches batch of
+ * SemanticSearch::multi_vector_search (search.rs:358-361). */
+int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k,
+                   uint64_t* out_idx_host, float* out_score_host);
+
+/* Same with DEVICE pointers for queries and outputs (results stay in HBM; the call
+ * returns after the work is enqueued and the exactness check has been read back). */
+int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
+                       uint64_t* out_idx_dev, float* out_score_dev);
+
+/* Copy stored row `id` (local id, without index_base) back as f32 (upcast of the
+ * stored value). Replaces VectorStore::get_embedding (traits.rs:15) /
+ * SurrealVectorBackend::get_node_embedding (surreal_store.rs:21). */
+int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host);
+
+/* Merge G partial top-k lists per query on device `device_id` (the step after the
+ * all-gather of per-shard partial results): inputs are
+ * [g][nq][k] (idx u64, score f32) DEVICE arrays, outputs [nq][k], ordered
+ * (score desc, idx asc); padding entries (UINT64_MAX) sort last. `stream` is a
+ * hipStream_t (NULL = default stream). */
+int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t g,
+                       uint32_t nq, uint32_t k, uint64_t* out_idx_dev, float* out_score_dev,
+                       void* stream);
+
+/* Run this handle's work on an external hipStream_t (e.g. PyTorch's current stream).
+ * NULL restores the handle's own stream. */
+int cgv_set_stream(cgv_index* h, void* stream);
+
+/* Block until all work enqueued by this handle has finished.
+ * Replaces GpuAcceleration::synchronize (gpu.rs). */
+int cgv_synchronize(cgv_index* h);
+
+/* Observability (cf. GpuAcceleration::get_memory_stats, gpu.rs; PerformanceMonitor). */
+typedef struct cgv_stats {
+    uint64_t n_rows;
+    uint64_t device_bytes;        /* HBM held by the handle */
+    uint64_t searches;            /* cgv_search_* calls */
+    uint64_t queries;             /* total queries */
+    uint64_t fallback_queries;    /* queries re-run through the exact full scan */
+    uint64_t overflow_queries;    /* subset of the above caused by candidate-list overflow */
+    float last_eps;               /* error bound used by the exactness check (score units) */
+    float max_observed_err;       /* max |coarse - exact| seen on re-scored candidates */
+    float last_coarse_ms;         /* HIP-event time of the dominant (MFMA coarse) kernel, last search;
+                                     valid when profiling is on */
+    float last_total_ms;          /* HIP-event time of the whole device pipeline, last search */
+    uint64_t coarse_rows;         /* corpus rows covered by the timed coarse launch (last search) */
+    uint32_t last_kprime;         /* candidates re-scored per query */
+    uint32_t last_path;           /* 0 = exact scan, 1 = MFMA coarse + exact re-score */
+} cgv_stats;
+int cgv_get_stats(cgv_index* h, cgv_stats* out);
+
+/* Enable (1) / disable (0) HIP-event timing of each search (adds two event records
+ * around the dominant kernel on the stream it is launched on). */
+int cgv_set_profiling(cgv_index* h, int enabled);
+
+/* Tuning knob for tests: force the exact full-scan path (1) or auto (0). */
+int cgv_set_force_exact(cgv_index* h, int enabled);
+
+/* Debug/validation: dense coarse scores of the MFMA path for small inputs,
+ * out_dev[nq][n] (f32, DEVICE). Used by tests to check the GEMM tile mapping. */
+int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t nq,
+                                float* out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGVEC_H */

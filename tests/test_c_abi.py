@@ -1,0 +1,67 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/cgvec.h declares, and fails LOUDLY (no CPU fallback) when no GPU is visible."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from _util import ROOT, pkg
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cgvec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cgv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    m = pkg()
+    m.build_library()
+    L = ctypes.CDLL(m.cgvec.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in cgvec.h but not exported"
+
+
+def test_version_and_error_string():
+    m = pkg()
+    L = m.cgvec.lib()
+    assert L.cgv_version() >= 1
+    assert isinstance(L.cgv_last_error(), bytes)
+
+
+def test_no_cpu_fallback_without_gpu():
+    m = pkg()
+    if m.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(m.CgvError) as ei:
+        m.HipKnnIndex(384)
+    assert ei.value.code == m.cgvec.CGV_ERR_HIP
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_argument_validation_needs_no_gpu():
+    m = pkg()
+    L = m.cgvec.lib()
+    h = ctypes.c_void_p()
+    assert L.cgv_create(0, 0, 1, 0, ctypes.byref(h)) == m.cgvec.CGV_ERR_INVALID_ARG   # dim 0
+    assert L.cgv_create(9000, 0, 1, 0, ctypes.byref(h)) == m.cgvec.CGV_ERR_INVALID_ARG  # config.rs:221-224
+    assert L.cgv_create(8, 7, 1, 0, ctypes.byref(h)) == m.cgvec.CGV_ERR_INVALID_ARG    # metric
+    assert L.cgv_create(8, 0, 9, 0, ctypes.byref(h)) == m.cgvec.CGV_ERR_INVALID_ARG    # dtype
+    assert L.cgv_count(None) == 0
+    assert L.cgv_destroy(None) == 0
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the product package may reference it."""
+    bad = []
+    pdir = os.path.join(ROOT, "codegraph-rust_amd")
+    for dp, _, fns in os.walk(pdir):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                t = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"\boracle\b", t):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

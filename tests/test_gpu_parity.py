@@ -1,0 +1,290 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, on a real MI355X.
+
+Bar (BASELINE.json north_star): top-k row ids bit-exact under (score desc, id asc);
+scores bit-exact too, because the re-score kernel reproduces the reference's f32 lane
+order (tolerance stated where it is not zero)."""
+import numpy as np
+import pytest
+
+from _util import pkg
+
+pytestmark = pytest.mark.gpu
+
+ODT = {"f32": 0, "bf16": 1, "fp16": 2}
+OMETRIC = {"cosine": 0, "dot": 1}
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    return x
+
+
+def _check(oracle, rows, queries, k, dtype, metric, idx, sc, what=""):
+    ref_i, ref_s = oracle.batch_top_k(queries, rows, k, metric=OMETRIC[metric], dtype=ODT[dtype])
+    assert np.array_equal(idx, ref_i), f"{what}: ids differ\n{idx[:2]}\n{ref_i[:2]}"
+    assert np.array_equal(sc, ref_s), f"{what}: scores differ (max abs {np.nanmax(np.abs(sc - ref_s))})"
+
+
+def _run(oracle, n, d, nq, k, dtype, metric, seed=0, unit=True, mutate=None):
+    m = pkg()
+    rng = np.random.default_rng(seed)
+    rows = _unit(rng, n, d) if unit else (rng.standard_normal((n, d)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    queries = _unit(rng, nq, d) if unit else rng.standard_normal((nq, d)).astype(np.float32)
+    if mutate:
+        mutate(rows, queries)
+    ix = m.HipKnnIndex(d, metric=metric, dtype=dtype)
+    try:
+        ix.add(rows)
+        assert len(ix) == n
+        idx, sc = ix.search(queries, k)
+        _check(oracle, rows, queries, k, dtype, metric, idx, sc, f"n={n} d={d} nq={nq} k={k} {dtype} {metric}")
+        return ix.stats()
+    finally:
+        ix.close()
+
+
+def test_device_visible():
+    assert pkg().device_count() >= 1
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("d", [64, 128, 768, 100])
+def test_mfma_tile_mapping_dense_scores(dtype, d):
+    """Dense coarse scores of the MFMA kernel vs an fp32 matmul of the rounded inputs
+    (tolerance 2e-4 abs on cosine: fp32 accumulation-order noise only). Asymmetric data
+    catches row/column swaps in the MFMA C layout."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(5)
+    n, nq = 700, 300
+    rows = (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = m.HipKnnIndex(d, metric="cosine", dtype=dtype)
+    try:
+        ix.add(rows)
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+        qd = torch.from_numpy(queries).cuda()
+        got = ix.debug_coarse_scores(qd).cpu().numpy()
+        r = torch.from_numpy(rows).to(tdt).double()
+        q = torch.from_numpy(queries).to(tdt).double()
+        ref = (q / q.norm(dim=1, keepdim=True)) @ (r / r.norm(dim=1, keepdim=True)).T
+        err = np.abs(got - ref.numpy())
+        assert not np.isnan(got).any(), "unwritten entries in the dense dump"
+        assert err.max() < 2e-4, f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "cosine"), ("bf16", "dot"),
+                                          ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot")])
+def test_parity_small(oracle, dtype, metric):
+    _run(oracle, n=1000, d=256, nq=7, k=10, dtype=dtype, metric=metric)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("d", [8, 31, 33, 37, 100, 384, 1536])
+def test_parity_ragged_dims(oracle, dtype, d):
+    """D < 32 takes the reference's scalar branch (simd_ops.rs:281-295); D % 8 != 0 the tail."""
+    _run(oracle, n=777, d=d, nq=5, k=10, dtype=dtype, metric="cosine", seed=d, unit=False)
+
+
+def test_parity_c1_shape_f32(oracle):
+    """BASELINE config C1: 10k x 384 f32 cosine, single query."""
+    st = _run(oracle, n=10_000, d=384, nq=1, k=10, dtype="f32", metric="cosine", seed=1)
+    assert st["last_path"] == 0
+
+
+def test_parity_c1_hash_embedder_corpus(oracle):
+    """The reference's own synthetic 384-d generator (search.rs:178-205) over "node_{i}"."""
+    m = pkg()
+    rows = np.stack([oracle.hash_embed(f"node_{i}", 384) for i in range(10_000)])
+    queries = np.stack([oracle.hash_embed(t, 384) for t in ("sum two numbers", "read a file", "node_17")])
+    for dtype in ("f32", "bf16"):
+        ix = m.HipKnnIndex(384, dtype=dtype)
+        try:
+            ix.add(rows)
+            idx, sc = ix.search(queries, 10)
+            _check(oracle, rows, queries, 10, dtype, "cosine", idx, sc, dtype)
+            assert idx[2, 0] == 17
+        finally:
+            ix.close()
+
+
+@pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "dot")])
+def test_parity_medium_staged(oracle, dtype, metric):
+    """70k rows -> 274 corpus tiles: exercises all three threshold stages, several
+    query tiles (nq=300) and the strided sample."""
+    st = _run(oracle, n=70_000, d=768 if dtype == "bf16" else 1536 // 4, nq=300, k=10, dtype=dtype, metric=metric, seed=3)
+    assert st["last_path"] == 1
+    assert st["fallback_queries"] == 0
+    assert st["max_observed_err"] <= st["last_eps"]
+
+
+def test_parity_unnormalised_rows_and_prefetch_k(oracle):
+    """Chunk-mean rows are not unit length; k=30 is search.rs:113's prefetch for limit 10."""
+    _run(oracle, n=20_000, d=384, nq=40, k=30, dtype="bf16", metric="cosine", seed=9, unit=False)
+
+
+def test_ties_duplicates_zero_rows_zero_query(oracle):
+    def mutate(rows, queries):
+        rows[100:140] = rows[7]          # 40 exact duplicates of the best match for query 0
+        queries[0] = rows[7]
+        rows[300:310] = 0.0              # zero rows -> score 0.0 (simd_ops.rs:73-74)
+        queries[1] = 0.0                 # zero query -> every score 0.0, ids 0..k-1
+    st = _run(oracle, n=5000, d=128, nq=4, k=10, dtype="bf16", metric="cosine", seed=4, mutate=mutate)
+    assert st["fallback_queries"] >= 1   # ties at the candidate boundary are resolved by the exact scan
+
+
+def test_fewer_rows_than_k_and_single_row(oracle):
+    m = pkg()
+    for n in (1, 3, 9):
+        st = _run(oracle, n=n, d=64, nq=3, k=10, dtype="bf16", metric="cosine", seed=n)
+    ix = m.HipKnnIndex(64)
+    try:
+        idx, sc = ix.search(np.ones((2, 64), np.float32), 5)     # empty index
+        assert np.all(idx == np.uint64(2**64 - 1)) and np.all(np.isneginf(sc))
+        i0, s0 = ix.search(np.ones((0, 64), np.float32), 5)      # nq == 0 (surreal_store.rs:62-64)
+        assert i0.shape == (0, 5)
+    finally:
+        ix.close()
+
+
+def test_incremental_add_equals_bulk_add(oracle):
+    m = pkg()
+    rng = np.random.default_rng(12)
+    rows, queries = _unit(rng, 3000, 96), _unit(rng, 6, 96)
+    ix = m.HipKnnIndex(96, dtype="bf16")
+    try:
+        for lo in range(0, 3000, 701):   # unaligned appends (norm-block stats must be redone)
+            ix.add(rows[lo:lo + 701])
+        idx, sc = ix.search(queries, 10)
+        _check(oracle, rows, queries, 10, "bf16", "cosine", idx, sc, "incremental")
+        assert np.array_equal(ix.get_row(1234), oracle.round_trip(rows[1234], 1))
+    finally:
+        ix.close()
+
+
+def test_kat_parallel_operations_on_gpu(oracle):
+    """simd_ops.rs:462-472: ones[256] vs ramp rows, k=10 -> rows 999..990."""
+    m = pkg()
+    q = np.ones((1, 256), np.float32)
+    rows = (np.arange(1000)[:, None] + np.arange(256)[None, :]).astype(np.float32)
+    for dtype in ("f32", "bf16"):
+        ix = m.HipKnnIndex(256, dtype=dtype)
+        try:
+            ix.add(rows)
+            idx, sc = ix.search(q, 10)
+            _check(oracle, rows, q, 10, dtype, "cosine", idx, sc, "KAT " + dtype)
+            if dtype == "f32":
+                assert idx[0].tolist() == list(range(999, 989, -1))
+        finally:
+            ix.close()
+
+
+def test_forced_exact_path_matches(oracle):
+    m = pkg()
+    rng = np.random.default_rng(21)
+    rows, queries = _unit(rng, 9000, 200), _unit(rng, 9, 200)
+    ix = m.HipKnnIndex(200, dtype="bf16")
+    try:
+        ix.add(rows)
+        ix.set_force_exact(True)
+        idx, sc = ix.search(queries, 17)
+        assert ix.stats()["last_path"] == 0
+        _check(oracle, rows, queries, 17, "bf16", "cosine", idx, sc, "forced exact")
+    finally:
+        ix.close()
+
+
+def test_nonfinite_inputs_are_errors():
+    """The reference panics on NaN (simd_ops.rs:379); across the FFI that is a status, not an abort."""
+    m = pkg()
+    ix = m.HipKnnIndex(32)
+    try:
+        ix.add(np.ones((10, 32), np.float32))
+        q = np.ones((1, 32), np.float32)
+        q[0, 3] = np.nan
+        with pytest.raises(m.CgvError) as ei:
+            ix.search(q, 3)
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+        with pytest.raises(m.CgvError):
+            ix.search(np.ones((1, 31), np.float32), 3)      # dimension mismatch (simd_ops.rs:16-18)
+        bad = np.ones((2, 32), np.float32)
+        bad[1, 0] = np.inf
+        with pytest.raises(m.CgvError):
+            ix.add(bad)
+    finally:
+        ix.close()
+
+
+def test_device_pointer_api_and_merge(oracle):
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(33)
+    rows, queries = _unit(rng, 6000, 128), _unit(rng, 33, 128)
+    k = 10
+    shards = []
+    try:
+        outs_i, outs_s = [], []
+        for r in range(3):
+            lo, hi = m.shard_range(6000, r, 3)
+            ix = m.HipKnnIndex(128, dtype="bf16")
+            shards.append(ix)
+            ix.add(torch.from_numpy(rows[lo:hi]).cuda())
+            ix.set_index_base(lo)
+            i, s = ix.search(torch.from_numpy(queries).cuda(), k)
+            outs_i.append(i)
+            outs_s.append(s)
+        gi, gs = m.merge_topk(torch.stack(outs_i), torch.stack(outs_s))
+        torch.cuda.synchronize()
+        _check(oracle, rows, queries, k, "bf16", "cosine", gi.cpu().numpy().view(np.uint64), gs.cpu().numpy(), "3-shard merge")
+    finally:
+        for ix in shards:
+            ix.close()
+
+
+def test_golden_fixture(oracle):
+    import os
+    m = pkg()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_small.npz"))
+    for dtype in ("f32", "bf16", "fp16"):
+        ix = m.HipKnnIndex(int(g["rows"].shape[1]), dtype=dtype)
+        try:
+            ix.add(g["rows"])
+            idx, sc = ix.search(g["queries"], int(g["k"]))
+            assert np.array_equal(idx, g[f"idx_{dtype}"])
+            assert np.array_equal(sc, g[f"score_{dtype}"])
+        finally:
+            ix.close()
+
+
+def test_full_size_properties_c2():
+    """BASELINE config C2 (1M x 768 bf16, batch 1024) through size-independent properties:
+    a stored row queried against the corpus returns itself first with score ~1; repeated
+    search is idempotent; scores are sorted; no fallback on random data."""
+    import torch
+    m = pkg()
+    n, d, nq, k = 1_000_000, 768, 1024, 10
+    gen = torch.Generator(device="cuda").manual_seed(0xC0DE6001)
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.reserve(n)
+        for lo in range(0, n, 250_000):
+            x = torch.randn((250_000, d), generator=gen, device="cuda")
+            x = torch.nn.functional.normalize(x, dim=1)
+            if lo == 0:
+                probe = x[:nq].clone()
+            ix.add(x)
+        del x
+        idx, sc = ix.search(probe, k)
+        idx2, sc2 = ix.search(probe, k)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+        assert torch.equal(idx[:, 0].cpu(), torch.arange(nq))
+        assert (sc[:, 0] > 0.999).all() and (sc[:, 1:] < 0.5).all()
+        assert (sc[:, :-1] >= sc[:, 1:]).all()
+        st = ix.stats()
+        assert st["fallback_queries"] == 0 and st["max_observed_err"] <= st["last_eps"]
+    finally:
+        ix.close()
