@@ -81,6 +81,7 @@ def lib():
     L.cgv_get_row_f32.argtypes = [vp, u64, vp]
     L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
     L.cgv_set_stream.argtypes = [vp, vp]
+    L.cgv_use_own_stream.argtypes = [vp]
     L.cgv_synchronize.argtypes = [vp]
     L.cgv_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cgv_set_profiling.argtypes = [vp, i32]
@@ -88,7 +89,7 @@ def lib():
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
     for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
-                 "cgv_merge_topk_dev", "cgv_set_stream", "cgv_synchronize", "cgv_get_stats",
+                 "cgv_merge_topk_dev", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
         getattr(L, name).restype = i32
     _lib = L
@@ -144,7 +145,11 @@ class HipKnnIndex:
         _check(lib().cgv_set_index_base(self._h, int(base)))
 
     def set_stream(self, stream_ptr):
+        """Use an external hipStream_t; 0/None is HIP's legacy default stream (PyTorch's default)."""
         _check(lib().cgv_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_own_stream(self):
+        _check(lib().cgv_use_own_stream(self._h))
 
     def use_torch_stream(self):
         import torch

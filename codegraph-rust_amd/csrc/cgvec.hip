@@ -591,7 +591,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
 int cgv_destroy(cgv_index* h) {
     if (!h) return CGV_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     if (h->rows) {
         (void)hipFree(h->rows);
         (void)hipFree(h->norm);
@@ -723,7 +723,14 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
 int cgv_set_stream(cgv_index* h, void* stream) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     std::lock_guard<std::mutex> lk(h->mu);
-    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    h->stream = (hipStream_t)stream;  // NULL == HIP's legacy default stream
+    return CGV_OK;
+}
+
+int cgv_use_own_stream(cgv_index* h) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->stream = h->own_stream;
     return CGV_OK;
 }
 

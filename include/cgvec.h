@@ -132,8 +132,12 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
                        void* stream);
 
 /* Run this handle's work on an external hipStream_t (e.g. PyTorch's current stream).
- * NULL restores the handle's own stream. */
+ * The value is used as-is: NULL is HIP's legacy default ("null") stream — which is what
+ * PyTorch uses unless told otherwise — NOT "no stream". */
 int cgv_set_stream(cgv_index* h, void* stream);
+
+/* Go back to the handle's own (non-blocking) stream, the default after cgv_create. */
+int cgv_use_own_stream(cgv_index* h);
 
 /* Block until all work enqueued by this handle has finished.
  * Replaces GpuAcceleration::synchronize (gpu.rs). */
