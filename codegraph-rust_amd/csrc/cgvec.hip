@@ -16,6 +16,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -122,9 +123,16 @@ struct cgv_index {
 
 namespace {
 
+// bytes of storage holding rows [0, nrows) (nrows rounded up to whole 256-row tiles for the
+// blocked layout, whose tiles are contiguous)
+size_t storage_bytes(const cgv_index* h, uint64_t nrows) {
+    const uint64_t r = (nrows + 255) / 256 * 256;
+    return (size_t)r * h->ld * h->esize;
+}
+
 size_t device_bytes(const cgv_index* h) {
     size_t b = 0;
-    if (h->rows) b += (size_t)h->cap * h->ld * h->esize + (size_t)h->cap * 8 + ((size_t)h->cap / 32 + 1) * 8;
+    if (h->rows) b += storage_bytes(h, h->cap) + (size_t)h->cap * 8 + ((size_t)h->cap / 32 + 1) * 8;
     const DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best,
                             &h->overflow, &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores,
                             &h->keysA, &h->keysB, &h->outidx, &h->outscore, &h->addstage, &h->dump};
@@ -133,20 +141,21 @@ size_t device_bytes(const cgv_index* h) {
 }
 
 template <int DT>
-void launch_prep(const float* in, uint64_t n, uint32_t D, uint32_t ld, char* out, float* norm,
+void launch_prep(const float* in, uint64_t n, uint32_t D, uint32_t ld, uint64_t row0, char* out, float* norm,
                  float* invn, uint32_t* nonfinite, hipStream_t s) {
     if (n == 0) return;
     uint64_t blocks = (n + 3) / 4;
-    hipLaunchKernelGGL(prep_rows_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, s, in, n, D, ld, out,
+    hipLaunchKernelGGL(prep_rows_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, s, in, n, D, ld, row0, out,
                        norm, invn, nonfinite);
 }
 
-int prep_dispatch(int dtype, const float* in, uint64_t n, uint32_t D, uint32_t ld, char* out,
+// Convert n f32 rows into the index' storage at absolute rows [row0, row0+n).
+int prep_dispatch(int dtype, const float* in, uint64_t n, uint32_t D, uint32_t ld, uint64_t row0, char* out,
                   float* norm, float* invn, uint32_t* nonfinite, hipStream_t s) {
     switch (dtype) {
-        case CGV_DTYPE_F32: launch_prep<DT_F32>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
-        case CGV_DTYPE_BF16: launch_prep<DT_BF16>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
-        case CGV_DTYPE_FP16: launch_prep<DT_FP16>(in, n, D, ld, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_F32: launch_prep<DT_F32>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_BF16: launch_prep<DT_BF16>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_FP16: launch_prep<DT_FP16>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
         default: return fail(CGV_ERR_INVALID_ARG, "dtype not supported by this build");
     }
     HIPCHK(hipGetLastError());
@@ -161,22 +170,23 @@ int grow(cgv_index* h, uint64_t need) {
     ncap = (ncap + 255) / 256 * 256;
     char* rows = nullptr;
     float *norm = nullptr, *invn = nullptr, *bmin = nullptr, *bmax = nullptr;
-    size_t rb = (size_t)ncap * h->ld * h->esize;
-    size_t nblk = (size_t)ncap / 32 + 1;
+    size_t rb = storage_bytes(h, ncap);
+    size_t nblk = (size_t)ncap / 32 + 8;
     HIPCHK(hipMalloc((void**)&rows, rb));
+    HIPCHK(hipMemsetAsync(rows, 0, rb, h->stream));  // padding rows / columns must read as zero
     HIPCHK(hipMalloc((void**)&norm, ncap * 4));
     HIPCHK(hipMalloc((void**)&invn, ncap * 4));
     HIPCHK(hipMalloc((void**)&bmin, nblk * 4));
     HIPCHK(hipMalloc((void**)&bmax, nblk * 4));
     if (h->n) {
-        HIPCHK(hipMemcpyAsync(rows, h->rows, (size_t)h->n * h->ld * h->esize, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(rows, h->rows, storage_bytes(h, h->n), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(norm, h->norm, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(invn, h->invn, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
         size_t ob = (size_t)(h->n + 31) / 32;
         HIPCHK(hipMemcpyAsync(bmin, h->blk_min, ob * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(bmax, h->blk_max, ob * 4, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
     if (h->rows) {
         (void)hipFree(h->rows);
         (void)hipFree(h->norm);
@@ -198,8 +208,8 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
     int rc = grow(h, h->n + cnt);
     if (rc) return rc;
     hipStream_t s = h->stream;
-    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->rows + (size_t)h->n * h->ld * h->esize,
-                       h->norm + h->n, h->invn + h->n, h->flags + F_NONFINITE_C, s);
+    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->n, h->rows, h->norm, h->invn,
+                       h->flags + F_NONFINITE_C, s);
     if (rc) return rc;
     const uint64_t n_new = h->n + cnt;
     const uint64_t b0 = h->n / 32, b1 = (n_new + 31) / 32;
@@ -220,34 +230,34 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
     return CGV_OK;
 }
 
-template <int DT, int TBM, int TBN, int WM, int WN, bool DUMP>
+template <int DT, bool DUMP>
 int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(TBM + TBN) * 128 + (size_t)TBN * 4;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128 + (size_t)BN * 4 + 2 * 256 * 4 + 2 * 16 * 4;
     static bool attr_set = false;
-    auto kern = coarse_kernel<DT, TBM, TBN, WM, WN, DUMP>;
+    auto kern = coarse_kernel<DT, DUMP>;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(W), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
     HIPCHK(hipGetLastError());
     return CGV_OK;
 }
 
 int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStream_t s) {
     if (dtype == CGV_DTYPE_BF16)
-        return dump ? launch_coarse_t<DT_BF16, BM, BN, 2, 4, true>(a, W, s)
-                    : launch_coarse_t<DT_BF16, BM, BN, 2, 4, false>(a, W, s);
+        return dump ? launch_coarse_t<DT_BF16, true>(a, W, s) : launch_coarse_t<DT_BF16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP16)
-        return dump ? launch_coarse_t<DT_FP16, BM, BN, 2, 4, true>(a, W, s)
-                    : launch_coarse_t<DT_FP16, BM, BN, 2, 4, false>(a, W, s);
+        return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
-int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime, hipStream_t s) {
+int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
+                  const float* dense, uint32_t n_dense, hipStream_t s) {
     SelectArgs sa;
     sa.cand = h->cand.as<uint2>();
     sa.cand_cnt = h->candcnt.as<uint32_t>();
+    sa.dense = dense;
     sa.best = h->best.as<uint64_t>();
     sa.nbest = h->nbest.as<uint32_t>();
     sa.tau = h->tau.as<float>();
@@ -257,7 +267,12 @@ int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
     sa.nsplit = nsplit;
     sa.bn = BN;
     sa.kprime = kprime;
-    const size_t lds = (size_t)SELECT_LDS_KEYS * 8 + ((size_t)nsplit + 1) * 4;
+    sa.n_dense = n_dense;
+    // LDS key capacity: the dense boot stage needs exactly kprime + n_dense; candidate stages get
+    // the full 8192 (64 KiB) so that only pathological emission counts overflow into the exact path.
+    sa.lds_keys = dense ? next_pow2(kprime + n_dense) : SELECT_LDS_KEYS;
+    if (sa.lds_keys > SELECT_LDS_KEYS) sa.lds_keys = SELECT_LDS_KEYS;
+    const size_t lds = (size_t)sa.lds_keys * 8 + ((size_t)nsplit + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -333,17 +348,24 @@ __global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
     }
 }
 
+// Staged thresholds. The corpus tiles (BM rows each) are partitioned into
+//   boot   : tiles [0, T1)            dense scores by boot_kernel, tau = -inf  -> first tau
+//   sample : tiles T1 + j*stride      strided sample, ~one tile per workgroup  -> tight tau
+//   main   : every remaining tile     the dominant launch
 struct StagePlan {
     uint32_t ntiles, T1, stride, cnt2, cnt3;
 };
 
-StagePlan plan_stages(uint64_t n, uint32_t kprime) {
+constexpr uint32_t BOOT_TILES = 4;  // 1024 rows: tau_1 passes ~k'/1024 of the sample stage
+
+StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
-    p.T1 = std::min<uint32_t>((kprime + BM - 1) / BM, p.ntiles);
+    p.T1 = std::min<uint32_t>(std::max<uint32_t>((kprime + BM - 1) / BM, BOOT_TILES), p.ntiles);
     const uint32_t R = p.ntiles - p.T1;
-    if (R >= 96) {
-        p.stride = 32;
+    if (R > 4 * nsplit_max && R >= 64) {
+        p.stride = (R + nsplit_max - 1) / nsplit_max;
+        if (p.stride < 2) p.stride = 2;
         p.cnt2 = (R + p.stride - 1) / p.stride;
         p.cnt3 = R - p.cnt2;
     } else {
@@ -352,6 +374,14 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime) {
         p.cnt3 = R;
     }
     return p;
+}
+
+template <int DT>
+void launch_boot(cgv_index* h, uint32_t n_boot, uint32_t nq, float* dense, hipStream_t s) {
+    const uint32_t nrb = (n_boot + 63) / 64, nqb = (nq + 63) / 64;
+    hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s, (const char*)h->rows,
+                       (const char*)h->qrows.p, (const float*)h->invn, (const float*)h->qinvn.p, n_boot, nq, h->ld,
+                       h->metric, dense);
 }
 
 int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, uint64_t* out_idx,
@@ -373,13 +403,13 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
 
     if (h->profiling) HIPCHK(hipEventRecord(h->ev[0], s));
     // --- queries: round to storage dtype, norms ---
-    if ((rc = h->qrows.ensure((size_t)nq * h->ld * h->esize))) return rc;
+    if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;  // whole 256-query tiles (DMA reads them)
     if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->fbflag.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qlist.ensure((size_t)nq * 4))) return rc;
     HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
-    rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, h->qrows.as<char>(), h->qnorm.as<float>(),
+    rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
                        h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
 
@@ -395,18 +425,26 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
     if (mfma) {
         const uint32_t nqt = (nq + BN - 1) / BN;
         const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
-        const StagePlan p = plan_stages(h->n, kprime);
+        const StagePlan p = plan_stages(h->n, kprime, nsplit_max);
         const uint32_t Wmax = nqt * nsplit_max;
+        const uint32_t n_boot = (uint32_t)std::min<uint64_t>((uint64_t)p.T1 * BM, h->n);
         if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
         if ((rc = h->nbest.ensure((size_t)nq * 4))) return rc;
         if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
         if ((rc = h->best.ensure((size_t)nq * kprime * 8))) return rc;
         if ((rc = h->cand.ensure((size_t)Wmax * BN * CAND_CAPS * 8))) return rc;
         if ((rc = h->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
-        hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->tau.as<float>(),
-                           -INFINITY, nq);
+        if ((rc = h->dump.ensure((size_t)nq * n_boot * 4))) return rc;
         HIPCHK(hipMemsetAsync(h->nbest.p, 0, (size_t)nq * 4, s));
         HIPCHK(hipMemsetAsync(h->overflow.p, 0, (size_t)nq * 4, s));
+
+        // boot: dense scores of the first n_boot rows -> top-k' -> first tau
+        if (h->dtype == CGV_DTYPE_BF16)
+            launch_boot<DT_BF16>(h, n_boot, nq, h->dump.as<float>(), s);
+        else
+            launch_boot<DT_FP16>(h, n_boot, nq, h->dump.as<float>(), s);
+        HIPCHK(hipGetLastError());
+        if ((rc = launch_select(h, nq, nqt, 0, kprime, h->dump.as<float>(), n_boot, s))) return rc;
 
         CoarseArgs a;
         a.rows = h->rows;
@@ -428,14 +466,14 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         a.stride = p.stride;
         a.nqt = nqt;
         a.metric = h->metric;
-        const uint32_t counts[3] = {p.T1, p.cnt2, p.cnt3};
-        for (int st = 1; st <= 3; ++st) {
+        const uint32_t counts[3] = {0, p.cnt2, p.cnt3};
+        for (int st = 2; st <= 3; ++st) {
             const uint32_t cnt = counts[st - 1];
             if (cnt == 0) continue;
             a.stage = (uint32_t)st;
             a.cnt = cnt;
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
-            const bool dominant = (st == 3) || (p.cnt3 == 0 && st == 1);
+            const bool dominant = (st == 3);
             if (h->profiling && dominant) HIPCHK(hipEventRecord(h->ev[1], s));
             if ((rc = launch_coarse(h->dtype, false, a, nqt * a.nsplit, s))) return rc;
             if (h->profiling && dominant) {
@@ -443,7 +481,7 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
                 timed_coarse = true;
                 h->last_coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
-            if ((rc = launch_select(h, nq, nqt, a.nsplit, kprime, s))) return rc;
+            if ((rc = launch_select(h, nq, nqt, a.nsplit, kprime, nullptr, 0, s))) return rc;
         }
         RescoreArgs r;
         r.best = h->best.as<uint64_t>();
@@ -506,31 +544,6 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         if (hipEventElapsedTime(&ms, h->ev[0], h->ev[3]) == hipSuccess) h->st.last_total_ms = ms;
     }
     return CGV_OK;
-}
-
-float host_f16_to_f32(uint16_t b) {
-    uint32_t sign = (uint32_t)(b & 0x8000u) << 16;
-    uint32_t ex = (b >> 10) & 0x1f, man = b & 0x3ffu;
-    uint32_t u;
-    if (ex == 0) {
-        if (man == 0) {
-            u = sign;
-        } else {
-            int e = -1;
-            do {
-                man <<= 1;
-                ++e;
-            } while (!(man & 0x400u));
-            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
-        }
-    } else if (ex == 31) {
-        u = sign | 0x7f800000u | (man << 13);
-    } else {
-        u = sign | ((ex + 112) << 23) | (man << 13);
-    }
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
 }
 
 }  // namespace
@@ -692,18 +705,19 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
     std::lock_guard<std::mutex> lk(h->mu);
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     HIPCHK(hipSetDevice(h->device));
-    std::vector<char> tmp((size_t)h->D * h->esize);
-    HIPCHK(hipMemcpyAsync(tmp.data(), h->rows + (size_t)id * h->ld * h->esize, tmp.size(), hipMemcpyDeviceToHost,
-                          h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    for (uint32_t i = 0; i < h->D; ++i) {
-        if (h->dtype == CGV_DTYPE_F32)
-            out_host[i] = ((const float*)tmp.data())[i];
-        else if (h->dtype == CGV_DTYPE_BF16)
-            out_host[i] = bf16_to_f32(((const uint16_t*)tmp.data())[i]);
-        else
-            out_host[i] = host_f16_to_f32(((const uint16_t*)tmp.data())[i]);
-    }
+    int rc;
+    if ((rc = h->qstage.ensure((size_t)h->D * 4))) return rc;
+    hipStream_t s = h->stream;
+    float* tmp = h->qstage.as<float>();
+    if (h->dtype == CGV_DTYPE_F32)
+        hipLaunchKernelGGL(gather_row_kernel<DT_F32>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+    else if (h->dtype == CGV_DTYPE_BF16)
+        hipLaunchKernelGGL(gather_row_kernel<DT_BF16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+    else
+        hipLaunchKernelGGL(gather_row_kernel<DT_FP16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_host, tmp, (size_t)h->D * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;
 }
 
@@ -772,12 +786,12 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int rc;
-    if ((rc = h->qrows.ensure((size_t)nq * h->ld * h->esize))) return rc;
+    if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;
     if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
-    rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, h->qrows.as<char>(), h->qnorm.as<float>(),
+    rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
                        h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
     const uint32_t nqt = (nq + BN - 1) / BN;

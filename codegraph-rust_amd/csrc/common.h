@@ -53,37 +53,78 @@ __device__ inline float f16_to_f32(uint16_t b) {
     return (float)h;
 }
 
+// ---- storage layouts ---------------------------------------------------------------
+// f32 corpora: plain row-major [rows][ld] (exact path only; the reference's own layout).
+// bf16/fp16 corpora: BLOCKED layout "B64", the unit the coarse kernel streams:
+//   rows are grouped in tiles of 256; K in chunks of 64 elements; block (tile t, chunk kc)
+//   is 32 KiB contiguous at byte ((t*KC + kc) << 15), KC = ld/64. Inside a block, row r
+//   (0..255) owns 128 B at r*128 and its 16-byte slot p holds elements 8c..8c+7 of the
+//   chunk with c = p ^ ((r>>1)&7). That is byte-for-byte the LDS image the MFMA kernel
+//   wants (bank-conflict-free ds_read_b128), so the global->LDS DMA is a linear 1-KiB copy
+//   per wave instruction: measured 64 KB / 1.05 us per CU vs 1.98 us for 128-B pieces at a
+//   1536-B row pitch (scripts/ubench/dma_ring.hip, dma_bw.hip).
+constexpr uint32_t TILE_ROWS = 256, KCHUNK = 64, BLOCK_BYTES = TILE_ROWS * KCHUNK * 2;
+
+__host__ __device__ inline uint64_t blocked_row_base(uint64_t R, uint32_t ld) {
+    return ((R >> 8) * (uint64_t)(ld / KCHUNK)) * BLOCK_BYTES + (R & 255u) * 128u;
+}
+__host__ __device__ inline uint32_t blocked_row_key(uint64_t R) { return (uint32_t)((R & 255u) >> 1) & 7u; }
+// byte offset of element i of a row, relative to blocked_row_base
+__host__ __device__ inline uint64_t blocked_elem_off(uint32_t i, uint32_t key) {
+    return (uint64_t)(i >> 6) * BLOCK_BYTES + ((((i >> 3) & 7u) ^ key) << 4) + ((i & 7u) << 1);
+}
+
 template <int DT>
 struct Elem;
 template <>
 struct Elem<DT_F32> {
     static constexpr int bytes = 4;
-    static __device__ inline float load(const char* p, uint32_t i) { return ((const float*)p)[i]; }
-    static __device__ inline void store(char* p, uint32_t i, float x) { ((float*)p)[i] = x; }
+    static __device__ inline float cvt_load(const char* p) { return *(const float*)p; }
+    static __device__ inline void cvt_store(char* p, float x) { *(float*)p = x; }
     static __device__ inline float round_trip(float x) { return x; }
 };
 template <>
 struct Elem<DT_BF16> {
     static constexpr int bytes = 2;
-    static __device__ inline float load(const char* p, uint32_t i) {
-        return bf16_to_f32(((const uint16_t*)p)[i]);
-    }
-    static __device__ inline void store(char* p, uint32_t i, float x) {
-        ((uint16_t*)p)[i] = f32_to_bf16_rne(x);
-    }
+    static __device__ inline float cvt_load(const char* p) { return bf16_to_f32(*(const uint16_t*)p); }
+    static __device__ inline void cvt_store(char* p, float x) { *(uint16_t*)p = f32_to_bf16_rne(x); }
     static __device__ inline float round_trip(float x) { return bf16_to_f32(f32_to_bf16_rne(x)); }
 };
 template <>
 struct Elem<DT_FP16> {
     static constexpr int bytes = 2;
-    static __device__ inline float load(const char* p, uint32_t i) {
-        return f16_to_f32(((const uint16_t*)p)[i]);
-    }
-    static __device__ inline void store(char* p, uint32_t i, float x) {
-        ((uint16_t*)p)[i] = f32_to_f16_rne(x);
-    }
+    static __device__ inline float cvt_load(const char* p) { return f16_to_f32(*(const uint16_t*)p); }
+    static __device__ inline void cvt_store(char* p, float x) { *(uint16_t*)p = f32_to_f16_rne(x); }
     static __device__ inline float round_trip(float x) { return f16_to_f32(f32_to_f16_rne(x)); }
 };
+
+// One stored row (corpus or query) seen as a sequence of f32 values.
+template <int DT>
+struct Row {
+    const char* p;
+    uint32_t key;
+    __device__ inline float at(uint32_t i) const {
+        if (DT == DT_F32) return Elem<DT>::cvt_load(p + (uint64_t)i * 4);
+        return Elem<DT>::cvt_load(p + blocked_elem_off(i, key));
+    }
+};
+template <int DT>
+__device__ inline Row<DT> make_row(const char* base, uint64_t R, uint32_t ld) {
+    Row<DT> r;
+    if (DT == DT_F32) {
+        r.p = base + R * (uint64_t)ld * 4;
+        r.key = 0;
+    } else {
+        r.p = base + blocked_row_base(R, ld);
+        r.key = blocked_row_key(R);
+    }
+    return r;
+}
+template <int DT>
+__device__ inline char* elem_ptr(char* base, uint64_t R, uint32_t ld, uint32_t i) {
+    if (DT == DT_F32) return base + (R * (uint64_t)ld + i) * 4;
+    return base + blocked_row_base(R, ld) + blocked_elem_off(i, blocked_row_key(R));
+}
 
 // ---- the reference's exact f32 arithmetic ---------------------------------------
 // One similarity is evaluated by a group of 8 consecutive lanes; lane l of the group
@@ -104,14 +145,14 @@ __device__ inline float group8_hsum(float v) {
 }
 
 template <int DT>
-__device__ inline float exact_cosine_group8(const char* q, const char* c, uint32_t D, int l) {
+__device__ inline float exact_cosine_group8(const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
     float result = 0.0f;
     if (D >= 32) {  // adaptive_cosine_similarity dispatch, simd_ops.rs:281-295
         float dp = 0.0f, na = 0.0f, nb = 0.0f;
         const uint32_t chunks = D / 8;
         for (uint32_t j = 0; j < chunks; ++j) {
-            float x = Elem<DT>::load(q, 8 * j + l);
-            float y = Elem<DT>::load(c, 8 * j + l);
+            float x = q.at(8 * j + l);
+            float y = c.at(8 * j + l);
             dp = fmaf(x, y, dp);
             na = fmaf(x, x, na);
             nb = fmaf(y, y, nb);
@@ -122,7 +163,7 @@ __device__ inline float exact_cosine_group8(const char* q, const char* c, uint32
         if (l == 0) {
             float dr = 0.0f, ar = 0.0f, br = 0.0f;
             for (uint32_t i = chunks * 8; i < D; ++i) {
-                float x = Elem<DT>::load(q, i), y = Elem<DT>::load(c, i);
+                float x = q.at(i), y = c.at(i);
                 dr = dr + x * y;
                 ar = ar + x * x;
                 br = br + y * y;
@@ -134,7 +175,7 @@ __device__ inline float exact_cosine_group8(const char* q, const char* c, uint32
     } else if (l == 0) {  // cosine_similarity_scalar, simd_ops.rs:257-278
         float dp = 0.0f, na = 0.0f, nb = 0.0f;
         for (uint32_t i = 0; i < D; ++i) {
-            float x = Elem<DT>::load(q, i), y = Elem<DT>::load(c, i);
+            float x = q.at(i), y = c.at(i);
             dp = dp + x * y;
             na = na + x * x;
             nb = nb + y * y;
@@ -146,27 +187,24 @@ __device__ inline float exact_cosine_group8(const char* q, const char* c, uint32
 }
 
 template <int DT>
-__device__ inline float exact_dot_group8(const char* q, const char* c, uint32_t D, int l) {
+__device__ inline float exact_dot_group8(const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
     // dot_product_avx2, simd_ops.rs:149-183
     float dp = 0.0f;
     const uint32_t chunks = D / 8;
-    for (uint32_t j = 0; j < chunks; ++j)
-        dp = fmaf(Elem<DT>::load(q, 8 * j + l), Elem<DT>::load(c, 8 * j + l), dp);
+    for (uint32_t j = 0; j < chunks; ++j) dp = fmaf(q.at(8 * j + l), c.at(8 * j + l), dp);
     dp = group8_hsum(dp);
     float result = 0.0f;
     if (l == 0) {
         float r = 0.0f;
-        for (uint32_t i = chunks * 8; i < D; ++i) r = r + Elem<DT>::load(q, i) * Elem<DT>::load(c, i);
+        for (uint32_t i = chunks * 8; i < D; ++i) r = r + q.at(i) * c.at(i);
         result = (D == 0) ? 0.0f : dp + r;
     }
     return result;
 }
 
 template <int DT>
-__device__ inline float exact_score_group8(int metric, const char* q, const char* c, uint32_t D,
-                                           int l) {
-    return metric == METRIC_DOT ? exact_dot_group8<DT>(q, c, D, l)
-                                : exact_cosine_group8<DT>(q, c, D, l);
+__device__ inline float exact_score_group8(int metric, const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
+    return metric == METRIC_DOT ? exact_dot_group8<DT>(q, c, D, l) : exact_cosine_group8<DT>(q, c, D, l);
 }
 
 // In-LDS bitonic sort, descending, P a power of two, NT threads.

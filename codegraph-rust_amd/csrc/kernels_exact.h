@@ -21,12 +21,11 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
                                                            float* __restrict__ scores) {
     const int tid = threadIdx.x;
     const int grp = tid >> 3, l = tid & 7;
-    const uint64_t eb = (uint64_t)Elem<DT>::bytes * ld;
     const uint32_t qi = blockIdx.y;
     const uint32_t q = qlist ? qlist[qi] : qi;
-    const char* qp = qrows + (uint64_t)q * eb;
+    const Row<DT> qr = make_row<DT>(qrows, q, ld);
     for (uint64_t row = (uint64_t)blockIdx.x * 32 + grp; row < n; row += (uint64_t)gridDim.x * 32) {
-        const float s = exact_score_group8<DT>(metric, qp, rows + row * eb, D, l);
+        const float s = exact_score_group8<DT>(metric, qr, make_row<DT>(rows, row, ld), D, l);
         if (l == 0) scores[(uint64_t)qi * n + row] = s;
     }
 }

@@ -10,12 +10,14 @@
 
 namespace cgv {
 
-// in: [n][D] f32. out rows: [n][ld] storage dtype, zero padded to ld (multiple of 64).
+// in: [n][D] f32 (n rows to append). out: the index' row storage (f32: row-major [.][ld];
+// bf16/fp16: blocked layout B64, see common.h), written at absolute rows row0 + r, columns
+// zero padded to ld (multiple of 64).
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
 // coarse pass), invn[r] = 1/norm or 0. nonfinite: set to 1 if any input is NaN/Inf.
 template <int DT>
 __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ in, uint64_t n,
-                                                        uint32_t D, uint32_t ld,
+                                                        uint32_t D, uint32_t ld, uint64_t row0,
                                                         char* __restrict__ out,
                                                         float* __restrict__ norm,
                                                         float* __restrict__ invn,
@@ -24,23 +26,30 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float* src = in + row * (uint64_t)D;
-    char* dst = out + row * (uint64_t)ld * Elem<DT>::bytes;
     float ss = 0.0f;
     int bad = 0;
     for (uint32_t i = lane; i < ld; i += 64) {
         float x = (i < D) ? src[i] : 0.0f;
         if (!(fabsf(x) <= 3.402823466e38f)) bad = 1;  // NaN or Inf
-        Elem<DT>::store(dst, i, x);
+        Elem<DT>::cvt_store(elem_ptr<DT>(out, row0 + row, ld, i), x);
         float xr = Elem<DT>::round_trip(x);
         ss = fmaf(xr, xr, ss);
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if (lane == 0) {
         float nr = sqrtf(ss);
-        norm[row] = nr;
-        invn[row] = nr > 0.0f ? 1.0f / nr : 0.0f;
+        norm[row0 + row] = nr;
+        invn[row0 + row] = nr > 0.0f ? 1.0f / nr : 0.0f;
     }
     if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
+}
+
+// Stored row -> f32 (get_embedding).
+template <int DT>
+__global__ void gather_row_kernel(const char* __restrict__ rows, uint64_t R, uint32_t D, uint32_t ld,
+                                  float* __restrict__ out) {
+    const Row<DT> r = make_row<DT>(rows, R, ld);
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = r.at(i);
 }
 
 // Per aligned 32-row block: min and max row norm over the valid rows (used by the

@@ -13,63 +13,129 @@ constexpr uint32_t SELECT_LDS_KEYS = 8192;  // 64 KiB of keys per workgroup
 struct SelectArgs {
     const uint2* cand;         // [W][BN][CAND_CAPS]
     const uint32_t* cand_cnt;  // [W][BN]
+    const float* dense;        // optional: [nq][n_dense] dense coarse scores (boot stage) instead of cand
     uint64_t* best;            // [nq][kprime] keys, sorted desc
     uint32_t* nbest;           // [nq]
     float* tau;                // [nq]
     uint32_t* overflow;        // [nq]
-    uint32_t nq, nqt, nsplit, bn, kprime;
+    uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
 };
 
 // One workgroup (256 threads) per query: merge best[q] with the nsplit candidate
-// sub-lists written by the last coarse launch, keep the top-k', publish tau[q] = the
-// k'-th best coarse score seen so far (a valid lower bound of the final k'-th best).
+// sub-lists written by the last coarse launch (or with the dense boot scores), keep the
+// top-k', publish tau[q] = the k'-th best coarse score seen so far (a valid lower bound of
+// the final k'-th best).
+//   gather : 256/nsplit threads per sub-list copy it into LDS (prefix sums give the offsets)
+//   select : k' <= 64 -> k' rounds of workgroup arg-max over the LDS keys (no full sort:
+//            M is ~1e3 and k' ~16); larger k' -> LDS bitonic sort.
 __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = (uint64_t*)smem;                                   // [SELECT_LDS_KEYS]
-    uint32_t* pre = (uint32_t*)(smem + SELECT_LDS_KEYS * 8);            // [nsplit + 1]
+    uint64_t* keys = (uint64_t*)smem;                            // [lds_keys]
+    uint32_t* pre = (uint32_t*)(smem + (size_t)a.lds_keys * 8);  // [nsplit + 1]
+    __shared__ uint64_t wmax[4];
+    __shared__ uint64_t outk[64];
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t qt = q / a.bn, ql = q % a.bn;
     const uint32_t nb = a.nbest[q];
-
-    for (uint32_t s = tid; s < a.nsplit; s += 256)
-        pre[s + 1] = a.cand_cnt[(uint64_t)(qt + s * a.nqt) * a.bn + ql];
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = nb;
-        pre[0] = run;
-        for (uint32_t s = 0; s < a.nsplit; ++s) {
-            uint32_t c = pre[s + 1];
-            pre[s + 1] = run + c;
-            run += c;
-        }
-    }
-    __syncthreads();
-    uint32_t M = pre[a.nsplit];
+    uint32_t M;
     bool trunc = false;
-    if (M > SELECT_LDS_KEYS) {  // cannot happen with sane thresholds; flag for the exact path
-        trunc = true;
-        M = SELECT_LDS_KEYS;
-    }
-    for (uint32_t i = tid; i < nb && i < M; i += 256) keys[i] = a.best[(uint64_t)q * a.kprime + i];
-    for (uint32_t s = tid; s < a.nsplit; s += 256) {
-        const uint32_t lo = pre[s], hi = pre[s + 1];
-        const uint2* src = a.cand + ((uint64_t)(qt + s * a.nqt) * a.bn + ql) * CAND_CAPS;
-        for (uint32_t e = lo; e < hi && e < M; ++e) {
-            const uint2 c = src[e - lo];
-            keys[e] = make_key(__uint_as_float(c.x), c.y);
+    if (a.dense) {
+        M = nb + a.n_dense;
+        if (M > a.lds_keys) {
+            trunc = true;
+            M = a.lds_keys;
+        }
+        for (uint32_t e = tid; e < M; e += 256)
+            keys[e] = (e < nb) ? a.best[(uint64_t)q * a.kprime + e]
+                               : make_key(a.dense[(uint64_t)q * a.n_dense + (e - nb)], e - nb);
+    } else {
+        // exclusive prefix of the sub-list counts: pre[s] = nb + sum_{s' < s} cnt[s']
+        if (tid < 64) {
+            const uint32_t per = (a.nsplit + 63) / 64;
+            uint32_t loc = 0;
+            for (uint32_t i = 0; i < per; ++i) {
+                const uint32_t s = tid * per + i;
+                if (s < a.nsplit) loc += a.cand_cnt[(uint64_t)(qt + s * a.nqt) * a.bn + ql];
+            }
+            uint32_t inc = loc;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += v;
+            }
+            uint32_t run = nb + inc - loc;
+            for (uint32_t i = 0; i < per; ++i) {
+                const uint32_t s = tid * per + i;
+                if (s < a.nsplit) {
+                    pre[s] = run;
+                    run += a.cand_cnt[(uint64_t)(qt + s * a.nqt) * a.bn + ql];
+                }
+            }
+            if (tid == 63) pre[a.nsplit] = nb + inc;
+        }
+        __syncthreads();
+        M = pre[a.nsplit];
+        if (M > a.lds_keys) {  // cannot happen with sane thresholds; flag for the exact path
+            trunc = true;
+            M = a.lds_keys;
+        }
+        for (uint32_t e = tid; e < nb && e < M; e += 256) keys[e] = a.best[(uint64_t)q * a.kprime + e];
+        // tps threads per sub-list (power of two), sub-lists in rounds of 256/tps
+        uint32_t tps = 256;
+        while (tps > 1 && tps * a.nsplit > 256) tps >>= 1;
+        const uint32_t per_round = 256 / tps;
+        const uint32_t sub = tid % tps;
+        for (uint32_t s = tid / tps; s < a.nsplit; s += per_round) {
+            const uint32_t lo = pre[s], hi = pre[s + 1];
+            const uint2* src = a.cand + ((uint64_t)(qt + s * a.nqt) * a.bn + ql) * CAND_CAPS;
+            for (uint32_t e = lo + sub; e < hi && e < M; e += tps) {
+                const uint2 c = src[e - lo];
+                keys[e] = make_key(__uint_as_float(c.x), c.y);
+            }
         }
     }
-    const uint32_t P = next_pow2(M < 2 ? 2 : M);
-    for (uint32_t i = M + tid; i < P; i += 256) keys[i] = 0ull;
-    __syncthreads();
-    bitonic_sort_desc<256>(keys, P, tid);
     const uint32_t keep = M < a.kprime ? M : a.kprime;
-    for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = keys[i];
-    if (tid == 0) {
-        a.nbest[q] = keep;
-        a.tau[q] = (M >= a.kprime) ? key_score(keys[a.kprime - 1]) : -INFINITY;
-        if (trunc) a.overflow[q] = 1u;
+    if (a.kprime <= 64) {
+        __syncthreads();
+        // keep rounds of arg-max; keys are unique, the owner zeroes the winner
+        for (uint32_t r = 0; r < keep; ++r) {
+            uint64_t mx = 0ull;
+            for (uint32_t e = tid; e < M; e += 256) {
+                const uint64_t v = keys[e];
+                mx = v > mx ? v : mx;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t o = __shfl_xor(mx, off, 64);
+                mx = o > mx ? o : mx;
+            }
+            if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+            __syncthreads();
+            uint64_t w = wmax[0];
+            w = wmax[1] > w ? wmax[1] : w;
+            w = wmax[2] > w ? wmax[2] : w;
+            w = wmax[3] > w ? wmax[3] : w;
+            for (uint32_t e = tid; e < M; e += 256)
+                if (keys[e] == w) keys[e] = 0ull;
+            if (tid == 0) outk[r] = w;
+            __syncthreads();
+        }
+        for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
+        if (tid == 0) {
+            a.nbest[q] = keep;
+            a.tau[q] = (M >= a.kprime) ? key_score(outk[a.kprime - 1]) : -INFINITY;
+            if (trunc) a.overflow[q] = 1u;
+        }
+    } else {
+        const uint32_t P = next_pow2(M < 2 ? 2 : M);
+        for (uint32_t i = M + tid; i < P; i += 256) keys[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc<256>(keys, P, tid);
+        for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = keys[i];
+        if (tid == 0) {
+            a.nbest[q] = keep;
+            a.tau[q] = (M >= a.kprime) ? key_score(keys[a.kprime - 1]) : -INFINITY;
+            if (trunc) a.overflow[q] = 1u;
+        }
     }
 }
 
@@ -104,8 +170,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     const uint32_t q = blockIdx.x;
     const uint32_t nb = a.nbest[q];
     const int grp = tid >> 3, l = tid & 7;
-    const uint64_t eb = (uint64_t)Elem<DT>::bytes * a.ld;
-    const char* qp = a.qrows + (uint64_t)q * eb;
+    const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
     if (tid == 0) maxerr = 0;
     const uint32_t P = next_pow2(nb < 2 ? 2 : nb);
     for (uint32_t i = nb + tid; i < P; i += 256) ekeys[i] = 0ull;
@@ -114,7 +179,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
         const uint64_t key = a.best[(uint64_t)q * a.kprime + c];
         const uint32_t row = key_row(key);
         const float coarse = key_score(key);
-        const float ex = exact_score_group8<DT>(a.metric, qp, a.rows + (uint64_t)row * eb, a.D, l);
+        const float ex = exact_score_group8<DT>(a.metric, qr, make_row<DT>(a.rows, row, a.ld), a.D, l);
         if (l == 0) {
             ekeys[c] = make_key(ex, row);
             float err = fabsf(ex - coarse);

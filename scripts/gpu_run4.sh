@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -x 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
+echo "== bench c2"; timeout 900 python bench.py --steps 20 --warmup 3 2>&1 | grep -v amdgpu.ids | tail -2 | tee gpurun_out/bench_c2.log
+echo "== rocprof"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cur -o c2 -- python $R/bench.py --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-600
+cd $R; python scripts/trace_timeline.py gpurun_out/prof_cur/c2_kernel_trace.csv | tee gpurun_out/timeline.txt

@@ -1,0 +1,33 @@
+import csv, glob, collections, sys, os
+d = sys.argv[1]
+allc = {}
+for f in sorted(glob.glob(os.path.join(d, 'p*_counter_collection.csv'))):
+    rows = list(csv.DictReader(open(f)))
+    by = collections.defaultdict(dict)
+    for r in rows:
+        by[int(r['Dispatch_Id'])][r['Counter_Name']] = float(r['Counter_Value'])
+        by[int(r['Dispatch_Id'])]['_grid'] = int(r['Grid_Size'])
+    if not by:
+        print(f, 'EMPTY'); continue
+    last = by[max(by)]          # the last dispatch = the main (stage 3) launch of the last search
+    for k, v in last.items():
+        allc[k] = v
+for k in sorted(allc):
+    print(f"{k:34s} {allc[k]:16.1f}")
+g = allc.get
+if g('SQ_WAVE_CYCLES'):
+    wc = g('SQ_WAVE_CYCLES')
+    print("-- fractions of SQ_WAVE_CYCLES: WAIT_ANY %.3f  WAIT_INST_ANY %.3f  ACTIVE_INST_ANY %.3f" % (
+        g('SQ_WAIT_ANY', 0) / wc, g('SQ_WAIT_INST_ANY', 0) / wc, g('SQ_ACTIVE_INST_ANY', 0) / wc))
+if g('SQ_VALU_MFMA_BUSY_CYCLES') and g('GRBM_GUI_ACTIVE'):
+    # GRBM_GUI_ACTIVE is summed over 8 XCDs; 1024 SIMDs
+    cyc = g('GRBM_GUI_ACTIVE') / 8
+    print("-- kernel cycles/XCD %.0f ; MFMA busy per SIMD %.0f ; MFMA util %.3f" % (
+        cyc, g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024, g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024 / cyc))
+if g('SQ_LDS_IDX_ACTIVE'):
+    print("-- LDS bank conflict fraction %.3f" % (g('SQ_LDS_BANK_CONFLICT', 0) / g('SQ_LDS_IDX_ACTIVE')))
+if g('FETCH_SIZE'):
+    print("-- FETCH_SIZE KB %.0f (x2 gfx950 correction => %.2f GB), WRITE_SIZE KB %.0f" % (
+        g('FETCH_SIZE'), g('FETCH_SIZE') * 2 * 1024 / 1e9, g('WRITE_SIZE', 0)))
+if g('TCC_REQ_sum'):
+    print("-- TCC hit rate %.3f" % (g('TCC_HIT_sum', 0) / (g('TCC_HIT_sum', 0) + g('TCC_MISS_sum', 1))))
