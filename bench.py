@@ -134,9 +134,18 @@ def main():
         if cms:
             flops = 2.0 * batch * coarse_rows * dim
             ach = flops / (cms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "coarse_kernel (stage 3)", "achieved": round(ach, 1),
+            traffic, traffic_src = None, None
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_main_kernel.json")) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+            if pmc and args.workload == "c2" and world == 1:
+                # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/collect_profiles.sh)
+                traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/" + pmc[-1]
+            roof = {"bound": "mfma", "kernel": "coarse_kernel (main stage)", "achieved": round(ach, 1),
                     "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4),
-                    "traffic": None, "avg_launch_ms": round(cms, 4), "rows_per_launch": int(coarse_rows),
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "avg_launch_ms": round(cms, 4), "rows_per_launch": int(coarse_rows),
                     "algorithmic_flops_per_launch": flops,
                     "algorithmic_bytes_per_launch": float(coarse_rows) * dim * 2 + batch * dim * 2 + coarse_rows * 4}
         result = {
