@@ -507,10 +507,25 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         r.eps_scale = 8.0f * (float)h->D * 5.9604645e-8f + 1e-7f;
         r.max_norm_c = h->max_norm_c;
         h->st.last_eps = r.eps_scale;
-        if (h->dtype == CGV_DTYPE_BF16)
-            hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), 0, s, r);
-        else
-            hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), 0, s, r);
+        {
+            const size_t rowb = (size_t)h->ld * 2, pitch = rowb + 16;
+            const size_t budget = 48 * 1024;  // LDS for staged rows
+            uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
+            r.rows_per_batch = rpb;
+            const size_t lds = rowb + (size_t)rpb * pitch;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_BF16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_set = true;
+            }
+            if (h->dtype == CGV_DTYPE_BF16)
+                hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r);
+            else
+                hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r);
+        }
         HIPCHK(hipGetLastError());
     }
     if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));

@@ -144,8 +144,8 @@ __device__ inline float group8_hsum(float v) {
     return z;
 }
 
-template <int DT>
-__device__ inline float exact_cosine_group8(const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
+template <class RQ, class RC>
+__device__ inline float exact_cosine_group8(const RQ& q, const RC& c, uint32_t D, int l) {
     float result = 0.0f;
     if (D >= 32) {  // adaptive_cosine_similarity dispatch, simd_ops.rs:281-295
         float dp = 0.0f, na = 0.0f, nb = 0.0f;
@@ -186,8 +186,8 @@ __device__ inline float exact_cosine_group8(const Row<DT>& q, const Row<DT>& c, 
     return result;
 }
 
-template <int DT>
-__device__ inline float exact_dot_group8(const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
+template <class RQ, class RC>
+__device__ inline float exact_dot_group8(const RQ& q, const RC& c, uint32_t D, int l) {
     // dot_product_avx2, simd_ops.rs:149-183
     float dp = 0.0f;
     const uint32_t chunks = D / 8;
@@ -202,9 +202,41 @@ __device__ inline float exact_dot_group8(const Row<DT>& q, const Row<DT>& c, uin
     return result;
 }
 
+template <class RQ, class RC>
+__device__ inline float exact_score_group8(int metric, const RQ& q, const RC& c, uint32_t D, int l) {
+    return metric == METRIC_DOT ? exact_dot_group8(q, c, D, l) : exact_cosine_group8(q, c, D, l);
+}
+
+// A row staged in LDS as linear [ld] storage-dtype elements.
 template <int DT>
-__device__ inline float exact_score_group8(int metric, const Row<DT>& q, const Row<DT>& c, uint32_t D, int l) {
-    return metric == METRIC_DOT ? exact_dot_group8<DT>(q, c, D, l) : exact_cosine_group8<DT>(q, c, D, l);
+struct LdsRow {
+    const char* p;
+    __device__ inline float at(uint32_t i) const { return Elem<DT>::cvt_load(p + (size_t)i * Elem<DT>::bytes); }
+};
+
+// Wave-wide (64 lanes) unsigned max, result uniform. DPP row operations + 4 readlanes:
+// ~20 issue slots, versus ~1.4k cycles for a 6-step ds_bpermute (__shfl_xor) butterfly.
+__device__ inline uint32_t wave_max_u32(uint32_t x) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x = t > x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x = t > x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x = t > x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false);  // row_mirror
+    x = t > x ? t : x;
+    const uint32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// 64-bit max as two 32-bit phases (high word, then low word among the lanes that hold it).
+__device__ inline uint64_t wave_max_u64(uint64_t k) {
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t mh = wave_max_u32(hi);
+    const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((uint64_t)mh << 32) | ml;
 }
 
 // In-LDS bitonic sort, descending, P a power of two, NT threads.

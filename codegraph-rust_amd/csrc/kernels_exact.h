@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
     const uint32_t q = qlist ? qlist[qi] : qi;
     const Row<DT> qr = make_row<DT>(qrows, q, ld);
     for (uint64_t row = (uint64_t)blockIdx.x * 32 + grp; row < n; row += (uint64_t)gridDim.x * 32) {
-        const float s = exact_score_group8<DT>(metric, qr, make_row<DT>(rows, row, ld), D, l);
+        const float s = exact_score_group8(metric, qr, make_row<DT>(rows, row, ld), D, l);
         if (l == 0) scores[(uint64_t)qi * n + row] = s;
     }
 }

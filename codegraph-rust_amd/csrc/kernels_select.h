@@ -21,104 +21,182 @@ struct SelectArgs {
     uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
 };
 
-// One workgroup (256 threads) per query: merge best[q] with the nsplit candidate
-// sub-lists written by the last coarse launch (or with the dense boot scores), keep the
-// top-k', publish tau[q] = the k'-th best coarse score seen so far (a valid lower bound of
-// the final k'-th best).
-//   gather : 256/nsplit threads per sub-list copy it into LDS (prefix sums give the offsets)
-//   select : k' <= 64 -> k' rounds of workgroup arg-max over the LDS keys (no full sort:
-//            M is ~1e3 and k' ~16); larger k' -> LDS bitonic sort.
-__global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = (uint64_t*)smem;                            // [lds_keys]
-    uint32_t* pre = (uint32_t*)(smem + (size_t)a.lds_keys * 8);  // [nsplit + 1]
-    __shared__ uint64_t wmax[4];
-    __shared__ uint64_t outk[64];
-    const int tid = threadIdx.x;
-    const uint32_t q = blockIdx.x;
+// ---- shared pieces of the select / final kernels ------------------------------------
+
+// Gather the keys of query (qt, ql) into LDS: best[q][0..nb) followed by the nsplit candidate
+// sub-lists of the last coarse launch (or the dense boot scores). Returns M (clamped to
+// lds_keys; *trunc set when clamped). Memory-latency bound, so it is written as two
+// round trips: (1) nbest + all sub-list counts, (2) every candidate load issued before the
+// first LDS store (4 independent 8-byte loads per thread per batch).
+__device__ inline uint32_t gather_keys(const SelectArgs& a, uint32_t q, uint64_t* keys, uint32_t* pre, int tid,
+                                       bool* trunc) {
     const uint32_t qt = q / a.bn, ql = q % a.bn;
     const uint32_t nb = a.nbest[q];
     uint32_t M;
-    bool trunc = false;
     if (a.dense) {
         M = nb + a.n_dense;
         if (M > a.lds_keys) {
-            trunc = true;
+            *trunc = true;
             M = a.lds_keys;
         }
         for (uint32_t e = tid; e < M; e += 256)
             keys[e] = (e < nb) ? a.best[(uint64_t)q * a.kprime + e]
                                : make_key(a.dense[(uint64_t)q * a.n_dense + (e - nb)], e - nb);
-    } else {
-        // exclusive prefix of the sub-list counts: pre[s] = nb + sum_{s' < s} cnt[s']
-        if (tid < 64) {
-            const uint32_t per = (a.nsplit + 63) / 64;
-            uint32_t loc = 0;
-            for (uint32_t i = 0; i < per; ++i) {
-                const uint32_t s = tid * per + i;
-                if (s < a.nsplit) loc += a.cand_cnt[(uint64_t)(qt + s * a.nqt) * a.bn + ql];
-            }
-            uint32_t inc = loc;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += v;
-            }
-            uint32_t run = nb + inc - loc;
-            for (uint32_t i = 0; i < per; ++i) {
-                const uint32_t s = tid * per + i;
-                if (s < a.nsplit) {
-                    pre[s] = run;
-                    run += a.cand_cnt[(uint64_t)(qt + s * a.nqt) * a.bn + ql];
-                }
-            }
-            if (tid == 63) pre[a.nsplit] = nb + inc;
-        }
         __syncthreads();
-        M = pre[a.nsplit];
-        if (M > a.lds_keys) {  // cannot happen with sane thresholds; flag for the exact path
-            trunc = true;
-            M = a.lds_keys;
+        return M;
+    }
+    if (tid < 64) {  // exclusive prefix of the sub-list counts: pre[s] = nb + sum_{s' < s} cnt[s']
+        uint32_t cnt[4] = {0, 0, 0, 0};  // nsplit <= 256
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t sidx = tid * 4 + i;
+            if (sidx < a.nsplit) cnt[i] = a.cand_cnt[(uint64_t)(qt + sidx * a.nqt) * a.bn + ql];
         }
-        for (uint32_t e = tid; e < nb && e < M; e += 256) keys[e] = a.best[(uint64_t)q * a.kprime + e];
-        // tps threads per sub-list (power of two), sub-lists in rounds of 256/tps
-        uint32_t tps = 256;
-        while (tps > 1 && tps * a.nsplit > 256) tps >>= 1;
-        const uint32_t per_round = 256 / tps;
-        const uint32_t sub = tid % tps;
-        for (uint32_t s = tid / tps; s < a.nsplit; s += per_round) {
-            const uint32_t lo = pre[s], hi = pre[s + 1];
-            const uint2* src = a.cand + ((uint64_t)(qt + s * a.nqt) * a.bn + ql) * CAND_CAPS;
-            for (uint32_t e = lo + sub; e < hi && e < M; e += tps) {
-                const uint2 c = src[e - lo];
-                keys[e] = make_key(__uint_as_float(c.x), c.y);
+        const uint32_t loc = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        uint32_t inc = loc;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += v;
+        }
+        uint32_t run = nb + inc - loc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t sidx = tid * 4 + i;
+            if (sidx < a.nsplit) pre[sidx] = run;
+            run += cnt[i];
+        }
+        if (tid == 63) pre[a.nsplit] = nb + inc;
+    }
+    __syncthreads();
+    M = pre[a.nsplit];
+    if (M > a.lds_keys) {  // cannot happen with sane thresholds; flag for the exact path
+        *trunc = true;
+        M = a.lds_keys;
+    }
+    for (uint32_t e = tid; e < nb && e < M; e += 256) keys[e] = a.best[(uint64_t)q * a.kprime + e];
+    uint32_t tps = 256;  // threads per sub-list (power of two)
+    while (tps > 1 && tps * a.nsplit > 256) tps >>= 1;
+    const uint32_t per_round = 256 / tps, sub = tid % tps;
+    for (uint32_t sidx = tid / tps; sidx < a.nsplit; sidx += per_round) {
+        const uint32_t lo = pre[sidx], hi = pre[sidx + 1] < M ? pre[sidx + 1] : M;
+        const uint2* src = a.cand + ((uint64_t)(qt + sidx * a.nqt) * a.bn + ql) * CAND_CAPS;
+        for (uint32_t e0 = lo + sub; e0 < hi; e0 += 4 * tps) {
+            uint2 c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * tps;
+                c[i] = (e < hi) ? src[e - lo] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * tps;
+                if (e < hi) keys[e] = make_key(__uint_as_float(c[i].x), c[i].y);
             }
         }
     }
-    const uint32_t keep = M < a.kprime ? M : a.kprime;
-    if (a.kprime <= 64) {
-        __syncthreads();
-        // keep rounds of arg-max; keys are unique, the owner zeroes the winner
-        for (uint32_t r = 0; r < keep; ++r) {
+    __syncthreads();
+    return M;
+}
+
+__device__ inline void cmpx_desc(uint64_t& x, uint64_t& y) {  // compare-exchange: x >= y afterwards
+    const uint64_t hi = x > y ? x : y, lo = x > y ? y : x;
+    x = hi;
+    y = lo;
+}
+
+// Top-`keep` (keep <= 64) of keys[0..M) -> outk[0..keep) sorted descending. 256 threads.
+// M <= 2048: every lane keeps its <= 8 keys SORTED IN REGISTERS, a round is one wave-wide max
+// (DPP) + a register shift in the owner; larger M: lane-private LDS rescans. The four per-wave
+// lists (already sorted) are merged by one lane.
+__device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, uint64_t* part /*[4*64]*/,
+                                    uint64_t* outk /*[64]*/, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    if (M <= 2048) {
+        uint64_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t e = (uint32_t)tid + 256u * i;
+            r[i] = e < M ? keys[e] : 0ull;
+        }
+        // 8-input sorting network (19 compare-exchanges), descending
+        cmpx_desc(r[0], r[1]); cmpx_desc(r[2], r[3]); cmpx_desc(r[4], r[5]); cmpx_desc(r[6], r[7]);
+        cmpx_desc(r[0], r[2]); cmpx_desc(r[1], r[3]); cmpx_desc(r[4], r[6]); cmpx_desc(r[5], r[7]);
+        cmpx_desc(r[1], r[2]); cmpx_desc(r[5], r[6]); cmpx_desc(r[0], r[4]); cmpx_desc(r[3], r[7]);
+        cmpx_desc(r[1], r[5]); cmpx_desc(r[2], r[6]);
+        cmpx_desc(r[1], r[4]); cmpx_desc(r[3], r[6]);
+        cmpx_desc(r[2], r[4]); cmpx_desc(r[3], r[5]);
+        cmpx_desc(r[3], r[4]);
+        for (uint32_t rd = 0; rd < keep; ++rd) {
+            const uint64_t w = wave_max_u64(r[0]);
+            if (w != 0ull && r[0] == w) {  // keys are unique: exactly one owner
+#pragma unroll
+                for (int i = 0; i < 7; ++i) r[i] = r[i + 1];
+                r[7] = 0ull;
+            }
+            if (lane == 0) part[wv * 64 + rd] = w;
+        }
+    } else {
+        auto lane_max = [&](uint32_t& at) {
             uint64_t mx = 0ull;
+            at = 0xFFFFFFFFu;
             for (uint32_t e = tid; e < M; e += 256) {
                 const uint64_t v = keys[e];
-                mx = v > mx ? v : mx;
+                if (v > mx) {
+                    mx = v;
+                    at = e;
+                }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint64_t o = __shfl_xor(mx, off, 64);
-                mx = o > mx ? o : mx;
+            return mx;
+        };
+        uint32_t my_at;
+        uint64_t my_mx = lane_max(my_at);
+        for (uint32_t rd = 0; rd < keep; ++rd) {
+            const uint64_t w = wave_max_u64(my_mx);
+            if (w != 0ull && my_mx == w) {
+                keys[my_at] = 0ull;
+                my_mx = lane_max(my_at);
             }
-            if ((tid & 63) == 0) wmax[tid >> 6] = mx;
-            __syncthreads();
-            uint64_t w = wmax[0];
-            w = wmax[1] > w ? wmax[1] : w;
-            w = wmax[2] > w ? wmax[2] : w;
-            w = wmax[3] > w ? wmax[3] : w;
-            for (uint32_t e = tid; e < M; e += 256)
-                if (keys[e] == w) keys[e] = 0ull;
-            if (tid == 0) outk[r] = w;
-            __syncthreads();
+            if (lane == 0) part[wv * 64 + rd] = w;
         }
+    }
+    __syncthreads();
+    if (tid == 0) {  // 4-way merge of the sorted per-wave lists
+        uint32_t h[4] = {0, 0, 0, 0};
+        for (uint32_t rd = 0; rd < keep; ++rd) {
+            uint64_t best = 0ull;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t v = h[i] < keep ? part[i * 64 + h[i]] : 0ull;
+                if (v > best) {
+                    best = v;
+                    bi = i;
+                }
+            }
+            h[bi]++;
+            outk[rd] = best;
+        }
+    }
+    __syncthreads();
+}
+
+// One workgroup (256 threads) per query: merge best[q] with the nsplit candidate
+// sub-lists written by the last coarse launch (or with the dense boot scores), keep the
+// top-k', publish tau[q] = the k'-th best coarse score seen so far (a valid lower bound of
+// the final k'-th best). k' <= 64: register-resident extraction; larger k': LDS bitonic sort.
+__global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* keys = (uint64_t*)smem;                            // [lds_keys]
+    uint32_t* pre = (uint32_t*)(smem + (size_t)a.lds_keys * 8);  // [nsplit + 1]
+    __shared__ uint64_t part[4 * 64];
+    __shared__ uint64_t outk[64];
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    bool trunc = false;
+    const uint32_t M = gather_keys(a, q, keys, pre, tid, &trunc);
+    const uint32_t keep = M < a.kprime ? M : a.kprime;
+    if (a.kprime <= 64) {
+        extract_topk(keys, M, keep, part, outk, tid);
         for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
         if (tid == 0) {
             a.nbest[q] = keep;
@@ -154,36 +232,74 @@ struct RescoreArgs {
     uint32_t* stat_maxerr;  // [1] f2ord(max |coarse-exact|)
     uint64_t index_base;
     uint32_t nq, n, D, ld, kprime, k, metric;
+    uint32_t rows_per_batch;  // candidate rows staged in LDS per pass
     float eps_scale;        // cosine: eps; dot: eps = eps_scale * |q| * max|c|
     float max_norm_c;
 };
 
-// One workgroup per query: exact reference arithmetic on the k' candidates
-// (8 lanes per candidate, see common.h), exact (score desc, row asc) ordering,
-// and the guarantee check  e_k > tau + eps  (every row outside the candidate set has
+// Exact reference arithmetic on the k' candidates of each query, exact (score desc, row asc)
+// ordering, and the guarantee check  e_k > tau + eps  (every row outside the candidate set has
 // coarse <= tau, hence exact <= tau + eps < e_k).
+// One workgroup (256 threads) per query. The k' candidate rows are gathered from HBM into
+// LDS cooperatively (every 16-byte piece is an independent load: one memory round trip instead
+// of a serial walk over 12+ cache lines per row); then 8 lanes per candidate = the 8 AVX2 lanes
+// of the reference (common.h) run the FMA chains out of LDS, 32 candidates at a time.
+// Dynamic LDS: [query row: ld*2 B][batch rows: (ld*2 + 16) B each, +16 B pad against bank
+// conflicts]. rows_per_batch is chosen by the host (>= 1).
 template <int DT>
 __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint64_t ekeys[CAND_CAPS];
     __shared__ uint32_t maxerr;
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t nb = a.nbest[q];
-    const int grp = tid >> 3, l = tid & 7;
-    const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
+    const uint32_t rowb = a.ld * 2, pitch = rowb + 16, pieces = rowb / 16;
+    char* qs = smem;
+    char* rs = smem + rowb;
     if (tid == 0) maxerr = 0;
     const uint32_t P = next_pow2(nb < 2 ? 2 : nb);
     for (uint32_t i = nb + tid; i < P; i += 256) ekeys[i] = 0ull;
-    __syncthreads();
-    for (uint32_t c = grp; c < nb; c += 32) {
-        const uint64_t key = a.best[(uint64_t)q * a.kprime + c];
-        const uint32_t row = key_row(key);
-        const float coarse = key_score(key);
-        const float ex = exact_score_group8<DT>(a.metric, qr, make_row<DT>(a.rows, row, a.ld), a.D, l);
-        if (l == 0) {
-            ekeys[c] = make_key(ex, row);
-            float err = fabsf(ex - coarse);
-            if (err == err) atomicMax(&maxerr, __float_as_uint(err));
+    {   // query row -> LDS (linear element order)
+        const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
+        for (uint32_t pc = tid; pc < pieces; pc += 256)
+            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)(qr.p + blocked_elem_off(pc * 8, qr.key));
+    }
+    for (uint32_t c0 = 0; c0 < nb; c0 += a.rows_per_batch) {
+        const uint32_t nbat = (nb - c0) < a.rows_per_batch ? (nb - c0) : a.rows_per_batch;
+        __syncthreads();
+        const uint32_t total = nbat * pieces;
+        for (uint32_t e0 = tid; e0 < total; e0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * 256;
+                if (e < total) {
+                    const uint32_t c = e / pieces, pc = e % pieces;
+                    const uint32_t row = key_row(a.best[(uint64_t)q * a.kprime + c0 + c]);
+                    v[i] = *(const uint4*)(a.rows + blocked_row_base(row, a.ld) +
+                                           blocked_elem_off(pc * 8, blocked_row_key(row)));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * 256;
+                if (e < total) *(uint4*)(rs + (size_t)(e / pieces) * pitch + (size_t)(e % pieces) * 16) = v[i];
+            }
+        }
+        __syncthreads();
+        const LdsRow<DT> ql{qs};
+        for (uint32_t c = (uint32_t)tid >> 3; c < nbat; c += 32) {
+            const uint64_t key = a.best[(uint64_t)q * a.kprime + c0 + c];
+            const uint32_t row = key_row(key);
+            const float coarse = key_score(key);
+            const LdsRow<DT> cl{rs + (size_t)c * pitch};
+            const float ex = exact_score_group8(a.metric, ql, cl, a.D, tid & 7);
+            if ((tid & 7) == 0) {
+                ekeys[c0 + c] = make_key(ex, row);
+                const float err = fabsf(ex - coarse);
+                if (err == err) atomicMax(&maxerr, __float_as_uint(err));
+            }
         }
     }
     __syncthreads();
