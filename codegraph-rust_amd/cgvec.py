@@ -76,6 +76,7 @@ def lib():
     L.cgv_dim.argtypes = [vp]
     L.cgv_dim.restype = u32
     L.cgv_set_index_base.argtypes = [vp, u64]
+    L.cgv_update_row_f32.argtypes = [vp, u64, vp]
     L.cgv_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_search_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_get_row_f32.argtypes = [vp, u64, vp]
@@ -88,7 +89,7 @@ def lib():
     L.cgv_set_force_exact.argtypes = [vp, i32]
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
     for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
-                 "cgv_set_index_base", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
+                 "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
                  "cgv_merge_topk_dev", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
         getattr(L, name).restype = i32
@@ -185,6 +186,12 @@ class HipKnnIndex:
         if r.ndim != 2 or r.shape[1] != self.dim:
             raise CgvError(CGV_ERR_DIM_MISMATCH, f"expected [n,{self.dim}] rows, got {r.shape}")
         _check(lib().cgv_add_f32(self._h, r.ctypes.data_as(C.c_void_p), r.shape[0]))
+
+    def update_row(self, i, row):
+        r = np.ascontiguousarray(row, dtype=np.float32)
+        if r.size != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"row dim {r.size} != {self.dim}")
+        _check(lib().cgv_update_row_f32(self._h, int(i), r.ctypes.data_as(C.c_void_p)))
 
     def get_row(self, i):
         out = np.empty(self.dim, dtype=np.float32)

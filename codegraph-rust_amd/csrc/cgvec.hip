@@ -565,7 +565,10 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 1u; }
+uint32_t cgv_version(void) { return (0u << 16) | 2u; }
+
+// internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
+int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 const char* cgv_last_error(void) { return g_err.c_str(); }
 
@@ -670,6 +673,34 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
         HIPCHK(hipMemcpyAsync(h->addstage.p, rows_host + r0 * h->D, (size_t)c * h->D * 4, hipMemcpyHostToDevice,
                               h->stream));
         if ((rc = add_dev_locked(h, h->addstage.as<float>(), c))) return rc;
+    }
+    return CGV_OK;
+}
+
+int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
+    if (!h || !row_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->addstage.ensure((size_t)h->D * 4))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->addstage.p, row_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
+    rc = prep_dispatch(h->dtype, h->addstage.as<float>(), 1, h->D, h->ld, id, h->rows, h->norm, h->invn,
+                       h->flags + F_NONFINITE_C, s);
+    if (rc) return rc;
+    const uint64_t b0 = id / 32;
+    hipLaunchKernelGGL(block_norm_stats_kernel, dim3(1), dim3(256), 0, s, h->norm, h->n, b0, b0 + 1, h->blk_min,
+                       h->blk_max);
+    hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, id, id + 1, h->max_norm_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
+    if (h->h_flags[F_NONFINITE_C]) {
+        h->corpus_nonfinite = true;
+        return fail(CGV_ERR_NONFINITE, "row contains NaN/Inf (the reference panics on NaN at simd_ops.rs:379)");
     }
     return CGV_OK;
 }

@@ -1,0 +1,791 @@
+// store.cpp — host-side mirror (C++) of the reference's vector-store surface over the HIP
+// kNN library. The reference is Rust; with no Rust toolchain in the build image the host
+// code above the C ABI is C++ (see include/cgvec_store.h for the file:line of every item
+// mirrored). Only the caller-side logic lives here (id mapping, prefetch rule, the per-hit
+// re-score of search.rs:119-137, min-max normalisation, filters, OR/AND merging); the kNN
+// itself always runs on the GPU through cgv_search_f32 — there is no CPU search path.
+// Compiled with -ffp-contract=off: the scalar formulas must round like the Rust code does.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/cgvec.h"
+#include "../../include/cgvec_store.h"
+
+extern "C" int cgv_set_error_(int code, const char* msg);  // defined in cgvec.hip (shared thread-local message)
+
+namespace {
+
+int fail(int code, const std::string& m) { return cgv_set_error_(code, m.c_str()); }
+
+// ---- NodeId (Uuid) ------------------------------------------------------------------
+using NodeId = std::array<uint8_t, 16>;
+struct NodeIdHash {
+    size_t operator()(const NodeId& id) const {
+        uint64_t a, b;
+        memcpy(&a, id.data(), 8);
+        memcpy(&b, id.data() + 8, 8);
+        return (size_t)(a * 0x9E3779B97F4A7C15ull ^ b);
+    }
+};
+
+int hexval(char c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+// Uuid::parse_str: hyphenated, simple (32 hex), braced, urn:uuid: forms.
+bool parse_uuid(const std::string& in, NodeId& out, std::string& why) {
+    std::string s = in;
+    if (s.rfind("urn:uuid:", 0) == 0) s = s.substr(9);
+    if (s.size() >= 2 && s.front() == '{' && s.back() == '}') s = s.substr(1, s.size() - 2);
+    std::string hex;
+    if (s.size() == 36) {
+        for (size_t i = 0; i < 36; ++i) {
+            const bool dash = (i == 8 || i == 13 || i == 18 || i == 23);
+            if (dash) {
+                if (s[i] != '-') {
+                    why = "invalid group separator";
+                    return false;
+                }
+            } else {
+                hex.push_back(s[i]);
+            }
+        }
+    } else if (s.size() == 32) {
+        hex = s;
+    } else {
+        why = "invalid length: expected length 32 for simple format, found " + std::to_string(s.size());
+        return false;
+    }
+    for (int i = 0; i < 16; ++i) {
+        const int h = hexval(hex[2 * i]), l = hexval(hex[2 * i + 1]);
+        if (h < 0 || l < 0) {
+            why = "invalid character";
+            return false;
+        }
+        out[i] = (uint8_t)(h * 16 + l);
+    }
+    return true;
+}
+
+std::string format_uuid(const NodeId& id) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (int i = 0; i < 16; ++i) {
+        if (i == 4 || i == 6 || i == 8 || i == 10) s.push_back('-');
+        s.push_back(d[id[i] >> 4]);
+        s.push_back(d[id[i] & 15]);
+    }
+    return s;
+}
+
+// ---- free functions of the mirrored surface ------------------------------------------
+
+// surrealdb_storage.rs:1932-1952 (unsupported dimension: warn, fall back to 2048)
+const char* column_for_dimension(size_t dim) {
+    switch (dim) {
+        case 384: return "embedding_384";
+        case 768: return "embedding_768";
+        case 1024: return "embedding_1024";
+        case 1536: return "embedding_1536";
+        case 2048: return "embedding_2048";
+        case 2560: return "embedding_2560";
+        case 3072: return "embedding_3072";
+        case 4096: return "embedding_4096";
+        default:
+            fprintf(stderr,
+                    "WARN Unsupported embedding dimension %zu, falling back to 2048. Supported dimensions: 384, "
+                    "768, 1024, 1536, 2048, 2560, 3072, 4096\n",
+                    dim);
+            return "embedding_2048";
+    }
+}
+
+// surreal_store.rs:123-128: strip everything up to the LAST ':'
+std::string normalize_surreal_node_id(const std::string& raw) {
+    const size_t p = raw.rfind(':');
+    return p == std::string::npos ? raw : raw.substr(p + 1);
+}
+
+// search.rs:519-533 (sequential f32 sums, no FMA; zero norm or length mismatch -> 0.0)
+float cosine_similarity(const float* a, size_t na, const float* b, size_t nb) {
+    if (na != nb) return 0.0f;
+    float dot = 0.0f, sa = 0.0f, sb = 0.0f;
+    for (size_t i = 0; i < na; ++i) dot += a[i] * b[i];
+    for (size_t i = 0; i < na; ++i) sa += a[i] * a[i];
+    for (size_t i = 0; i < na; ++i) sb += b[i] * b[i];
+    const float norm_a = sqrtf(sa), norm_b = sqrtf(sb);
+    if (norm_a == 0.0f || norm_b == 0.0f) return 0.0f;
+    return dot / (norm_a * norm_b);
+}
+
+uint64_t prefetch_k(uint64_t limit) {  // search.rs:113
+    const uint64_t t = limit > UINT64_MAX / 3 ? UINT64_MAX : limit * 3;
+    return std::max<uint64_t>(t, limit + 10);
+}
+
+struct SearchResult {
+    NodeId node_id;
+    float score;
+};
+
+void normalize_scores(std::vector<SearchResult>& r) {  // search.rs:574-592
+    if (r.empty()) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (auto& x : r) {
+        if (x.score < mn) mn = x.score;
+        if (x.score > mx) mx = x.score;
+    }
+    float range = mx - mn;
+    if (!(range > 1e-12f)) range = 1e-12f;
+    for (auto& x : r) x.score = (x.score - mn) / range;
+}
+
+void stable_sort_desc(std::vector<SearchResult>& r) {  // sort_by(b.partial_cmp(a).unwrap_or(Equal))
+    std::stable_sort(r.begin(), r.end(), [](const SearchResult& a, const SearchResult& b) { return a.score > b.score; });
+}
+
+uint32_t simple_hash(const std::string& text) {  // search.rs:535-541
+    uint32_t h = 5381u;
+    for (unsigned char c : text) h = h * 33u + (uint32_t)c;
+    return h;
+}
+
+void hash_embed(const std::string& text, uint32_t dim, float* out) {  // search.rs:178-205
+    uint32_t s = simple_hash(text);
+    const float umax = (float)UINT32_MAX;
+    for (uint32_t i = 0; i < dim; ++i) {
+        s = s * 1103515245u + 12345u;
+        out[i] = (((float)s / umax) - 0.5f) * 2.0f;
+    }
+    float nsq = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) nsq += out[i] * out[i];
+    const float norm = sqrtf(nsq);
+    if (norm > 0.0f)
+        for (uint32_t i = 0; i < dim; ++i) out[i] /= norm;
+}
+
+// ---- trait SurrealVectorBackend (surreal_store.rs:11-22) ------------------------------
+struct Node {
+    NodeId id;
+    const float* embedding;  // may be null (CodeNode.embedding: Option<Vec<f32>>)
+    uint32_t dim;
+};
+
+struct SurrealVectorBackend {
+    virtual ~SurrealVectorBackend() {}
+    virtual int upsert_nodes(const std::vector<Node>& nodes) = 0;
+    virtual int vector_knn(const std::string& column, const std::vector<float>& query, size_t limit, size_t ef_search,
+                           std::vector<std::pair<std::string, float>>& out) = 0;
+    // batched extension (the caller shape is multi_vector_search, search.rs:358-361)
+    virtual int vector_knn_batch(const std::string& column, const float* queries, size_t nq, size_t dim, size_t limit,
+                                 size_t ef_search, std::vector<std::vector<std::pair<std::string, float>>>& out) {
+        out.resize(nq);
+        for (size_t i = 0; i < nq; ++i) {
+            std::vector<float> q(queries + i * dim, queries + (i + 1) * dim);
+            int rc = vector_knn(column, q, limit, ef_search, out[i]);
+            if (rc) return rc;
+        }
+        return CGV_OK;
+    }
+    virtual int get_node_embedding(const NodeId& id, std::vector<float>& out, bool& found) = 0;
+};
+
+// The GPU backend: one device index per embedding column.
+class HipKnnBackend : public SurrealVectorBackend {
+   public:
+    HipKnnBackend(int dtype, int device) : dtype_(dtype), device_(device) {}
+    ~HipKnnBackend() override {
+        for (auto& kv : cols_) cgv_destroy(kv.second.h);
+    }
+    int upsert_nodes(const std::vector<Node>& nodes) override {
+        // group appended rows per column so that each column gets one cgv_add_f32
+        std::map<std::string, std::vector<const Node*>> fresh;
+        for (const Node& n : nodes) {
+            if (!n.embedding) continue;
+            const std::string col = column_for_dimension(n.dim);
+            Column* c = nullptr;
+            int rc = column(col, n.dim, &c);
+            if (rc) return rc;
+            if (c->dim != n.dim) return fail(CGV_ERR_DIM_MISMATCH, "embedding dimension does not match column " + col);
+            auto it = c->row_of.find(n.id);
+            if (it != c->row_of.end()) {  // UPSERT of a known id: rewrite the stored row in place
+                if ((rc = cgv_update_row_f32(c->h, it->second, n.embedding))) return rc;
+            } else {
+                fresh[col].push_back(&n);
+            }
+        }
+        for (auto& kv : fresh) {
+            Column& c = cols_[kv.first];
+            std::vector<float> flat;
+            flat.reserve(kv.second.size() * c.dim);
+            std::vector<NodeId> ids;
+            for (const Node* n : kv.second) {
+                if (c.row_of.count(n->id)) continue;  // duplicate id inside this batch: first wins, then update
+                c.row_of[n->id] = c.ids.size() + ids.size();
+                ids.push_back(n->id);
+                flat.insert(flat.end(), n->embedding, n->embedding + c.dim);
+            }
+            const uint64_t before = cgv_count(c.h);
+            int rc = cgv_add_f32(c.h, flat.data(), ids.size());
+            if (rc) {
+                for (auto& id : ids) c.row_of.erase(id);
+                (void)before;
+                return rc;
+            }
+            c.ids.insert(c.ids.end(), ids.begin(), ids.end());
+        }
+        return CGV_OK;
+    }
+    int vector_knn(const std::string& column_name, const std::vector<float>& query, size_t limit, size_t ef_search,
+                   std::vector<std::pair<std::string, float>>& out) override {
+        std::vector<std::vector<std::pair<std::string, float>>> o;
+        int rc = vector_knn_batch(column_name, query.data(), 1, query.size(), limit, ef_search, o);
+        if (rc) return rc;
+        out = std::move(o[0]);
+        return CGV_OK;
+    }
+    int vector_knn_batch(const std::string& column_name, const float* queries, size_t nq, size_t dim, size_t limit,
+                         size_t /*ef_search: exact search, no beam width*/,
+                         std::vector<std::vector<std::pair<std::string, float>>>& out) override {
+        out.assign(nq, {});
+        auto it = cols_.find(column_name);
+        if (it == cols_.end() || limit == 0 || nq == 0) return CGV_OK;  // empty column: no neighbours
+        Column& c = it->second;
+        if (dim != c.dim) return fail(CGV_ERR_DIM_MISMATCH, "query dimension " + std::to_string(dim) + " != column " + column_name);
+        const size_t k = std::min<size_t>(limit, CGV_MAX_K);
+        std::vector<uint64_t> idx(nq * k);
+        std::vector<float> sc(nq * k);
+        int rc = cgv_search_f32(c.h, queries, (uint32_t)nq, (uint32_t)k, idx.data(), sc.data());
+        if (rc) return rc;
+        for (size_t q = 0; q < nq; ++q)
+            for (size_t j = 0; j < k; ++j) {
+                const uint64_t r = idx[q * k + j];
+                if (r == UINT64_MAX) break;
+                // the seam's contract: "nodes:<uuid>", distance ascending = 1 - cosine
+                // (surrealdb_storage.rs:297-301 ORDER BY score ASC)
+                out[q].push_back({"nodes:" + format_uuid(c.ids[(size_t)r]), 1.0f - sc[q * k + j]});
+            }
+        return CGV_OK;
+    }
+    int get_node_embedding(const NodeId& id, std::vector<float>& out, bool& found) override {
+        found = false;
+        for (auto& kv : cols_) {
+            auto it = kv.second.row_of.find(id);
+            if (it == kv.second.row_of.end()) continue;
+            out.resize(kv.second.dim);
+            int rc = cgv_get_row_f32(kv.second.h, it->second, out.data());
+            if (rc) return rc;
+            found = true;
+            return CGV_OK;
+        }
+        return CGV_OK;
+    }
+
+   private:
+    struct Column {
+        cgv_index* h = nullptr;
+        uint32_t dim = 0;
+        std::vector<NodeId> ids;                                  // row -> NodeId
+        std::unordered_map<NodeId, uint64_t, NodeIdHash> row_of;  // NodeId -> row
+    };
+    int column(const std::string& name, uint32_t dim, Column** out) {
+        auto it = cols_.find(name);
+        if (it == cols_.end()) {
+            Column c;
+            c.dim = dim;
+            int rc = cgv_create(dim, CGV_METRIC_COSINE, dtype_, device_, &c.h);
+            if (rc) return rc;
+            it = cols_.emplace(name, std::move(c)).first;
+        }
+        *out = &it->second;
+        return CGV_OK;
+    }
+    int dtype_, device_;
+    std::map<std::string, Column> cols_;
+};
+
+// surreal_store.rs:167-205 MockBackend (the reference's own test double for this seam)
+class MockBackend : public SurrealVectorBackend {
+   public:
+    explicit MockBackend(std::vector<std::pair<std::string, float>> r) : results_(std::move(r)) {}
+    int upsert_nodes(const std::vector<Node>&) override { return CGV_OK; }
+    int vector_knn(const std::string& column, const std::vector<float>&, size_t, size_t,
+                   std::vector<std::pair<std::string, float>>& out) override {
+        columns.push_back(column);
+        out = results_;
+        return CGV_OK;
+    }
+    int get_node_embedding(const NodeId&, std::vector<float>&, bool& found) override {
+        found = false;
+        return CGV_OK;
+    }
+    std::vector<std::string> columns;
+
+   private:
+    std::vector<std::pair<std::string, float>> results_;
+};
+
+struct NodeMeta {
+    std::string language, node_type, file_path;
+    std::map<std::string, std::string> attributes;
+    bool has_language = false, has_node_type = false;
+};
+
+struct Filters {
+    bool has_languages = false, has_node_types = false;
+    std::vector<std::string> languages, node_types, path_prefixes;
+    std::vector<std::pair<std::string, std::string>> attrs;
+};
+
+Filters make_filters(const cgvs_filters* f) {
+    Filters r;
+    if (!f) return r;
+    if (f->languages) {
+        r.has_languages = true;
+        for (uint32_t i = 0; i < f->n_languages; ++i) r.languages.push_back(f->languages[i]);
+    }
+    if (f->node_types) {
+        r.has_node_types = true;
+        for (uint32_t i = 0; i < f->n_node_types; ++i) r.node_types.push_back(f->node_types[i]);
+    }
+    for (uint32_t i = 0; i < f->n_attrs; ++i) r.attrs.push_back({f->attr_keys[i], f->attr_values[i]});
+    for (uint32_t i = 0; i < f->n_path_prefixes; ++i) r.path_prefixes.push_back(f->path_prefixes[i]);
+    return r;
+}
+
+bool contains(const std::vector<std::string>& v, const std::string& s) { return std::find(v.begin(), v.end(), s) != v.end(); }
+bool starts_with(const std::string& s, const std::string& p) { return s.compare(0, p.size(), p) == 0; }
+
+}  // namespace
+
+// SurrealVectorStore (surreal_store.rs:25-86) + SemanticSearch (search.rs) over one backend.
+struct cgvs_store {
+    std::unique_ptr<SurrealVectorBackend> backend;
+    MockBackend* mock = nullptr;
+    size_t ef_search = 100;
+    std::unordered_map<NodeId, NodeMeta, NodeIdHash> node_metadata;
+    std::mutex mu;
+
+    // VectorStore::search_similar, surreal_store.rs:61-85
+    int search_similar(const float* q, size_t dim, size_t limit, std::vector<NodeId>& out) {
+        out.clear();
+        if (dim == 0 || limit == 0) return CGV_OK;
+        const std::string column = column_for_dimension(dim);
+        std::vector<std::pair<std::string, float>> neighbors;
+        int rc = backend->vector_knn(column, std::vector<float>(q, q + dim), limit, ef_search, neighbors);
+        if (rc) return rc;
+        return ids_from(neighbors, out);
+    }
+    int ids_from(const std::vector<std::pair<std::string, float>>& neighbors, std::vector<NodeId>& out) {
+        out.reserve(neighbors.size());
+        for (auto& kv : neighbors) {
+            NodeId id;
+            std::string why;
+            if (!parse_uuid(normalize_surreal_node_id(kv.first), id, why))
+                return fail(CGV_ERR_INVALID_ARG, "Invalid node id '" + kv.first + "' returned by Surreal search: " + why);
+            out.push_back(id);
+        }
+        return CGV_OK;
+    }
+    // search.rs:207-217 calculate_similarity_score
+    int similarity_score(const float* q, size_t dim, const NodeId& id, float& score) {
+        std::vector<float> e;
+        bool found = false;
+        int rc = backend->get_node_embedding(id, e, found);
+        if (rc) return rc;
+        score = found ? cosine_similarity(q, dim, e.data(), e.size()) : 0.0f;
+        return CGV_OK;
+    }
+    int rescore(const float* q, size_t dim, const std::vector<NodeId>& ids, size_t limit, std::vector<SearchResult>& out) {
+        out.clear();
+        for (auto& id : ids) {
+            float s;
+            int rc = similarity_score(q, dim, id, s);
+            if (rc) return rc;
+            out.push_back({id, s});
+        }
+        stable_sort_desc(out);
+        if (out.size() > limit) out.resize(limit);
+        normalize_scores(out);
+        return CGV_OK;
+    }
+    // SemanticSearch::search_by_embedding, search.rs:91-144 (QueryHash cache not reproduced)
+    int search_by_embedding(const float* q, size_t dim, size_t limit, std::vector<SearchResult>& out) {
+        std::vector<NodeId> ids;
+        int rc = search_similar(q, dim, (size_t)prefetch_k(limit), ids);
+        if (rc) return rc;
+        return rescore(q, dim, ids, limit, out);
+    }
+    // the same for nq queries with ONE batched kNN on the GPU
+    int search_by_embedding_batch(const float* qs, size_t nq, size_t dim, size_t limit,
+                                  std::vector<std::vector<SearchResult>>& out) {
+        out.assign(nq, {});
+        if (dim == 0 || limit == 0) return CGV_OK;
+        std::vector<std::vector<std::pair<std::string, float>>> nb;
+        int rc = backend->vector_knn_batch(column_for_dimension(dim), qs, nq, dim, (size_t)prefetch_k(limit), ef_search, nb);
+        if (rc) return rc;
+        for (size_t i = 0; i < nq; ++i) {
+            std::vector<NodeId> ids;
+            if ((rc = ids_from(nb[i], ids))) return rc;
+            if ((rc = rescore(qs + i * dim, dim, ids, limit, out[i]))) return rc;
+        }
+        return CGV_OK;
+    }
+    // search.rs:420-463 node_matches_filters
+    bool node_matches(const NodeId& id, const Filters& f) {
+        auto it = node_metadata.find(id);
+        if (it == node_metadata.end()) return false;
+        const NodeMeta& n = it->second;
+        if (f.has_languages && !(n.has_language && contains(f.languages, n.language))) return false;
+        if (f.has_node_types && !(n.has_node_type && contains(f.node_types, n.node_type))) return false;
+        for (auto& kv : f.attrs) {
+            auto a = n.attributes.find(kv.first);
+            if (a == n.attributes.end() || a->second != kv.second) return false;
+        }
+        if (!f.path_prefixes.empty()) {
+            bool any = false;
+            for (auto& p : f.path_prefixes) any = any || starts_with(n.file_path, p);
+            if (!any) return false;
+        }
+        return true;
+    }
+    // search.rs:465-516 metadata_match_score
+    float metadata_score(const NodeId& id, const Filters& f) {
+        auto it = node_metadata.find(id);
+        if (it == node_metadata.end()) return 0.0f;
+        const NodeMeta& n = it->second;
+        float score = 0.0f, denom = 0.0f;
+        if (f.has_languages) {
+            denom += 1.0f;
+            if (n.has_language && contains(f.languages, n.language)) score += 1.0f;
+        }
+        if (f.has_node_types) {
+            denom += 1.0f;
+            if (n.has_node_type && contains(f.node_types, n.node_type)) score += 1.0f;
+        }
+        if (!f.attrs.empty()) {
+            denom += 1.0f;
+            bool all = true;
+            for (auto& kv : f.attrs) {
+                auto a = n.attributes.find(kv.first);
+                all = all && a != n.attributes.end() && a->second == kv.second;
+            }
+            if (all) score += 1.0f;
+        }
+        if (!f.path_prefixes.empty()) {
+            denom += 1.0f;
+            bool any = false;
+            for (auto& p : f.path_prefixes) any = any || starts_with(n.file_path, p);
+            if (any) score += 1.0f;
+        }
+        return denom == 0.0f ? 0.0f : score / denom;
+    }
+    void apply_filters(std::vector<SearchResult>& base, const cgvs_filters* filters, size_t limit) {  // search.rs:298-308
+        if (filters) {
+            const Filters f = make_filters(filters);
+            std::vector<SearchResult> kept;
+            for (auto& r : base)
+                if (node_matches(r.node_id, f)) kept.push_back(r);
+            base.swap(kept);
+        }
+        if (base.size() > limit) base.resize(limit);
+        normalize_scores(base);
+    }
+};
+
+namespace {
+int emit(const std::vector<SearchResult>& r, uint8_t* out_ids16, float* out_scores, uint32_t* out_n) {
+    for (size_t i = 0; i < r.size(); ++i) {
+        memcpy(out_ids16 + 16 * i, r[i].node_id.data(), 16);
+        if (out_scores) out_scores[i] = r[i].score;
+    }
+    *out_n = (uint32_t)r.size();
+    return CGV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cgvs_store_create(int dtype, int device_id, uint32_t ef_search, cgvs_store** out) {
+    if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (cgv_device_count() == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16) return fail(CGV_ERR_INVALID_ARG, "bad dtype");
+    cgvs_store* s = new cgvs_store();
+    s->backend.reset(new HipKnnBackend(dtype, device_id));
+    s->ef_search = ef_search;
+    *out = s;
+    return CGV_OK;
+}
+
+int cgvs_store_create_mock(const char* const* ids, const float* distances, uint32_t n, uint32_t ef_search,
+                           cgvs_store** out) {
+    if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
+    std::vector<std::pair<std::string, float>> r;
+    for (uint32_t i = 0; i < n; ++i) r.push_back({ids[i], distances[i]});
+    cgvs_store* s = new cgvs_store();
+    s->mock = new MockBackend(std::move(r));
+    s->backend.reset(s->mock);
+    s->ef_search = ef_search;
+    *out = s;
+    return CGV_OK;
+}
+
+int cgvs_mock_recorded_columns(cgvs_store* s, char* buf, size_t buf_len) {
+    if (!s || !s->mock || !buf || !buf_len) return fail(CGV_ERR_INVALID_ARG, "not a mock store");
+    std::string j;
+    for (auto& c : s->mock->columns) j += (j.empty() ? "" : "\n") + c;
+    snprintf(buf, buf_len, "%s", j.c_str());
+    return CGV_OK;
+}
+
+int cgvs_store_destroy(cgvs_store* s) {
+    delete s;
+    return CGV_OK;
+}
+
+int cgvs_upsert_nodes(cgvs_store* s, uint32_t n, const uint8_t* ids16, const float* embeddings, uint32_t dim) {
+    if (!s) return fail(CGV_ERR_INVALID_ARG, "store is NULL");
+    if (n == 0) return CGV_OK;  // surreal_store.rs:92-94
+    if (!ids16) return fail(CGV_ERR_INVALID_ARG, "ids is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<Node> nodes(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(nodes[i].id.data(), ids16 + 16 * i, 16);
+        nodes[i].embedding = embeddings ? embeddings + (size_t)i * dim : nullptr;
+        nodes[i].dim = dim;
+    }
+    return s->backend->upsert_nodes(nodes);
+}
+
+int cgvs_upsert_node_metadata(cgvs_store* s, const uint8_t* id16, const char* language, const char* node_type,
+                              const char* file_path, const char* const* attr_keys, const char* const* attr_values,
+                              uint32_t n_attrs) {
+    if (!s || !id16) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    NodeId id;
+    memcpy(id.data(), id16, 16);
+    NodeMeta m;
+    if (language) {
+        m.language = language;
+        m.has_language = true;
+    }
+    if (node_type) {
+        m.node_type = node_type;
+        m.has_node_type = true;
+    }
+    if (file_path) m.file_path = file_path;
+    for (uint32_t i = 0; i < n_attrs; ++i) m.attributes[attr_keys[i]] = attr_values[i];
+    s->node_metadata[id] = std::move(m);
+    return CGV_OK;
+}
+
+int cgvs_vector_knn(cgvs_store* s, const char* column, const float* query, uint32_t dim, uint32_t limit,
+                    uint32_t ef_search, char* out_ids, float* out_dist, uint32_t* out_n) {
+    if (!s || !column || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<std::pair<std::string, float>> nb;
+    int rc = s->backend->vector_knn(column, std::vector<float>(query, query + dim), limit, ef_search, nb);
+    if (rc) return rc;
+    for (size_t i = 0; i < nb.size(); ++i) {
+        snprintf(out_ids + 48 * i, 48, "%s", nb[i].first.c_str());
+        out_dist[i] = nb[i].second;
+    }
+    *out_n = (uint32_t)nb.size();
+    return CGV_OK;
+}
+
+int cgvs_search_similar(cgvs_store* s, const float* query, uint32_t dim, uint32_t limit, uint8_t* out_ids16,
+                        uint32_t* out_n) {
+    if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<NodeId> ids;
+    int rc = s->search_similar(query, dim, limit, ids);
+    if (rc) return rc;
+    for (size_t i = 0; i < ids.size(); ++i) memcpy(out_ids16 + 16 * i, ids[i].data(), 16);
+    *out_n = (uint32_t)ids.size();
+    return CGV_OK;
+}
+
+int cgvs_get_embedding(cgvs_store* s, const uint8_t* id16, float* out, uint32_t cap, uint32_t* out_dim) {
+    if (!s || !id16 || !out_dim) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    NodeId id;
+    memcpy(id.data(), id16, 16);
+    std::vector<float> e;
+    bool found = false;
+    int rc = s->backend->get_node_embedding(id, e, found);
+    if (rc) return rc;
+    *out_dim = 0;
+    if (!found) return CGV_OK;  // Ok(None)
+    if (e.size() > cap) return fail(CGV_ERR_INVALID_ARG, "output buffer too small");
+    memcpy(out, e.data(), e.size() * 4);
+    *out_dim = (uint32_t)e.size();
+    return CGV_OK;
+}
+
+int cgvs_search_by_embedding(cgvs_store* s, const float* query, uint32_t dim, uint32_t limit, uint8_t* out_ids16,
+                             float* out_scores, uint32_t* out_n) {
+    if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<SearchResult> r;
+    int rc = s->search_by_embedding(query, dim, limit, r);
+    if (rc) return rc;
+    return emit(r, out_ids16, out_scores, out_n);
+}
+
+int cgvs_search_by_text(cgvs_store* s, const char* text, uint32_t limit, uint8_t* out_ids16, float* out_scores,
+                        uint32_t* out_n) {
+    if (!s || !text || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::vector<float> q(384);  // encode_query: dimension = 384 (search.rs:182)
+    hash_embed(text, 384, q.data());
+    return cgvs_search_by_embedding(s, q.data(), 384, limit, out_ids16, out_scores, out_n);
+}
+
+int cgvs_semantic_search(cgvs_store* s, const float* query, uint32_t dim, const cgvs_filters* filters,
+                         uint32_t limit, uint8_t* out_ids16, float* out_scores, uint32_t* out_n) {
+    if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);  // search.rs:293
+    std::vector<SearchResult> base;
+    int rc = s->search_by_embedding(query, dim, pk, base);
+    if (rc) return rc;
+    s->apply_filters(base, filters, limit);
+    return emit(base, out_ids16, out_scores, out_n);
+}
+
+int cgvs_hybrid_search(cgvs_store* s, const float* query, uint32_t dim, const cgvs_filters* filters,
+                       float vector_weight, uint32_t limit, uint8_t* out_ids16, float* out_scores, uint32_t* out_n) {
+    if (!s || !out_n || !filters) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    const float vw = vector_weight < 0.0f ? 0.0f : (vector_weight > 1.0f ? 1.0f : vector_weight);  // clamp(0,1)
+    const float mw = 1.0f - vw;
+    const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);
+    std::vector<SearchResult> cand;
+    int rc = s->search_by_embedding(query, dim, pk, cand);
+    if (rc) return rc;
+    const Filters f = make_filters(filters);
+    for (auto& r : cand) r.score = vw * r.score + mw * s->metadata_score(r.node_id, f);
+    stable_sort_desc(cand);
+    if (cand.size() > limit) cand.resize(limit);
+    normalize_scores(cand);
+    return emit(cand, out_ids16, out_scores, out_n);
+}
+
+int cgvs_multi_vector_search(cgvs_store* s, const float* queries, uint32_t nq, uint32_t dim, int mode,
+                             const cgvs_filters* filters, uint32_t limit, uint8_t* out_ids16, float* out_scores,
+                             uint32_t* out_n) {
+    if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    *out_n = 0;
+    if (nq == 0) return CGV_OK;  // search.rs:354-356
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);
+    std::vector<std::vector<SearchResult>> lists;
+    int rc = s->search_by_embedding_batch(queries, nq, dim, pk, lists);  // one GPU batch for all queries
+    if (rc) return rc;
+    for (auto& l : lists) s->apply_filters(l, filters, limit);  // = semantic_search per query
+    std::map<NodeId, std::pair<float, size_t>> agg;             // ordered by id: deterministic tie order
+    if (mode == CGVS_COMBINE_OR_MAX) {
+        for (auto& l : lists)
+            for (auto& r : l) {
+                auto it = agg.find(r.node_id);
+                if (it == agg.end())
+                    agg[r.node_id] = {r.score, 1};
+                else if (r.score > it->second.first)
+                    it->second.first = r.score;
+            }
+    } else {
+        for (auto& l : lists)
+            for (auto& r : l) {
+                auto it = agg.find(r.node_id);
+                if (it == agg.end())
+                    agg[r.node_id] = {r.score, 1};
+                else {
+                    it->second.first += r.score;
+                    it->second.second += 1;
+                }
+            }
+        for (auto it = agg.begin(); it != agg.end();) it = (it->second.second == nq) ? std::next(it) : agg.erase(it);
+        for (auto& kv : agg) kv.second.first /= (float)nq;
+    }
+    std::vector<SearchResult> combined;
+    for (auto& kv : agg) combined.push_back({kv.first, kv.second.first});
+    stable_sort_desc(combined);
+    if (combined.size() > limit) combined.resize(limit);
+    normalize_scores(combined);
+    return emit(combined, out_ids16, out_scores, out_n);
+}
+
+int cgvs_combine_embeddings(const float* embeddings, uint32_t n, uint32_t dim, float* out) {
+    if (n == 0) return fail(CGV_ERR_INVALID_ARG, "No embeddings to combine");  // search.rs:233-237
+    for (uint32_t i = 0; i < dim; ++i) out[i] = 0.0f;
+    for (uint32_t e = 0; e < n; ++e)
+        for (uint32_t i = 0; i < dim; ++i) out[i] += embeddings[(size_t)e * dim + i];
+    const float count = (float)n;
+    for (uint32_t i = 0; i < dim; ++i) out[i] /= count;
+    float nsq = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) nsq += out[i] * out[i];
+    const float norm = sqrtf(nsq);
+    if (norm > 0.0f)
+        for (uint32_t i = 0; i < dim; ++i) out[i] /= norm;
+    return CGV_OK;
+}
+
+const char* cgvs_embedding_column_for_dimension(uint32_t dim) { return column_for_dimension(dim); }
+
+int cgvs_normalize_node_id(const char* raw, char* out, size_t out_len) {
+    if (!raw || !out || !out_len) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    snprintf(out, out_len, "%s", normalize_surreal_node_id(raw).c_str());
+    return CGV_OK;
+}
+
+int cgvs_parse_node_id(const char* text, uint8_t* out_id16) {
+    if (!text || !out_id16) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    NodeId id;
+    std::string why;
+    if (!parse_uuid(text, id, why)) return fail(CGV_ERR_INVALID_ARG, "invalid UUID '" + std::string(text) + "': " + why);
+    memcpy(out_id16, id.data(), 16);
+    return CGV_OK;
+}
+
+int cgvs_format_node_id(const uint8_t* id16, char* out37) {
+    if (!id16 || !out37) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    NodeId id;
+    memcpy(id.data(), id16, 16);
+    snprintf(out37, 37, "%s", format_uuid(id).c_str());
+    return CGV_OK;
+}
+
+uint32_t cgvs_simple_hash(const char* text) { return simple_hash(text ? text : ""); }
+
+int cgvs_hash_embed(const char* text, uint32_t dim, float* out) {
+    if (!text || !out) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    hash_embed(text, dim, out);
+    return CGV_OK;
+}
+
+uint64_t cgvs_prefetch_k(uint64_t limit) { return prefetch_k(limit); }
+
+void cgvs_normalize_scores(float* scores, uint32_t n) {
+    std::vector<SearchResult> r(n);
+    for (uint32_t i = 0; i < n; ++i) r[i].score = scores[i];
+    normalize_scores(r);
+    for (uint32_t i = 0; i < n; ++i) scores[i] = r[i].score;
+}
+
+float cgvs_cosine_similarity(const float* a, const float* b, uint32_t n) { return cosine_similarity(a, n, b, n); }
+
+}  // extern "C"

@@ -95,6 +95,10 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n);
 /* Same, rows already in DEVICE memory of this index's device. */
 int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n);
 
+/* Overwrite stored row `id` (local id) with a new f32 row (HOST pointer): the in-place half of
+ * UPSERT (SurrealVectorBackend::upsert_nodes on a known node id, surreal_store.rs:13). */
+int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host);
+
 /* Number of rows stored / dimension / dtype / metric. */
 uint64_t cgv_count(const cgv_index* h);
 uint32_t cgv_dim(const cgv_index* h);

@@ -10,9 +10,9 @@ from _util import ROOT, pkg
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cgvec.h")).read()
+    text = open(os.path.join(ROOT, "include", "cgvec.h")).read() + open(os.path.join(ROOT, "include", "cgvec_store.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cgv_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(cgvs?_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     m.build_library()
     L = ctypes.CDLL(m.cgvec.LIB_PATH)
     syms = _declared_symbols()
-    assert len(syms) >= 20
+    assert len(syms) >= 45
     for s in syms:
         assert hasattr(L, s), f"{s} declared in cgvec.h but not exported"
 

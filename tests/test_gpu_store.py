@@ -1,0 +1,161 @@
+"""The host-side mirror over the real HIP backend: parity of the SemanticSearch pipeline with
+the oracle restatement of the reference's caller-side arithmetic (search.rs:91-144, 271-418)."""
+import uuid
+
+import numpy as np
+import pytest
+
+from _util import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d, seed, dtype="f32"):
+    m = pkg()
+    rng = np.random.default_rng(seed)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    ids = [uuid.UUID(int=int(rng.integers(1, 2**62)) * 4 + i) for i in range(n)]
+    st = m.store.VectorStore(dtype=dtype)
+    st.store_embeddings(ids, rows)
+    return st, ids, rows, rng
+
+
+def _expected_search_by_embedding(oracle, q, rows_stored, ids, limit, odt):
+    """search.rs:91-144 on the oracle: prefetch by O2 top-k, re-score with the search.rs formula
+    against get_embedding (= the stored rows), stable sort desc, truncate, min-max."""
+    pk = oracle.prefetch_k(limit)
+    idx, _ = oracle.batch_top_k(q[None, :], rows_stored, min(pk, 256), dtype=odt)
+    cand = [int(i) for i in idx[0] if i != np.uint64(2**64 - 1)]
+    scored = [(c, oracle.search_cosine(q, rows_stored[c])) for c in cand]
+    scored = sorted(scored, key=lambda t: -t[1])[:limit]          # python's sort is stable
+    sc = oracle.normalize_scores([s for _, s in scored]) if scored else []
+    return [(ids[c], float(s)) for (c, _), s in zip(scored, sc)]
+
+
+def test_index_and_search_memory():
+    # crates/codegraph-core/src/integration/graph_vector.rs:540-596 with HasherEmbeddingService(384)
+    m = pkg()
+    texts = ["Rust Function sum fn sum(a: i32, b: i32) -> i32 { a + b }",
+             "Rust Function add fn add(x: i32, y: i32) -> i32 { x + y }",
+             "Rust Function read_file fn read_file(p: &str) -> String { std::fs::read_to_string(p).unwrap() }"]
+    ids = [uuid.uuid4() for _ in texts]
+    st = m.store.VectorStore(dtype="f32")
+    st.store_embeddings(ids, np.stack([m.store.hash_embed(t, 384) for t in texts]))
+    res = st.search_by_text("sum two numbers", 2)
+    assert len(res) == 2 and all(r[0] in ids for r in res)
+    st.store_embeddings(ids, np.stack([m.store.hash_embed(t, 384) for t in texts]))   # re-index: UPSERT, no growth
+    assert len(st.search_similar(m.store.hash_embed("x", 384), 10)) == 3
+    st.close()
+
+
+@pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1)])
+def test_search_similar_and_vector_knn_parity(oracle, dtype, odt):
+    st, ids, rows, rng = _mk(3000, 384, 5, dtype)
+    stored = oracle.round_trip(rows, odt)
+    q = rng.standard_normal(384).astype(np.float32)
+    ref_i, ref_s = oracle.batch_top_k(q[None, :], rows, 12, dtype=odt)
+    assert st.search_similar(q, 12) == [ids[int(i)] for i in ref_i[0]]
+    knn = st.vector_knn("embedding_384", q, 12)
+    assert [k[0] for k in knn] == ["nodes:" + str(ids[int(i)]) for i in ref_i[0]]
+    assert np.array_equal(np.array([k[1] for k in knn], np.float32), (np.float32(1.0) - ref_s[0]).astype(np.float32))
+    assert np.array_equal(st.get_embedding(ids[77]), stored[77])
+    assert st.get_embedding(uuid.uuid4()) is None
+    assert st.vector_knn("embedding_768", np.zeros(768, np.float32), 5) == []     # empty column
+    st.close()
+
+
+@pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1)])
+def test_search_by_embedding_parity(oracle, dtype, odt):
+    st, ids, rows, rng = _mk(4000, 256, 6, dtype)
+    stored = oracle.round_trip(rows, odt)
+    for limit in (1, 10, 25):
+        q = rng.standard_normal(256).astype(np.float32)
+        got = st.search_by_embedding(q, limit)
+        exp = _expected_search_by_embedding(oracle, q, stored, ids, limit, 0)
+        assert [g[0] for g in got] == [e[0] for e in exp]
+        assert np.array_equal(np.array([g[1] for g in got], np.float32), np.array([e[1] for e in exp], np.float32))
+    st.close()
+
+
+def test_upsert_updates_in_place(oracle):
+    st, ids, rows, rng = _mk(500, 128, 7, "bf16")
+    q = rng.standard_normal(128).astype(np.float32)
+    st.store_embeddings([ids[123]], (q / np.linalg.norm(q))[None, :])     # make row 123 the best match
+    assert st.search_similar(q, 1) == [ids[123]]
+    assert np.array_equal(st.get_embedding(ids[123]), oracle.round_trip(q / np.linalg.norm(q), 1))
+    st.close()
+
+
+def test_semantic_hybrid_and_multi_vector(oracle):
+    st, ids, rows, rng = _mk(2000, 128, 9, "f32")
+    for i, nid in enumerate(ids):
+        st.upsert_node_metadata(nid, language="Rust" if i % 2 == 0 else "Python",
+                                node_type="Function" if i % 3 == 0 else "Struct",
+                                file_path=f"src/mod{i % 5}/f{i}.rs", attributes={"visibility": "pub" if i % 4 == 0 else "priv"})
+    idx_of = {nid: i for i, nid in enumerate(ids)}
+    q = rng.standard_normal(128).astype(np.float32)
+    limit = 8
+    pk = max(4 * limit, limit + 25)                                  # search.rs:293
+    base = _expected_search_by_embedding(oracle, q, rows, ids, pk, 0)
+
+    # semantic_search without filters: truncate + second min-max (search.rs:271-313)
+    got = st.semantic_search(q, None, limit)
+    exp = base[:limit]
+    exp_s = oracle.normalize_scores([s for _, s in exp])
+    assert [g[0] for g in got] == [e[0] for e in exp]
+    assert np.array_equal(np.array([g[1] for g in got], np.float32), exp_s)
+
+    # with filters
+    f = {"languages": ["Rust"], "node_types": None, "attribute_equals": {}, "path_prefixes": ["src/mod0", "src/mod2"]}
+    got = st.semantic_search(q, f, limit)
+    keep = [(n, s) for n, s in base if idx_of[n] % 2 == 0 and idx_of[n] % 5 in (0, 2)][:limit]
+    assert [g[0] for g in got] == [k[0] for k in keep]
+    if keep:
+        assert np.array_equal(np.array([g[1] for g in got], np.float32), oracle.normalize_scores([s for _, s in keep]))
+
+    # hybrid_search (search.rs:317-344)
+    f2 = {"languages": ["Rust"], "node_types": ["Function"], "attribute_equals": {"visibility": "pub"}, "path_prefixes": []}
+    vw = np.float32(0.7)
+    mw = np.float32(1.0) - vw
+
+    def meta(i):
+        sc = np.float32(0)
+        sc += np.float32(1) if i % 2 == 0 else np.float32(0)
+        sc += np.float32(1) if i % 3 == 0 else np.float32(0)
+        sc += np.float32(1) if i % 4 == 0 else np.float32(0)
+        return np.float32(sc / np.float32(3))
+    hyb = [(n, np.float32(np.float32(vw * np.float32(s)) + np.float32(mw * meta(idx_of[n])))) for n, s in base]
+    hyb = sorted(hyb, key=lambda t: -t[1])[:limit]
+    got = st.hybrid_search(q, f2, 0.7, limit)
+    assert [g[0] for g in got] == [h[0] for h in hyb]
+    assert np.allclose(np.array([g[1] for g in got]), oracle.normalize_scores([s for _, s in hyb]), atol=1e-6)
+
+    # multi_vector_search OR-max / AND-average (search.rs:347-418), one GPU batch
+    qs = rng.standard_normal((3, 128)).astype(np.float32)
+    qs[1] = qs[0] + 0.05 * rng.standard_normal(128).astype(np.float32)      # overlapping neighbourhoods
+    qs[2] = qs[0] + 0.05 * rng.standard_normal(128).astype(np.float32)
+    lists = []
+    for qq in qs:
+        b = _expected_search_by_embedding(oracle, qq, rows, ids, pk, 0)[:limit]
+        sc = oracle.normalize_scores([s for _, s in b])
+        lists.append(list(zip([n for n, _ in b], sc)))
+    agg = {}
+    for l in lists:
+        for n, s in l:
+            agg[n] = max(agg.get(n, np.float32(-1)), np.float32(s))
+    exp = sorted(sorted(agg.items(), key=lambda t: t[0].bytes), key=lambda t: -t[1])[:limit]
+    got = st.multi_vector_search(qs, m_or := pkg().store.OR_MAX, None, limit)
+    assert [g[0] for g in got] == [e[0] for e in exp]
+    assert np.array_equal(np.array([g[1] for g in got], np.float32), oracle.normalize_scores([s for _, s in exp]))
+    cnt, tot = {}, {}
+    for l in lists:
+        for n, s in l:
+            cnt[n] = cnt.get(n, 0) + 1
+            tot[n] = np.float32(tot.get(n, np.float32(0)) + np.float32(s))
+    avg = {n: np.float32(tot[n] / np.float32(3)) for n in tot if cnt[n] == 3}
+    exp = sorted(sorted(avg.items(), key=lambda t: t[0].bytes), key=lambda t: -t[1])[:limit]
+    got = st.multi_vector_search(qs, pkg().store.AND_AVERAGE, None, limit)
+    assert [g[0] for g in got] == [e[0] for e in exp]
+    assert st.multi_vector_search(np.zeros((0, 128), np.float32), 0, None, 5) == []
+    st.close()
