@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (rows, dim, dtype, metric, batch, k)
     "c2": (1_000_000, 768, "bf16", "cosine", 1024, 10),
     "c4": (1_000_000, 1536, "fp16", "dot", 256, 10),
+    "c3shard": (1_250_000, 768, "bf16", "cosine", 4096, 10),   # one GPU's share of C3 (10M rows / 8)
     "small": (100_000, 768, "bf16", "cosine", 1024, 10),
 }
 CHUNK = 125_000
@@ -169,7 +170,7 @@ def main():
         rs = o.RowSet(rows_host)
         del rows_host
         cores = o.max_threads()
-        qh = qpool[0].to(tdt).float().cpu().numpy()
+        qh = qpool[0][:args.cpu_max_queries].to(tdt).float().cpu().numpy()
         gi, gs = ix.search(qpool[0], k)
         gi = gi.cpu().numpy().view(np.uint64)
         gs = gs.cpu().numpy()

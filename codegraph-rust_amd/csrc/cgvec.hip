@@ -348,30 +348,54 @@ __global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
     }
 }
 
-// Staged thresholds. The corpus tiles (BM rows each) are partitioned into
-//   boot   : tiles [0, T1)            dense scores by boot_kernel, tau = -inf  -> first tau
-//   sample : tiles T1 + j*stride      strided sample, ~one tile per workgroup  -> tight tau
-//   main   : every remaining tile     the dominant launch
+// Staged thresholds. Tiles [0, T1) are the boot tiles (dense scores by
+// boot_kernel, tau = -inf); the remaining R tiles are visited in the golden-ratio order of
+// stage_tile() in a few launches of geometrically growing size: a launch covering N rows with a
+// threshold learnt from C earlier rows emits about k' * N / C candidates per query, spread
+// over nsplit (workgroup, query) lists of CAND_CAPS entries — N is chosen so that the expected
+// list length stays at EMIT_TARGET and the per-query total at MERGE_TARGET. The last launch is
+// the dominant one.
+constexpr uint32_t BOOT_TILES = 4;    // 1024 rows
+constexpr uint32_t EMIT_TARGET = 24;  // expected entries per (workgroup, query) list per launch
+constexpr uint32_t MERGE_TARGET = 2048;  // expected candidates per query per launch (select holds 8192;
+                                         // the count fluctuates by ~1/sqrt(k') around its mean)
+
 struct StagePlan {
-    uint32_t ntiles, T1, stride, cnt2, cnt3;
+    uint32_t ntiles, T1, R, P;
+    std::vector<uint32_t> counts;  // tiles per launch, in visiting order
 };
 
-constexpr uint32_t BOOT_TILES = 4;  // 1024 rows: tau_1 passes ~k'/1024 of the sample stage
+uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) {
+        const uint32_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
 
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
     p.T1 = std::min<uint32_t>(std::max<uint32_t>((kprime + BM - 1) / BM, BOOT_TILES), p.ntiles);
-    const uint32_t R = p.ntiles - p.T1;
-    if (R > 4 * nsplit_max && R >= 64) {
-        p.stride = (R + nsplit_max - 1) / nsplit_max;
-        if (p.stride < 2) p.stride = 2;
-        p.cnt2 = (R + p.stride - 1) / p.stride;
-        p.cnt3 = R - p.cnt2;
-    } else {
-        p.stride = 0;
-        p.cnt2 = 0;
-        p.cnt3 = R;
+    p.R = p.ntiles - p.T1;
+    p.P = 1;
+    if (p.R > 2) {
+        p.P = (uint32_t)((double)p.R * 0.6180339887498949);
+        if (p.P < 1) p.P = 1;
+        while (gcd_u32(p.P, p.R) != 1) ++p.P;
+    }
+    uint64_t seen = (uint64_t)p.T1 * BM;  // rows behind the current threshold
+    uint32_t left = p.R;
+    while (left > 0) {
+        const uint32_t nsplit = std::min<uint32_t>(left, nsplit_max);
+        // rows this launch may cover: k' * N / seen / nsplit <= EMIT_TARGET
+        uint64_t rows = seen * std::min<uint64_t>((uint64_t)nsplit * EMIT_TARGET, MERGE_TARGET) / std::max<uint32_t>(kprime, 1);
+        uint32_t tiles = (uint32_t)std::min<uint64_t>(left, std::max<uint64_t>(rows / BM, nsplit));
+        if (tiles * 3 >= left * 2) tiles = left;  // do not leave a small tail for another launch
+        p.counts.push_back(tiles);
+        left -= tiles;
+        seen += (uint64_t)tiles * BM;
     }
     return p;
 }
@@ -463,17 +487,17 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         a.ld = h->ld;
         a.kc = h->ld / 64;
         a.T1 = p.T1;
-        a.stride = p.stride;
+        a.R = p.R;
+        a.P = p.P;
         a.nqt = nqt;
         a.metric = h->metric;
-        const uint32_t counts[3] = {0, p.cnt2, p.cnt3};
-        for (int st = 2; st <= 3; ++st) {
-            const uint32_t cnt = counts[st - 1];
-            if (cnt == 0) continue;
-            a.stage = (uint32_t)st;
+        uint32_t j0 = 0;
+        for (size_t st = 0; st < p.counts.size(); ++st) {
+            const uint32_t cnt = p.counts[st];
+            a.j0 = j0;
             a.cnt = cnt;
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
-            const bool dominant = (st == 3);
+            const bool dominant = (st + 1 == p.counts.size());
             if (h->profiling && dominant) HIPCHK(hipEventRecord(h->ev[1], s));
             if ((rc = launch_coarse(h->dtype, false, a, nqt * a.nsplit, s))) return rc;
             if (h->profiling && dominant) {
@@ -482,6 +506,7 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
                 h->last_coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
             if ((rc = launch_select(h, nq, nqt, a.nsplit, kprime, nullptr, 0, s))) return rc;
+            j0 += cnt;
         }
         RescoreArgs r;
         r.best = h->best.as<uint64_t>();
@@ -504,7 +529,9 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         r.kprime = kprime;
         r.k = k;
         r.metric = h->metric;
-        r.eps_scale = 8.0f * (float)h->D * 5.9604645e-8f + 1e-7f;
+        // |coarse - exact| <= (accumulation depth of both sums + norm terms) * u * |q||c|: the MFMA
+        // path adds D/16 partial sums, the reference D/8 per lane + a 3-level tree
+        r.eps_scale = ((float)h->D * 0.5f + 64.0f) * 5.9604645e-8f;
         r.max_norm_c = h->max_norm_c;
         h->st.last_eps = r.eps_scale;
         {
@@ -863,9 +890,10 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.nq = nq;
     a.ld = h->ld;
     a.kc = h->ld / 64;
-    a.stage = 1;
-    a.T1 = ntiles;
-    a.stride = 0;
+    a.T1 = 0;
+    a.R = ntiles;
+    a.P = 1;
+    a.j0 = 0;
     a.cnt = ntiles;
     a.nsplit = nsplit;
     a.nqt = nqt;

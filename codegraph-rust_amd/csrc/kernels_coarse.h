@@ -74,19 +74,15 @@ struct CoarseArgs {
     uint32_t* overflow;     // [nq]
     float* dump;            // DUMP mode: dense [nq][n] coarse scores
     uint32_t n, nq, ld, kc;
-    uint32_t stage, T1, stride, cnt, nsplit, nqt, metric;
+    uint32_t T1, R, P, j0, cnt, nsplit, nqt, metric;
 };
 
-// Stage partition of the corpus tiles (see api: staged thresholds).
-//   stage 1: tiles [0, T1)
-//   stage 2: tiles T1 + j*stride                       (strided sample)
-//   stage 3: every remaining tile (stride == 0: all tiles >= T1)
-__host__ __device__ inline uint32_t stage_tile(uint32_t stage, uint32_t T1, uint32_t stride,
-                                               uint32_t j) {
-    if (stage == 1) return j;
-    if (stage == 2) return T1 + j * stride;
-    if (stride == 0) return T1 + j;
-    return T1 + (j / (stride - 1)) * stride + (j % (stride - 1)) + 1;
+// Order in which the corpus tiles beyond the boot tiles are visited: tile j of
+// the sequence is T1 + (j * P) mod R with P ~ 0.618 R coprime to R (a golden-ratio stride), so
+// EVERY prefix of the sequence is spread evenly over the corpus: each threshold stage is a
+// representative sample of the rows still to come, whatever the insertion order of the corpus.
+__host__ __device__ inline uint32_t stage_tile(uint32_t T1, uint32_t R, uint32_t P, uint32_t j) {
+    return T1 + (uint32_t)(((uint64_t)j * P) % R);
 }
 
 // LDS counter increment (returns the old value). Inline asm on purpose: for a builtin LDS
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     uint32_t lj = 0, lkc = 0, issued = 0, ltile = 0;
     const char* acur = atile;
     auto set_tile = [&](uint32_t j) {
-        ltile = stage_tile(a.stage, a.T1, a.stride, jlo + j);
+        ltile = stage_tile(a.T1, a.R, a.P, a.j0 + jlo + j);
         acur = atile + (uint64_t)ltile * KC * BLOCK_BYTES;
     };
     if (total > 0) set_tile(0);
@@ -393,7 +389,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         acc[3][1] = Mfma<DT>::mma(fa1[3], fb1[1], acc[3][1]);
         __builtin_amdgcn_sched_barrier(0);
         if (ckc == KC - 1)
-            tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, stage_tile(a.stage, a.T1, a.stride, jlo + cj), wm,
+            tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, stage_tile(a.T1, a.R, a.P, a.j0 + jlo + cj), wm,
                                                           wn, lane, g, qt, tq, tauv, invq, cntq,
                                                           invn_s + (cj & 1u) * 256, stat_s + (cj & 1u) * 16);
         if (++ckc == KC) {

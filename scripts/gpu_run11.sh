@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -x 2>&1 | tail -5
+for W in c2 c4 c3shard; do
+echo "== $W"; timeout 900 python bench.py --workload $W --steps 10 --warmup 2 --cpu-seconds 6 --cpu-max-queries 8 2>&1 | grep -v amdgpu.ids | tail -1 | python -c "
+import sys,json
+r=json.loads(sys.stdin.read()); print('qps', r['value'], 'step_ms', r['ms_per_step'], 'roof', r['roofline'] and (r['roofline']['avg_launch_ms'], r['roofline']['achieved'], r['roofline']['rows_per_launch']), 'fb', r['pipeline']['fallback_queries'], 'eps', r['pipeline']['eps'], 'maxerr', r['pipeline']['max_observed_coarse_err'], 'cpu', r.get('cpu_baseline') and r['cpu_baseline']['value'], 'recall', r.get('recall_at_10'), r.get('ordered_match_rate'), r.get('score_bit_exact_rate'))"
+done
