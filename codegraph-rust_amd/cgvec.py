@@ -80,6 +80,9 @@ def lib():
     L.cgv_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_search_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_get_row_f32.argtypes = [vp, u64, vp]
+    L.cgv_batch_similarity_f32.argtypes = [vp, vp, i32, u64, vp]
+    L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
+    L.cgv_normalize_rows_f32.argtypes = [i32, vp, u64, u32]
     L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
     L.cgv_set_stream.argtypes = [vp, vp]
     L.cgv_use_own_stream.argtypes = [vp]
@@ -90,7 +93,7 @@ def lib():
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
     for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
-                 "cgv_merge_topk_dev", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
+                 "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
         getattr(L, name).restype = i32
     _lib = L
@@ -228,6 +231,29 @@ class HipKnnIndex:
                                         idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return idx, sc
 
+    OPS = {"cosine": 0, "dot": 1, "l2": 2, "cosine_seq": 3, "cosine_distance_seq": 4}
+
+    def batch_similarity(self, query, op="cosine", limit_rows=0):
+        """parallel_batch_similarity / compute_distances_cpu: op(query, row i) for the first rows."""
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        if q.size != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {q.size} != {self.dim}")
+        n = min(limit_rows, len(self)) if limit_rows else len(self)
+        out = np.empty(n, dtype=np.float32)
+        _check(lib().cgv_batch_similarity_f32(self._h, q.ctypes.data_as(C.c_void_p), self.OPS[op], int(limit_rows),
+                                              out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def search_baseline(self, query, limit):
+        """ModelOptimizer::search_baseline -> (row ids, distances)."""
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        idx = np.empty(max(limit, 1), dtype=np.uint64)
+        dist = np.empty(max(limit, 1), dtype=np.float32)
+        n = C.c_uint32(0)
+        _check(lib().cgv_search_baseline_f32(self._h, q.ctypes.data_as(C.c_void_p), int(limit), idx.ctypes.data_as(C.c_void_p),
+                                             dist.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return idx[:n.value], dist[:n.value]
+
     def debug_coarse_scores(self, queries):
         """Dense approximate (MFMA) scores [nq, n] as a CUDA tensor — test hook."""
         import torch
@@ -237,6 +263,15 @@ class HipKnnIndex:
         _check(lib().cgv_debug_coarse_scores_dev(self._h, C.c_void_p(q.data_ptr()), q.shape[0],
                                                  C.c_void_p(out.data_ptr())))
         return out
+
+
+def normalize_rows(rows, device=0):
+    """parallel_normalize_vectors on device; returns a normalised copy."""
+    r = np.array(rows, dtype=np.float32, copy=True, order="C")
+    if r.ndim == 1:
+        r = r[None, :]
+    _check(lib().cgv_normalize_rows_f32(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1]))
+    return r
 
 
 def merge_topk(idx, score, device=None):

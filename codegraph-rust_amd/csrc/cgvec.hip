@@ -285,16 +285,17 @@ int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
 }
 
 template <int DT>
-void launch_exact_scores(cgv_index* h, const uint32_t* qlist, uint32_t nql, float* scores, hipStream_t s) {
+void launch_exact_scores(cgv_index* h, const uint32_t* qlist, uint32_t nql, float* scores, int op, hipStream_t s) {
     uint64_t gx = ((uint64_t)h->n + 31) / 32;
     if (gx > 16384) gx = 16384;
     hipLaunchKernelGGL(exact_scores_kernel<DT>, dim3((unsigned)gx, nql), dim3(256), 0, s, h->rows,
-                       h->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, h->metric, scores);
+                       h->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, op, scores);
 }
 
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
 int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
-                 float* out_score, hipStream_t s) {
+                 float* out_score, hipStream_t s, int op = -1) {
+    if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : OP_COSINE;
     const uint64_t n = h->n;
     const uint32_t K = next_pow2(std::max<uint32_t>(k, 2));
     uint64_t qg = std::max<uint64_t>(1, (512ull << 20) / (n * 4));
@@ -310,9 +311,9 @@ int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t
         const uint32_t* ql = qlist_dev + q0;
         float* sc = h->scores.as<float>();
         switch (h->dtype) {
-            case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, ql, g, sc, s); break;
-            case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, ql, g, sc, s); break;
-            case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, ql, g, sc, s); break;
+            case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, ql, g, sc, op, s); break;
+            case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, ql, g, sc, op, s); break;
+            case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, ql, g, sc, op, s); break;
             default: return fail(CGV_ERR_INTERNAL, "exact path: unsupported dtype");
         }
         uint64_t* cur = h->keysA.as<uint64_t>();
@@ -791,6 +792,94 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_host, tmp, (size_t)h->D * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return CGV_OK;
+}
+
+// One query against the first `limit_rows` stored rows (0 = all): the reference's building blocks
+// evaluated on device with their exact f32 operation order.
+static int prep_single_query(cgv_index* h, const float* query_host, hipStream_t s) {
+    int rc;
+    if ((rc = h->qstage.ensure((size_t)h->D * 4))) return rc;
+    if ((rc = h->qrows.ensure(storage_bytes(h, 1)))) return rc;
+    if ((rc = h->qnorm.ensure(4))) return rc;
+    if ((rc = h->qinvn.ensure(4))) return rc;
+    if ((rc = h->qlist.ensure(4))) return rc;
+    HIPCHK(hipMemcpyAsync(h->qstage.p, query_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
+    HIPCHK(hipMemsetAsync(h->qlist.p, 0, 4, s));
+    return prep_dispatch(h->dtype, h->qstage.as<float>(), 1, h->D, h->ld, 0, h->qrows.as<char>(),
+                         h->qnorm.as<float>(), h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+}
+
+int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host) {
+    if (!h || !query_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    const uint64_t n = limit_rows ? std::min<uint64_t>(limit_rows, h->n) : h->n;
+    if (n == 0) return CGV_OK;
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = prep_single_query(h, query_host, s))) return rc;
+    if ((rc = h->scores.ensure((size_t)h->n * 4))) return rc;
+    switch (h->dtype) {
+        case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
+        case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
+        default: launch_exact_scores<DT_FP16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_host, h->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CGV_OK;
+}
+
+int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limit, uint64_t* out_idx_host,
+                            float* out_dist_host, uint32_t* out_n) {
+    if (!h || !query_host || !out_idx_host || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    *out_n = 0;
+    if (limit > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "limit exceeds CGV_MAX_K");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->n == 0 || limit == 0) return CGV_OK;  // optimization.rs:382-384
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = prep_single_query(h, query_host, s))) return rc;
+    if ((rc = h->outidx.ensure((size_t)limit * 8))) return rc;
+    if ((rc = h->outscore.ensure((size_t)limit * 4))) return rc;
+    // ascending distance, stable (ties keep index order) == descending (-distance, index asc)
+    if ((rc = exact_search(h, h->qlist.as<uint32_t>(), 1, limit, h->outidx.as<uint64_t>(), h->outscore.as<float>(), s,
+                           OP_NEG_COSINE_DISTANCE_SEQ)))
+        return rc;
+    std::vector<float> sc(limit);
+    HIPCHK(hipMemcpyAsync(out_idx_host, h->outidx.p, (size_t)limit * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sc.data(), h->outscore.p, (size_t)limit * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint32_t m = 0;
+    while (m < limit && out_idx_host[m] != UINT64_MAX) ++m;
+    for (uint32_t i = 0; i < m; ++i) {
+        out_idx_host[i] -= h->index_base;
+        if (out_dist_host) out_dist_host[i] = -sc[i];
+    }
+    *out_n = m;
+    return CGV_OK;
+}
+
+int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim) {
+    if (n == 0 || dim == 0) return CGV_OK;  // simd_ops.rs:190-192
+    if (!rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
+    if (cgv_device_count() == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+    HIPCHK(hipSetDevice(device_id));
+    float* d = nullptr;
+    const size_t bytes = (size_t)n * dim * 4;
+    HIPCHK(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemcpy(d, rows_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, 0, d, n, dim);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rows_host, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CGV_ERR_HIP, std::string("cgv_normalize_rows_f32: ") + hipGetErrorString(e));
     return CGV_OK;
 }
 

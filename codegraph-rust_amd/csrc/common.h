@@ -207,6 +207,62 @@ __device__ inline float exact_score_group8(int metric, const RQ& q, const RC& c,
     return metric == METRIC_DOT ? exact_dot_group8(q, c, D, l) : exact_cosine_group8(q, c, D, l);
 }
 
+// l2_distance_avx2, simd_ops.rs:105-143 (8 lanes: diff, fused square-accumulate; h-sum; scalar
+// tail with separate rounding; sqrt of the total)
+template <class RQ, class RC>
+__device__ inline float exact_l2_group8(const RQ& q, const RC& c, uint32_t D, int l) {
+    float acc = 0.0f;
+    const uint32_t chunks = D / 8;
+    for (uint32_t j = 0; j < chunks; ++j) {
+        const float d = q.at(8 * j + l) - c.at(8 * j + l);
+        acc = fmaf(d, d, acc);
+    }
+    acc = group8_hsum(acc);
+    float result = 0.0f;
+    if (l == 0) {
+        float r = 0.0f;
+        for (uint32_t i = chunks * 8; i < D; ++i) {
+            const float d = q.at(i) - c.at(i);
+            r = r + d * d;
+        }
+        result = (D == 0) ? 0.0f : sqrtf(acc + r);
+    }
+    return result;
+}
+
+// The reference's scalar formula (sequential f32 sums, no FMA): search.rs:519-533,
+// optimization.rs:404-418, gpu.rs:324-338. One lane walks the whole row.
+// distance = false: dot/(|a||b|), 0 on a zero norm; true: 1 - that, +inf on a zero norm.
+template <class RQ, class RC>
+__device__ inline float exact_cosine_seq(const RQ& q, const RC& c, uint32_t D, bool distance) {
+    float dot = 0.0f, na = 0.0f, nb = 0.0f;
+    for (uint32_t i = 0; i < D; ++i) {
+        const float x = q.at(i), y = c.at(i);
+        dot = dot + x * y;
+        na = na + x * x;
+        nb = nb + y * y;
+    }
+    const float norm_a = sqrtf(na), norm_b = sqrtf(nb);
+    if (norm_a == 0.0f || norm_b == 0.0f) return distance ? INFINITY : 0.0f;
+    const float cs = dot / (norm_a * norm_b);
+    return distance ? 1.0f - cs : cs;
+}
+
+constexpr int OP_COSINE = 0, OP_DOT = 1, OP_L2 = 2, OP_COSINE_SEQ = 3, OP_COSINE_DISTANCE_SEQ = 4,
+              OP_NEG_COSINE_DISTANCE_SEQ = 5;  // 5: -(distance), so that "larger is better" orders by distance asc
+
+template <class RQ, class RC>
+__device__ inline float exact_op_group8(int op, const RQ& q, const RC& c, uint32_t D, int l) {
+    switch (op) {
+        case OP_DOT: return exact_dot_group8(q, c, D, l);
+        case OP_L2: return exact_l2_group8(q, c, D, l);
+        case OP_COSINE_SEQ: return l == 0 ? exact_cosine_seq(q, c, D, false) : 0.0f;
+        case OP_COSINE_DISTANCE_SEQ: return l == 0 ? exact_cosine_seq(q, c, D, true) : 0.0f;
+        case OP_NEG_COSINE_DISTANCE_SEQ: return l == 0 ? -exact_cosine_seq(q, c, D, true) : 0.0f;
+        default: return exact_cosine_group8(q, c, D, l);
+    }
+}
+
 // A row staged in LDS as linear [ld] storage-dtype elements.
 template <int DT>
 struct LdsRow {

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
                                                            const char* __restrict__ qrows,
                                                            const uint32_t* __restrict__ qlist,
                                                            uint32_t nql, uint32_t n, uint32_t D,
-                                                           uint32_t ld, int metric,
+                                                           uint32_t ld, int op /* OP_* of common.h */,
                                                            float* __restrict__ scores) {
     const int tid = threadIdx.x;
     const int grp = tid >> 3, l = tid & 7;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
     const uint32_t q = qlist ? qlist[qi] : qi;
     const Row<DT> qr = make_row<DT>(qrows, q, ld);
     for (uint64_t row = (uint64_t)blockIdx.x * 32 + grp; row < n; row += (uint64_t)gridDim.x * 32) {
-        const float s = exact_score_group8(metric, qr, make_row<DT>(rows, row, ld), D, l);
+        const float s = exact_op_group8(op, qr, make_row<DT>(rows, row, ld), D, l);
         if (l == 0) scores[(uint64_t)qi * n + row] = s;
     }
 }
@@ -80,6 +80,26 @@ __global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, 
     }
     out_idx[(uint64_t)q * k + j] = oi;
     out_score[(uint64_t)q * k + j] = os;
+}
+
+// normalize_avx2 (simd_ops.rs:189-222) / parallel_normalize_vectors (:386-419), in place on a
+// flat f32 [n][dim] matrix: nsq = dot_product_avx2(v, v) (8 lane chains + h-sum + tail), zero
+// vectors untouched, every element MULTIPLIED by 1/sqrt(nsq). 8 lanes per row.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
+    const int l = threadIdx.x & 7;
+    const uint64_t row = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (row >= n) return;
+    float* v = rows + row * dim;
+    float acc = 0.0f;
+    const uint32_t chunks = dim / 8;
+    for (uint32_t j = 0; j < chunks; ++j) acc = fmaf(v[8 * j + l], v[8 * j + l], acc);
+    acc = group8_hsum(acc);
+    float r = 0.0f;
+    for (uint32_t i = chunks * 8; i < dim; ++i) r = r + v[i] * v[i];
+    const float nsq = __shfl(acc + r, 0, 8);  // lane 0 of the group holds the h-sum
+    if (nsq == 0.0f) return;
+    const float inv = 1.0f / sqrtf(nsq);
+    for (uint32_t i = l; i < dim; i += 8) v[i] = v[i] * inv;
 }
 
 // Compact the flagged query ids: qlist[0..count) (order irrelevant).

@@ -126,6 +126,30 @@ int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint
  * SurrealVectorBackend::get_node_embedding (surreal_store.rs:21). */
 int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host);
 
+/* ---- the reference's building blocks, with their exact f32 operation order, on device ----
+ * op for cgv_batch_similarity_f32: */
+#define CGV_OP_COSINE 0              /* SIMDVectorOps::adaptive_cosine_similarity, simd_ops.rs:281-295 */
+#define CGV_OP_DOT 1                 /* SIMDVectorOps::dot_product_avx2, simd_ops.rs:149-183 */
+#define CGV_OP_L2 2                  /* SIMDVectorOps::l2_distance_avx2, simd_ops.rs:105-143 */
+#define CGV_OP_COSINE_SEQ 3          /* cosine_similarity, search.rs:519-533 (sequential sums, no FMA) */
+#define CGV_OP_COSINE_DISTANCE_SEQ 4 /* cosine_distance, optimization.rs:404-418 / gpu.rs:324-338 */
+
+/* One query (HOST, f32[dim]) against the first limit_rows stored rows (0 = all), out_host[i] =
+ * op(query, row i). Replaces ParallelVectorOps::parallel_batch_similarity (simd_ops.rs:347-358),
+ * SIMDVectorOps::batch_cosine_similarity_avx2 (:85-99) and, with CGV_OP_COSINE_DISTANCE_SEQ and
+ * limit_rows = limit, GpuAcceleration::compute_distances / compute_distances_cpu
+ * (gpu.rs:248-322: distances of the FIRST `limit` rows, not a top-k). */
+int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host);
+
+/* ModelOptimizer::search_baseline (optimization.rs:376-402): ascending cosine_distance, stable
+ * (ties keep row order), take(limit). out_dist_host may be NULL. Row ids are local (no index_base). */
+int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limit, uint64_t* out_idx_host,
+                            float* out_dist_host, uint32_t* out_n);
+
+/* ParallelVectorOps::parallel_normalize_vectors / SIMDVectorOps::normalize_avx2
+ * (simd_ops.rs:386-419, 189-222), in place on a flat HOST matrix [n][dim], computed on device. */
+int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim);
+
 /* Merge G partial top-k lists per query on device `device_id` (the step after the
  * all-gather of per-shard partial results): inputs are
  * [g][nq][k] (idx u64, score f32) DEVICE arrays, outputs [nq][k], ordered

@@ -288,3 +288,57 @@ def test_full_size_properties_c2():
         assert st["fallback_queries"] == 0 and st["max_observed_err"] <= st["last_eps"]
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1)])
+@pytest.mark.parametrize("d", [24, 100, 384])
+def test_building_blocks_batch_similarity(oracle, dtype, odt, d):
+    """parallel_batch_similarity with each of the reference's kernels, and
+    compute_distances_cpu's 'first limit rows' semantics — bit-exact."""
+    m = pkg()
+    rng = np.random.default_rng(d)
+    rows = rng.standard_normal((300, d)).astype(np.float32)
+    rows[17] = 0.0
+    q = rng.standard_normal(d).astype(np.float32)
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        rs, qs = oracle.round_trip(rows, odt), oracle.round_trip(q, odt)
+        for op, fn in (("cosine", oracle.cosine_adaptive), ("dot", oracle.dot_avx2), ("l2", oracle.l2_avx2),
+                       ("cosine_seq", oracle.search_cosine), ("cosine_distance_seq", oracle.cosine_distance)):
+            got = ix.batch_similarity(q, op)
+            ref = np.array([fn(qs, r) for r in rs], np.float32)
+            assert np.array_equal(got, ref), op
+        first = ix.batch_similarity(q, "cosine_distance_seq", limit_rows=10)      # gpu.rs:297-322
+        assert first.shape == (10,) and np.array_equal(first, ix.batch_similarity(q, "cosine_distance_seq")[:10])
+    finally:
+        ix.close()
+
+
+def test_search_baseline_o1(oracle):
+    """optimization.rs:376-402: ascending cosine_distance, stable."""
+    m = pkg()
+    rng = np.random.default_rng(77)
+    rows = rng.standard_normal((5000, 128)).astype(np.float32)
+    rows[900] = rows[30]          # exact duplicate -> stable order keeps 30 before 900
+    rows[55] = 0.0                # zero norm -> +inf distance, sorts last
+    q = rows[30] + 0.01 * rng.standard_normal(128).astype(np.float32)
+    ix = m.HipKnnIndex(128, dtype="f32")
+    try:
+        ix.add(rows)
+        for limit in (1, 10, 40):
+            gi, gd = ix.search_baseline(q, limit)
+            ri, rd = oracle.search_baseline(q, rows, limit)
+            assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    finally:
+        ix.close()
+
+
+def test_normalize_rows_on_device(oracle):
+    """simd_ops.rs:189-222 / 386-419 (reciprocal multiply; zero rows untouched)."""
+    m = pkg()
+    rng = np.random.default_rng(3)
+    for d in (7, 64, 100, 768):
+        rows = (rng.standard_normal((50, d)) * 3).astype(np.float32)
+        rows[4] = 0.0
+        assert np.array_equal(m.cgvec.normalize_rows(rows), oracle.normalize_rows(rows)), d
