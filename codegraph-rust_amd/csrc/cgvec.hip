@@ -104,6 +104,8 @@ struct cgv_index {
     float* invn = nullptr;
     float* blk_min = nullptr;
     float* blk_max = nullptr;
+    int8_t* rexp = nullptr;       // fp8 only: per-row scale exponent
+    DevBuf qrexp;                 // fp8 only: per-query scale exponent
     uint32_t* flags = nullptr;    // device, F_COUNT words
     float* max_norm_dev = nullptr;
     uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
@@ -142,20 +144,21 @@ size_t device_bytes(const cgv_index* h) {
 
 template <int DT>
 void launch_prep(const float* in, uint64_t n, uint32_t D, uint32_t ld, uint64_t row0, char* out, float* norm,
-                 float* invn, uint32_t* nonfinite, hipStream_t s) {
+                 float* invn, int8_t* rexp, uint32_t* nonfinite, hipStream_t s) {
     if (n == 0) return;
     uint64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(prep_rows_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, s, in, n, D, ld, row0, out,
-                       norm, invn, nonfinite);
+                       norm, invn, rexp, nonfinite);
 }
 
 // Convert n f32 rows into the index' storage at absolute rows [row0, row0+n).
 int prep_dispatch(int dtype, const float* in, uint64_t n, uint32_t D, uint32_t ld, uint64_t row0, char* out,
-                  float* norm, float* invn, uint32_t* nonfinite, hipStream_t s) {
+                  float* norm, float* invn, int8_t* rexp, uint32_t* nonfinite, hipStream_t s) {
     switch (dtype) {
-        case CGV_DTYPE_F32: launch_prep<DT_F32>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
-        case CGV_DTYPE_BF16: launch_prep<DT_BF16>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
-        case CGV_DTYPE_FP16: launch_prep<DT_FP16>(in, n, D, ld, row0, out, norm, invn, nonfinite, s); break;
+        case CGV_DTYPE_F32: launch_prep<DT_F32>(in, n, D, ld, row0, out, norm, invn, rexp, nonfinite, s); break;
+        case CGV_DTYPE_BF16: launch_prep<DT_BF16>(in, n, D, ld, row0, out, norm, invn, rexp, nonfinite, s); break;
+        case CGV_DTYPE_FP16: launch_prep<DT_FP16>(in, n, D, ld, row0, out, norm, invn, rexp, nonfinite, s); break;
+        case CGV_DTYPE_FP8E4M3: launch_prep<DT_FP8>(in, n, D, ld, row0, out, norm, invn, rexp, nonfinite, s); break;
         default: return fail(CGV_ERR_INVALID_ARG, "dtype not supported by this build");
     }
     HIPCHK(hipGetLastError());
@@ -170,6 +173,7 @@ int grow(cgv_index* h, uint64_t need) {
     ncap = (ncap + 255) / 256 * 256;
     char* rows = nullptr;
     float *norm = nullptr, *invn = nullptr, *bmin = nullptr, *bmax = nullptr;
+    int8_t* rexp = nullptr;
     size_t rb = storage_bytes(h, ncap);
     size_t nblk = (size_t)ncap / 32 + 8;
     HIPCHK(hipMalloc((void**)&rows, rb));
@@ -178,10 +182,12 @@ int grow(cgv_index* h, uint64_t need) {
     HIPCHK(hipMalloc((void**)&invn, ncap * 4));
     HIPCHK(hipMalloc((void**)&bmin, nblk * 4));
     HIPCHK(hipMalloc((void**)&bmax, nblk * 4));
+    HIPCHK(hipMalloc((void**)&rexp, ncap));
     if (h->n) {
         HIPCHK(hipMemcpyAsync(rows, h->rows, storage_bytes(h, h->n), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(norm, h->norm, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(invn, h->invn, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(rexp, h->rexp, h->n, hipMemcpyDeviceToDevice, h->stream));
         size_t ob = (size_t)(h->n + 31) / 32;
         HIPCHK(hipMemcpyAsync(bmin, h->blk_min, ob * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(bmax, h->blk_max, ob * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -193,8 +199,10 @@ int grow(cgv_index* h, uint64_t need) {
         (void)hipFree(h->invn);
         (void)hipFree(h->blk_min);
         (void)hipFree(h->blk_max);
+        (void)hipFree(h->rexp);
     }
     h->rows = rows;
+    h->rexp = rexp;
     h->norm = norm;
     h->invn = invn;
     h->blk_min = bmin;
@@ -208,7 +216,7 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
     int rc = grow(h, h->n + cnt);
     if (rc) return rc;
     hipStream_t s = h->stream;
-    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->n, h->rows, h->norm, h->invn,
+    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->n, h->rows, h->norm, h->invn, h->rexp,
                        h->flags + F_NONFINITE_C, s);
     if (rc) return rc;
     const uint64_t n_new = h->n + cnt;
@@ -249,6 +257,8 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
         return dump ? launch_coarse_t<DT_BF16, true>(a, W, s) : launch_coarse_t<DT_BF16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP16)
         return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
+    if (dtype == CGV_DTYPE_FP8E4M3)
+        return dump ? launch_coarse_t<DT_FP8, true>(a, W, s) : launch_coarse_t<DT_FP8, false>(a, W, s);
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
@@ -314,6 +324,7 @@ int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t
             case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, ql, g, sc, op, s); break;
             case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, ql, g, sc, op, s); break;
             case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, ql, g, sc, op, s); break;
+            case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, ql, g, sc, op, s); break;
             default: return fail(CGV_ERR_INTERNAL, "exact path: unsupported dtype");
         }
         uint64_t* cur = h->keysA.as<uint64_t>();
@@ -431,16 +442,16 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
     if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;  // whole 256-query tiles (DMA reads them)
     if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->qrexp.ensure((size_t)nq + 16))) return rc;
     if ((rc = h->fbflag.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qlist.ensure((size_t)nq * 4))) return rc;
     HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
     rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
-                       h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+                       h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
 
     const uint32_t kprime = kprime_of(k);
-    const bool mfma = !h->force_exact && (h->dtype == CGV_DTYPE_BF16 || h->dtype == CGV_DTYPE_FP16) &&
-                      kprime <= CAND_CAPS;
+    const bool mfma = !h->force_exact && h->dtype != CGV_DTYPE_F32 && kprime <= CAND_CAPS;
     h->st.last_path = mfma ? 1u : 0u;
     h->st.last_kprime = mfma ? kprime : 0u;
     h->st.last_coarse_ms = 0.0f;
@@ -466,8 +477,10 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         // boot: dense scores of the first n_boot rows -> top-k' -> first tau
         if (h->dtype == CGV_DTYPE_BF16)
             launch_boot<DT_BF16>(h, n_boot, nq, h->dump.as<float>(), s);
-        else
+        else if (h->dtype == CGV_DTYPE_FP16)
             launch_boot<DT_FP16>(h, n_boot, nq, h->dump.as<float>(), s);
+        else
+            launch_boot<DT_FP8>(h, n_boot, nq, h->dump.as<float>(), s);
         HIPCHK(hipGetLastError());
         if ((rc = launch_select(h, nq, nqt, 0, kprime, h->dump.as<float>(), n_boot, s))) return rc;
 
@@ -486,7 +499,7 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         a.n = (uint32_t)h->n;
         a.nq = nq;
         a.ld = h->ld;
-        a.kc = h->ld / 64;
+        a.kc = h->ld / kchunk_of(h->dtype);
         a.T1 = p.T1;
         a.R = p.R;
         a.P = p.P;
@@ -536,7 +549,7 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         r.max_norm_c = h->max_norm_c;
         h->st.last_eps = r.eps_scale;
         {
-            const size_t rowb = (size_t)h->ld * 2, pitch = rowb + 16;
+            const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
             const size_t budget = 48 * 1024;  // LDS for staged rows
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
@@ -547,12 +560,16 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP8>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set = true;
             }
             if (h->dtype == CGV_DTYPE_BF16)
                 hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r);
-            else
+            else if (h->dtype == CGV_DTYPE_FP16)
                 hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r);
+            else
+                hipLaunchKernelGGL(rescore_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, r);
         }
         HIPCHK(hipGetLastError());
     }
@@ -614,8 +631,10 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     *out = nullptr;
     if (dim == 0 || dim > 8192) return fail(CGV_ERR_INVALID_ARG, "dim must be in 1..=8192");
     if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT) return fail(CGV_ERR_INVALID_ARG, "bad metric");
-    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16)
-        return fail(CGV_ERR_INVALID_ARG, "dtype not supported by this build (f32, bf16, fp16)");
+    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16 && dtype != CGV_DTYPE_FP8E4M3)
+        return fail(CGV_ERR_INVALID_ARG, "unknown dtype (f32, bf16, fp16, fp8e4m3)");
+    if (dtype == CGV_DTYPE_FP8E4M3 && metric != CGV_METRIC_COSINE)
+        return fail(CGV_ERR_INVALID_ARG, "fp8 storage keeps a per-row scale: cosine only in this build");
     int ndev = cgv_device_count();
     if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
     if (device_id < 0 || device_id >= ndev) return fail(CGV_ERR_INVALID_ARG, "device_id out of range");
@@ -623,7 +642,8 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     cgv_index* h = new cgv_index();
     h->device = device_id;
     h->D = dim;
-    h->ld = (dim + 63) / 64 * 64;
+    const uint32_t kch = kchunk_of(dtype);  // elements per 128-byte row chunk
+    h->ld = (dim + kch - 1) / kch * kch;
     h->metric = metric;
     h->dtype = dtype;
     h->esize = esize_of(dtype);
@@ -657,7 +677,9 @@ int cgv_destroy(cgv_index* h) {
         (void)hipFree(h->invn);
         (void)hipFree(h->blk_min);
         (void)hipFree(h->blk_max);
+        (void)hipFree(h->rexp);
     }
+    h->qrexp.release();
     DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best, &h->overflow,
                       &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores, &h->keysA, &h->keysB,
                       &h->outidx, &h->outscore, &h->addstage, &h->dump};
@@ -714,7 +736,7 @@ int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     if ((rc = h->addstage.ensure((size_t)h->D * 4))) return rc;
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->addstage.p, row_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
-    rc = prep_dispatch(h->dtype, h->addstage.as<float>(), 1, h->D, h->ld, id, h->rows, h->norm, h->invn,
+    rc = prep_dispatch(h->dtype, h->addstage.as<float>(), 1, h->D, h->ld, id, h->rows, h->norm, h->invn, h->rexp,
                        h->flags + F_NONFINITE_C, s);
     if (rc) return rc;
     const uint64_t b0 = id / 32;
@@ -784,11 +806,13 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
     hipStream_t s = h->stream;
     float* tmp = h->qstage.as<float>();
     if (h->dtype == CGV_DTYPE_F32)
-        hipLaunchKernelGGL(gather_row_kernel<DT_F32>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+        hipLaunchKernelGGL(gather_row_kernel<DT_F32>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, (const int8_t*)h->rexp, tmp);
     else if (h->dtype == CGV_DTYPE_BF16)
-        hipLaunchKernelGGL(gather_row_kernel<DT_BF16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+        hipLaunchKernelGGL(gather_row_kernel<DT_BF16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, (const int8_t*)h->rexp, tmp);
+    else if (h->dtype == CGV_DTYPE_FP16)
+        hipLaunchKernelGGL(gather_row_kernel<DT_FP16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, (const int8_t*)h->rexp, tmp);
     else
-        hipLaunchKernelGGL(gather_row_kernel<DT_FP16>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, tmp);
+        hipLaunchKernelGGL(gather_row_kernel<DT_FP8>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, (const int8_t*)h->rexp, tmp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_host, tmp, (size_t)h->D * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -803,17 +827,20 @@ static int prep_single_query(cgv_index* h, const float* query_host, hipStream_t 
     if ((rc = h->qrows.ensure(storage_bytes(h, 1)))) return rc;
     if ((rc = h->qnorm.ensure(4))) return rc;
     if ((rc = h->qinvn.ensure(4))) return rc;
+    if ((rc = h->qrexp.ensure(16))) return rc;
     if ((rc = h->qlist.ensure(4))) return rc;
     HIPCHK(hipMemcpyAsync(h->qstage.p, query_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
     HIPCHK(hipMemsetAsync(h->qlist.p, 0, 4, s));
     return prep_dispatch(h->dtype, h->qstage.as<float>(), 1, h->D, h->ld, 0, h->qrows.as<char>(),
-                         h->qnorm.as<float>(), h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+                         h->qnorm.as<float>(), h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
 }
 
 int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host) {
     if (!h || !query_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
+    if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
+        return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     const uint64_t n = limit_rows ? std::min<uint64_t>(limit_rows, h->n) : h->n;
@@ -825,6 +852,7 @@ int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint
     switch (h->dtype) {
         case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
         case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
+        case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
         default: launch_exact_scores<DT_FP16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
     }
     HIPCHK(hipGetLastError());
@@ -941,8 +969,7 @@ int cgv_set_force_exact(cgv_index* h, int enabled) {
 
 int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t nq, float* out_dev) {
     if (!h || !queries_dev || !out_dev) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    if (h->dtype != CGV_DTYPE_BF16 && h->dtype != CGV_DTYPE_FP16)
-        return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16 index");
+    if (h->dtype == CGV_DTYPE_F32) return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16/fp8 index");
     if (nq == 0 || h->n == 0) return CGV_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
@@ -951,10 +978,11 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;
     if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = h->qrexp.ensure((size_t)nq + 16))) return rc;
     if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
     if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
     rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
-                       h->qinvn.as<float>(), h->flags + F_NONFINITE_Q, s);
+                       h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
     const uint32_t nqt = (nq + BN - 1) / BN;
     const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
@@ -978,7 +1006,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.n = (uint32_t)h->n;
     a.nq = nq;
     a.ld = h->ld;
-    a.kc = h->ld / 64;
+    a.kc = h->ld / kchunk_of(h->dtype);
     a.T1 = 0;
     a.R = ntiles;
     a.P = 1;

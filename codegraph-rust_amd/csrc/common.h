@@ -53,26 +53,81 @@ __device__ inline float f16_to_f32(uint16_t b) {
     return (float)h;
 }
 
+// OCP FP8 E4M3FN (gfx950's fp8): bias 7, no inf, NaN = S.1111.111, max 448. RNE, finite inputs
+// beyond the range saturate to +-448.
+__device__ inline uint8_t f32_to_e4m3_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint8_t)(sign | 0x7fu);
+    const float af = __uint_as_float(a);
+    if (af >= 464.0f) return (uint8_t)(sign | 0x7eu);
+    if (af < 0.0009765625f) return sign;  // below half of the smallest subnormal 2^-9
+    int ex = (int)(a >> 23) - 127;
+    if (ex < -6) ex = -6;                                                 // subnormal quantum 2^-9
+    const float q = __uint_as_float((uint32_t)(ex - 3 + 127) << 23);      // quantum 2^(ex-3)
+    float v = rintf(af / q) * q;                                          // RNE; /q and *q are exact
+    if (v > 448.0f) v = 448.0f;
+    if (v == 0.0f) return sign;
+    const uint32_t vu = __float_as_uint(v);
+    const int e2 = (int)(vu >> 23) - 127;
+    if (e2 < -6) return (uint8_t)(sign | (uint8_t)(int)(v * 512.0f));     // k * 2^-9, k = 1..7
+    return (uint8_t)(sign | (uint8_t)((e2 + 7) << 3) | (uint8_t)((vu >> 20) & 7u));
+}
+__host__ __device__ inline float e4m3_to_f32(uint8_t b) {
+    const uint32_t sign = (uint32_t)(b & 0x80u) << 24;
+    const uint32_t ex = (b >> 3) & 0xfu, man = b & 7u;
+    uint32_t u;
+    if (ex == 0) {
+        float f = (float)man * 0.001953125f;  // man * 2^-9, exact
+        __builtin_memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (ex == 15 && man == 7) {
+        u = sign | 0x7fc00000u;
+    } else {
+        u = sign | ((ex + 120u) << 23) | (man << 20);
+    }
+    float r;
+    __builtin_memcpy(&r, &u, 4);
+    return r;
+}
+// Per-row power-of-two scale exponent of the fp8 storage: largest e with amax * 2^e <= 448
+// (integer logic; pure bit arithmetic, no libm).
+__host__ __device__ inline int fp8_row_exponent(float amax) {
+    uint32_t u;
+    __builtin_memcpy(&u, &amax, 4);
+    const int bexp = (int)((u >> 23) & 0xffu);
+    if (amax == 0.0f || bexp == 0 || bexp == 0xff) return 0;
+    const int x = bexp - 127;
+    int e = ((u & 0x7fffffu) <= 0x600000u) ? 8 - x : 7 - x;
+    if (e > 100) e = 100;
+    if (e < -100) e = -100;
+    return e;
+}
+
 // ---- storage layouts ---------------------------------------------------------------
 // f32 corpora: plain row-major [rows][ld] (exact path only; the reference's own layout).
 // bf16/fp16 corpora: BLOCKED layout "B64", the unit the coarse kernel streams:
-//   rows are grouped in tiles of 256; K in chunks of 64 elements; block (tile t, chunk kc)
-//   is 32 KiB contiguous at byte ((t*KC + kc) << 15), KC = ld/64. Inside a block, row r
+//   rows are grouped in tiles of 256; K in chunks of 64 elements (128 B); block (tile t,
+//   chunk kc) is 32 KiB contiguous at byte ((t*KC + kc) << 15), KC = ld/64. Inside a block, row r
 //   (0..255) owns 128 B at r*128 and its 16-byte slot p holds elements 8c..8c+7 of the
 //   chunk with c = p ^ ((r>>1)&7). That is byte-for-byte the LDS image the MFMA kernel
 //   wants (bank-conflict-free ds_read_b128), so the global->LDS DMA is a linear 1-KiB copy
 //   per wave instruction: measured 64 KB / 1.05 us per CU vs 1.98 us for 128-B pieces at a
 //   1536-B row pitch (scripts/ubench/dma_ring.hip, dma_bw.hip).
-constexpr uint32_t TILE_ROWS = 256, KCHUNK = 64, BLOCK_BYTES = TILE_ROWS * KCHUNK * 2;
+// (fp8: 1-byte elements, so a 128-byte row chunk holds 128 elements and KC = ld/128.)
+constexpr uint32_t TILE_ROWS = 256, BLOCK_BYTES = TILE_ROWS * 128;
 
-__host__ __device__ inline uint64_t blocked_row_base(uint64_t R, uint32_t ld) {
-    return ((R >> 8) * (uint64_t)(ld / KCHUNK)) * BLOCK_BYTES + (R & 255u) * 128u;
+__host__ __device__ inline constexpr uint32_t kchunk_of(int dt) { return dt == DT_FP8 ? 128u : 64u; }
+
+// byte offset of 16-byte piece pc (= elements of one 128-B chunk slot) of a row, relative to its base
+__host__ __device__ inline uint64_t blocked_piece_off(uint32_t pc, uint32_t key) {
+    return (uint64_t)(pc >> 3) * BLOCK_BYTES + (((pc & 7u) ^ key) << 4);
+}
+__host__ __device__ inline uint64_t blocked_row_base(uint64_t R, uint32_t ld, uint32_t kchunk) {
+    return ((R >> 8) * (uint64_t)(ld / kchunk)) * BLOCK_BYTES + (R & 255u) * 128u;
 }
 __host__ __device__ inline uint32_t blocked_row_key(uint64_t R) { return (uint32_t)((R & 255u) >> 1) & 7u; }
-// byte offset of element i of a row, relative to blocked_row_base
-__host__ __device__ inline uint64_t blocked_elem_off(uint32_t i, uint32_t key) {
-    return (uint64_t)(i >> 6) * BLOCK_BYTES + ((((i >> 3) & 7u) ^ key) << 4) + ((i & 7u) << 1);
-}
 
 template <int DT>
 struct Elem;
@@ -82,6 +137,7 @@ struct Elem<DT_F32> {
     static __device__ inline float cvt_load(const char* p) { return *(const float*)p; }
     static __device__ inline void cvt_store(char* p, float x) { *(float*)p = x; }
     static __device__ inline float round_trip(float x) { return x; }
+    static __host__ __device__ inline uint64_t elem_off(uint32_t i, uint32_t) { return (uint64_t)i * 4; }
 };
 template <>
 struct Elem<DT_BF16> {
@@ -89,6 +145,9 @@ struct Elem<DT_BF16> {
     static __device__ inline float cvt_load(const char* p) { return bf16_to_f32(*(const uint16_t*)p); }
     static __device__ inline void cvt_store(char* p, float x) { *(uint16_t*)p = f32_to_bf16_rne(x); }
     static __device__ inline float round_trip(float x) { return bf16_to_f32(f32_to_bf16_rne(x)); }
+    static __host__ __device__ inline uint64_t elem_off(uint32_t i, uint32_t key) {
+        return blocked_piece_off(i >> 3, key) + ((i & 7u) << 1);
+    }
 };
 template <>
 struct Elem<DT_FP16> {
@@ -96,6 +155,19 @@ struct Elem<DT_FP16> {
     static __device__ inline float cvt_load(const char* p) { return f16_to_f32(*(const uint16_t*)p); }
     static __device__ inline void cvt_store(char* p, float x) { *(uint16_t*)p = f32_to_f16_rne(x); }
     static __device__ inline float round_trip(float x) { return f16_to_f32(f32_to_f16_rne(x)); }
+    static __host__ __device__ inline uint64_t elem_off(uint32_t i, uint32_t key) {
+        return blocked_piece_off(i >> 3, key) + ((i & 7u) << 1);
+    }
+};
+template <>
+struct Elem<DT_FP8> {  // values are in the row's SCALED domain (x * 2^e), see fp8_row_exponent
+    static constexpr int bytes = 1;
+    static __device__ inline float cvt_load(const char* p) { return e4m3_to_f32(*(const uint8_t*)p); }
+    static __device__ inline void cvt_store(char* p, float x) { *(uint8_t*)p = f32_to_e4m3_rne(x); }
+    static __device__ inline float round_trip(float x) { return e4m3_to_f32(f32_to_e4m3_rne(x)); }
+    static __host__ __device__ inline uint64_t elem_off(uint32_t i, uint32_t key) {
+        return blocked_piece_off(i >> 4, key) + (i & 15u);
+    }
 };
 
 // One stored row (corpus or query) seen as a sequence of f32 values.
@@ -103,10 +175,7 @@ template <int DT>
 struct Row {
     const char* p;
     uint32_t key;
-    __device__ inline float at(uint32_t i) const {
-        if (DT == DT_F32) return Elem<DT>::cvt_load(p + (uint64_t)i * 4);
-        return Elem<DT>::cvt_load(p + blocked_elem_off(i, key));
-    }
+    __device__ inline float at(uint32_t i) const { return Elem<DT>::cvt_load(p + Elem<DT>::elem_off(i, key)); }
 };
 template <int DT>
 __device__ inline Row<DT> make_row(const char* base, uint64_t R, uint32_t ld) {
@@ -115,7 +184,7 @@ __device__ inline Row<DT> make_row(const char* base, uint64_t R, uint32_t ld) {
         r.p = base + R * (uint64_t)ld * 4;
         r.key = 0;
     } else {
-        r.p = base + blocked_row_base(R, ld);
+        r.p = base + blocked_row_base(R, ld, kchunk_of(DT));
         r.key = blocked_row_key(R);
     }
     return r;
@@ -123,7 +192,7 @@ __device__ inline Row<DT> make_row(const char* base, uint64_t R, uint32_t ld) {
 template <int DT>
 __device__ inline char* elem_ptr(char* base, uint64_t R, uint32_t ld, uint32_t i) {
     if (DT == DT_F32) return base + (R * (uint64_t)ld + i) * 4;
-    return base + blocked_row_base(R, ld) + blocked_elem_off(i, blocked_row_key(R));
+    return base + blocked_row_base(R, ld, kchunk_of(DT)) + Elem<DT>::elem_off(i, blocked_row_key(R));
 }
 
 // ---- the reference's exact f32 arithmetic ---------------------------------------

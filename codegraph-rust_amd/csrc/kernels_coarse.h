@@ -59,10 +59,23 @@ struct Mfma<DT_FP16> {
     }
 };
 
+// fp8 (e4m3): one 16-byte LDS piece holds 16 elements = the lane's share of TWO K=16 MFMAs
+// (low / high 8 bytes), so "mma" issues v_mfma_f32_32x32x16_fp8_fp8 twice and the K chunk of
+// a 128-byte row is 128 elements. Any K permutation is fine as long as A and B use the same one.
+typedef long fp8x16_t __attribute__((ext_vector_type(2)));
+template <>
+struct Mfma<DT_FP8> {
+    typedef fp8x16_t frag;
+    static __device__ inline f32x16_t mma(frag a, frag b, f32x16_t c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[0], b[0], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[1], b[1], c, 0, 0, 0);
+    }
+};
+
 constexpr uint32_t CAND_CAPS = 256;  // entries per (workgroup, query) candidate list
 
 struct CoarseArgs {
-    const char* rows;       // corpus, blocked layout B64 (2-byte elements), zero padded
+    const char* rows;       // corpus, blocked layout B64 (128-byte row chunks), zero padded
     const char* qrows;      // queries, blocked layout B64
     const float* invn_c;    // [n]
     const float* invn_q;    // [nq]
@@ -437,11 +450,11 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
     for (int i = 0; i < 2; ++i) {
         uint32_t r = rb * 64 + i * 32 + (lane & 31);
         r = r < n_boot ? r : n_boot - 1;
-        ap[i] = rows + blocked_row_base(r, ld);
+        ap[i] = rows + blocked_row_base(r, ld, kchunk_of(DT));
         akey[i] = blocked_row_key(r);
         uint32_t q = qb * 64 + i * 32 + (lane & 31);
         q = q < nq ? q : nq - 1;
-        bp[i] = qrows + blocked_row_base(q, ld);
+        bp[i] = qrows + blocked_row_base(q, ld, kchunk_of(DT));
         bkey[i] = blocked_row_key(q);
     }
     f32x16_t acc[2][2];
@@ -451,10 +464,10 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const uint32_t ks = ld / 16;
+    const uint32_t ks = ld * Elem<DT>::bytes / 32;  // pairs of 16-byte pieces per row
 #pragma unroll 4
     for (uint32_t k = 0; k < ks; ++k) {
-        // elements [16k + 8hi, +8) = 16-B chunk c = (2k + hi) & 7 of K-chunk k >> 2
+        // this lane's 16-byte piece 2k + hi = slot (2k + hi) & 7 of 128-byte row chunk k >> 2
         const uint64_t blk = (uint64_t)(k >> 2) * BLOCK_BYTES;
         const uint32_t c = (2 * k + hi) & 7u;
         frag a0 = *(const frag*)(ap[0] + blk + ((c ^ akey[0]) << 4)), a1 = *(const frag*)(ap[1] + blk + ((c ^ akey[1]) << 4));

@@ -13,6 +13,8 @@ namespace cgv {
 // in: [n][D] f32 (n rows to append). out: the index' row storage (f32: row-major [.][ld];
 // bf16/fp16: blocked layout B64, see common.h), written at absolute rows row0 + r, columns
 // zero padded to ld (multiple of 64).
+// fp8 rows are stored scaled by their own power of two (rexp[r], common.h); norms are taken in
+// that scaled domain, where the coarse pass works.
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
 // coarse pass), invn[r] = 1/norm or 0. nonfinite: set to 1 if any input is NaN/Inf.
 template <int DT>
@@ -21,16 +23,26 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
                                                         char* __restrict__ out,
                                                         float* __restrict__ norm,
                                                         float* __restrict__ invn,
+                                                        int8_t* __restrict__ rexp,
                                                         uint32_t* __restrict__ nonfinite) {
     const int lane = threadIdx.x & 63;
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float* src = in + row * (uint64_t)D;
+    int e = 0;
+    if (DT == DT_FP8) {  // per-row power-of-two scale: amax * 2^e <= 448 (common.h)
+        float amax = 0.0f;
+        for (uint32_t i = lane; i < D; i += 64) amax = fmaxf(amax, fabsf(src[i]));
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        e = fp8_row_exponent(amax);
+        if (lane == 0) rexp[row0 + row] = (int8_t)e;
+    }
     float ss = 0.0f;
     int bad = 0;
     for (uint32_t i = lane; i < ld; i += 64) {
         float x = (i < D) ? src[i] : 0.0f;
         if (!(fabsf(x) <= 3.402823466e38f)) bad = 1;  // NaN or Inf
+        if (DT == DT_FP8) x = ldexpf(x, e);            // exact
         Elem<DT>::cvt_store(elem_ptr<DT>(out, row0 + row, ld, i), x);
         float xr = Elem<DT>::round_trip(x);
         ss = fmaf(xr, xr, ss);
@@ -44,12 +56,13 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
 }
 
-// Stored row -> f32 (get_embedding).
+// Stored row -> f32 (get_embedding); fp8 rows are returned de-scaled (value * 2^-e).
 template <int DT>
 __global__ void gather_row_kernel(const char* __restrict__ rows, uint64_t R, uint32_t D, uint32_t ld,
-                                  float* __restrict__ out) {
+                                  const int8_t* __restrict__ rexp, float* __restrict__ out) {
     const Row<DT> r = make_row<DT>(rows, R, ld);
-    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = r.at(i);
+    const int e = (DT == DT_FP8 && rexp) ? (int)rexp[R] : 0;
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = ldexpf(r.at(i), -e);
 }
 
 // Per aligned 32-row block: min and max row norm over the valid rows (used by the

@@ -244,7 +244,7 @@ struct RescoreArgs {
 // LDS cooperatively (every 16-byte piece is an independent load: one memory round trip instead
 // of a serial walk over 12+ cache lines per row); then 8 lanes per candidate = the 8 AVX2 lanes
 // of the reference (common.h) run the FMA chains out of LDS, 32 candidates at a time.
-// Dynamic LDS: [query row: ld*2 B][batch rows: (ld*2 + 16) B each, +16 B pad against bank
+// Dynamic LDS: [query row: ld*esize B][batch rows: (ld*esize + 16) B each, +16 B pad against bank
 // conflicts]. rows_per_batch is chosen by the host (>= 1).
 template <int DT>
 __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t nb = a.nbest[q];
-    const uint32_t rowb = a.ld * 2, pitch = rowb + 16, pieces = rowb / 16;
+    const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
     char* qs = smem;
     char* rs = smem + rowb;
     if (tid == 0) maxerr = 0;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     {   // query row -> LDS (linear element order)
         const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
         for (uint32_t pc = tid; pc < pieces; pc += 256)
-            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)(qr.p + blocked_elem_off(pc * 8, qr.key));
+            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)(qr.p + blocked_piece_off(pc, qr.key));
     }
     for (uint32_t c0 = 0; c0 < nb; c0 += a.rows_per_batch) {
         const uint32_t nbat = (nb - c0) < a.rows_per_batch ? (nb - c0) : a.rows_per_batch;
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
                 if (e < total) {
                     const uint32_t c = e / pieces, pc = e % pieces;
                     const uint32_t row = key_row(a.best[(uint64_t)q * a.kprime + c0 + c]);
-                    v[i] = *(const uint4*)(a.rows + blocked_row_base(row, a.ld) +
-                                           blocked_elem_off(pc * 8, blocked_row_key(row)));
+                    v[i] = *(const uint4*)(a.rows + blocked_row_base(row, a.ld, kchunk_of(DT)) +
+                                           blocked_piece_off(pc, blocked_row_key(row)));
                 }
             }
 #pragma unroll

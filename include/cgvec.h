@@ -50,7 +50,7 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_DTYPE_F32 0     /* the reference's own Vec<f32> (node.rs:14) */
 #define CGV_DTYPE_BF16 1
 #define CGV_DTYPE_FP16 2
-#define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale */
+#define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale; cosine metric only */
 
 /* status codes */
 #define CGV_OK 0

@@ -549,7 +549,41 @@ float cgo_e4m3_to_f32(uint8_t b) {
     return sign ? -v : v;
 }
 
-// Round an f32 array to `dtype` and back (0=f32 identity, 1=bf16, 2=fp16, 3=fp8e4m3).
+// FP8 storage uses a per-row power-of-two scale (SURVEY.md §7 "fp8 dynamic range": unit-norm
+// 768-d components sit at e4m3's subnormal edge): stored byte = e4m3(x * 2^e), value = byte * 2^-e,
+// with e the largest exponent that keeps amax * 2^e <= 448. Power-of-two scaling is exact, so the
+// dequantised value is exactly representable in f32 and cosine is unaffected by the scale.
+int cgo_fp8_row_exponent(const float* row, size_t d) {
+    float amax = 0.0f;
+    for (size_t i = 0; i < d; ++i) {
+        float a = fabsf(row[i]);
+        if (a > amax) amax = a;  // NaN never compares greater
+    }
+    uint32_t u = f2u(amax);
+    int bexp = (int)((u >> 23) & 0xff);
+    if (amax == 0.0f || bexp == 0 || bexp == 0xff) return 0;  // zero / subnormal / inf: no scaling
+    int x = bexp - 127;                                        // amax = m * 2^x, m in [1,2)
+    uint32_t mant = u & 0x7fffffu;
+    int e = (mant <= 0x600000u) ? 8 - x : 7 - x;               // m <= 1.75 -> fits below 448 = 1.75 * 2^8
+    if (e > 100) e = 100;
+    if (e < -100) e = -100;
+    return e;
+}
+// descale != 0: the VALUES the storage holds (code * 2^-e; what get_row returns).
+// descale == 0: the e4m3 CODES as f32 (x * 2^e rounded) - the domain scores are defined in:
+// cosine is invariant under the per-row power-of-two scale, and in the code domain every
+// partial sum stays in f32's normal range whatever the magnitude of the original row.
+void cgo_round_trip_fp8_rows(const float* in, size_t n, size_t d, float* out, int descale) {
+    for (size_t r = 0; r < n; ++r) {
+        const int e = cgo_fp8_row_exponent(in + r * d, d);
+        for (size_t i = 0; i < d; ++i) {
+            const float c = cgo_e4m3_to_f32(cgo_f32_to_e4m3(ldexpf(in[r * d + i], e)));
+            out[r * d + i] = descale ? ldexpf(c, -e) : c;
+        }
+    }
+}
+
+// Round an f32 array to `dtype` and back (0=f32 identity, 1=bf16, 2=fp16, 3=fp8e4m3 UNSCALED).
 void cgo_round_trip(const float* in, size_t n, int dtype, float* out) {
     for (size_t i = 0; i < n; ++i) {
         switch (dtype) {

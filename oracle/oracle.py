@@ -66,6 +66,10 @@ def lib():
         L.cgo_quantize_u8.argtypes = [fp, C.c_size_t, u8p]
         L.cgo_search_optimized_u8.restype = C.c_uint64
         L.cgo_search_optimized_u8.argtypes = [fp, u8p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]
+        L.cgo_round_trip_fp8_rows.restype = None
+        L.cgo_round_trip_fp8_rows.argtypes = [fp, C.c_size_t, C.c_size_t, fp, C.c_int]
+        L.cgo_fp8_row_exponent.restype = C.c_int
+        L.cgo_fp8_row_exponent.argtypes = [fp, C.c_size_t]
         L.cgo_round_trip.restype = None
         L.cgo_round_trip.argtypes = [fp, C.c_size_t, C.c_int, fp]
         L.cgo_f32_to_e4m3.restype = C.c_uint8
@@ -142,8 +146,8 @@ def parallel_top_k(query, rows, k, metric=COSINE, threads=0):
 def batch_top_k(queries, rows, k, metric=COSINE, threads=0, dtype=F32):
     """N independent single-query searches (the reference's only 'batch' shape,
     search.rs:358-361) on rounded-then-upcast inputs."""
-    qs = round_trip(queries, dtype)
-    rs = round_trip(rows, dtype)
+    qs = round_trip(queries, dtype, fp8_codes=True)
+    rs = round_trip(rows, dtype, fp8_codes=True)
     idx = np.empty((qs.shape[0], k), dtype=np.uint64)
     sc = np.empty((qs.shape[0], k), dtype=np.float32)
     for i in range(qs.shape[0]):
@@ -230,12 +234,19 @@ def search_optimized_u8(query, data_u8, limit):
     return idx[:m]  # optimization.rs:63-150
 
 
-def round_trip(a, dtype):
-    """f32 -> storage dtype (RNE) -> f32."""
+def round_trip(a, dtype, scaled_fp8=True, fp8_codes=False):
+    """f32 -> storage dtype (RNE) -> f32. FP8 rows use the per-row power-of-two scale of the
+    storage format (last axis = row) unless scaled_fp8=False; fp8_codes=True returns the e4m3
+    codes (x * 2^e rounded) instead of the de-scaled values - the domain fp8 scores are defined in."""
     a, pa = _f(a)
     if dtype == F32:
         return a
     out = np.empty_like(a)
+    if dtype == FP8 and scaled_fp8:
+        d = a.shape[-1] if a.ndim else 1
+        lib().cgo_round_trip_fp8_rows(pa, a.size // max(d, 1), d, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                      0 if fp8_codes else 1)
+        return out
     lib().cgo_round_trip(pa, a.size, dtype, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
 

@@ -10,7 +10,7 @@ from _util import pkg
 
 pytestmark = pytest.mark.gpu
 
-ODT = {"f32": 0, "bf16": 1, "fp16": 2}
+ODT = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
 OMETRIC = {"cosine": 0, "dot": 1}
 
 
@@ -48,9 +48,9 @@ def test_device_visible():
     assert pkg().device_count() >= 1
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8"])
 @pytest.mark.parametrize("d", [64, 128, 768, 100])
-def test_mfma_tile_mapping_dense_scores(dtype, d):
+def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
     """Dense coarse scores of the MFMA kernel vs an fp32 matmul of the rounded inputs
     (tolerance 2e-4 abs on cosine: fp32 accumulation-order noise only). Asymmetric data
     catches row/column swaps in the MFMA C layout."""
@@ -63,11 +63,15 @@ def test_mfma_tile_mapping_dense_scores(dtype, d):
     ix = m.HipKnnIndex(d, metric="cosine", dtype=dtype)
     try:
         ix.add(rows)
-        tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
         qd = torch.from_numpy(queries).cuda()
         got = ix.debug_coarse_scores(qd).cpu().numpy()
-        r = torch.from_numpy(rows).to(tdt).double()
-        q = torch.from_numpy(queries).to(tdt).double()
+        if dtype == "fp8":   # e4m3 codes under the per-row power-of-two scale
+            r = torch.from_numpy(oracle.round_trip(rows, 3, fp8_codes=True)).double()
+            q = torch.from_numpy(oracle.round_trip(queries, 3, fp8_codes=True)).double()
+        else:
+            tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+            r = torch.from_numpy(rows).to(tdt).double()
+            q = torch.from_numpy(queries).to(tdt).double()
         ref = (q / q.norm(dim=1, keepdim=True)) @ (r / r.norm(dim=1, keepdim=True)).T
         err = np.abs(got - ref.numpy())
         assert not np.isnan(got).any(), "unwritten entries in the dense dump"
@@ -77,12 +81,13 @@ def test_mfma_tile_mapping_dense_scores(dtype, d):
 
 
 @pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "cosine"), ("bf16", "dot"),
-                                          ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot")])
+                                          ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot"),
+                                          ("fp8", "cosine")])
 def test_parity_small(oracle, dtype, metric):
     _run(oracle, n=1000, d=256, nq=7, k=10, dtype=dtype, metric=metric)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "fp8"])
 @pytest.mark.parametrize("d", [8, 31, 33, 37, 100, 384, 1536])
 def test_parity_ragged_dims(oracle, dtype, d):
     """D < 32 takes the reference's scalar branch (simd_ops.rs:281-295); D % 8 != 0 the tail."""
@@ -111,11 +116,11 @@ def test_parity_c1_hash_embedder_corpus(oracle):
             ix.close()
 
 
-@pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "dot")])
+@pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "dot"), ("fp8", "cosine")])
 def test_parity_medium_staged(oracle, dtype, metric):
     """70k rows -> 274 corpus tiles: exercises all three threshold stages, several
     query tiles (nq=300) and the strided sample."""
-    st = _run(oracle, n=70_000, d=768 if dtype == "bf16" else 1536 // 4, nq=300, k=10, dtype=dtype, metric=metric, seed=3)
+    st = _run(oracle, n=70_000, d=1536 // 4 if dtype == "fp16" else 768, nq=300, k=10, dtype=dtype, metric=metric, seed=3)
     assert st["last_path"] == 1
     assert st["fallback_queries"] == 0
     assert st["max_observed_err"] <= st["last_eps"]
@@ -163,6 +168,46 @@ def test_incremental_add_equals_bulk_add(oracle):
         assert np.array_equal(ix.get_row(1234), oracle.round_trip(rows[1234], 1))
     finally:
         ix.close()
+
+
+def test_fp8_storage_semantics(oracle):
+    """BASELINE config C5's storage: e4m3fn codes under a per-row power-of-two scale
+    (SURVEY.md §7 'fp8 dynamic range'). get_row returns code * 2^-e; rows of wildly different
+    magnitude, zero rows and duplicates keep the (score desc, id asc) order of the oracle;
+    dot is refused (the per-row scale is not carried into a dot product)."""
+    m = pkg()
+    rng = np.random.default_rng(33)
+    d = 200
+    rows = _unit(rng, 6000, d) * np.exp2(rng.integers(-20, 20, (6000, 1))).astype(np.float32)
+    rows[50:60] = 0.0
+    rows[700:720] = rows[3] * np.float32(4.0)     # same direction, other scale -> identical codes
+    queries = _unit(rng, 12, d)
+    queries[0] = rows[3]
+    queries[1] = 0.0
+    ix = m.HipKnnIndex(d, dtype="fp8")
+    try:
+        ix.add(rows[:2500])
+        ix.add(rows[2500:])
+        idx, sc = ix.search(queries, 25)
+        _check(oracle, rows, queries, 25, "fp8", "cosine", idx, sc, "fp8 semantics")
+        assert idx[0, :21].tolist() == [3] + list(range(700, 720))
+        for r in (0, 3, 55, 4321):
+            assert np.array_equal(ix.get_row(r), oracle.round_trip(rows[r], 3))
+        ix.update_row(10, rows[3])
+        idx2, _ = ix.search(queries[:1], 25)
+        assert idx2[0, :2].tolist() == [3, 10]
+        cur = oracle.round_trip(np.vstack([rows[:10], rows[3:4], rows[11:]]), 3, fp8_codes=True)
+        q2 = oracle.round_trip(queries[2], 3, fp8_codes=True)
+        for op, fn in (("cosine", oracle.cosine_adaptive), ("cosine_seq", oracle.search_cosine),
+                       ("cosine_distance_seq", oracle.cosine_distance)):
+            ref = np.array([fn(q2, r) for r in cur[:400]], np.float32)
+            assert np.array_equal(ix.batch_similarity(queries[2], op=op, limit_rows=400), ref), op
+        with pytest.raises(m.CgvError):
+            ix.batch_similarity(queries[2], op="dot")
+    finally:
+        ix.close()
+    with pytest.raises(m.CgvError):
+        m.HipKnnIndex(d, metric="dot", dtype="fp8")
 
 
 def test_kat_parallel_operations_on_gpu(oracle):

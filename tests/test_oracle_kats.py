@@ -222,7 +222,7 @@ def test_dtype_round_trips(oracle):
     t = torch.from_numpy(x)
     assert np.array_equal(oracle.round_trip(x, oracle.BF16), t.to(torch.bfloat16).float().numpy())
     assert np.array_equal(oracle.round_trip(x, oracle.FP16), t.to(torch.float16).float().numpy())
-    got = oracle.round_trip(x, oracle.FP8)
+    got = oracle.round_trip(x, oracle.FP8, scaled_fp8=False)
     ref = t.clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()  # torch cast: RNE, no saturation
     assert np.array_equal(got, ref)
 
@@ -232,3 +232,19 @@ def test_merge_topk(oracle):
     sc = np.array([[0.9, 0.5, -np.inf], [0.9, 0.6, 0.1]], dtype=np.float32)
     oi, os_ = oracle.merge_topk(idx, sc, 3)
     assert oi.tolist() == [1, 5, 7] and np.allclose(os_, [0.9, 0.9, 0.6])
+
+
+def test_fp8_row_scaling(oracle):
+    rng = np.random.default_rng(4)
+    rows = rng.standard_normal((64, 768)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)        # components ~0.036: e4m3 subnormal edge
+    q = oracle.round_trip(rows, oracle.FP8)
+    rel = np.abs(q - rows).max(axis=1) / np.abs(rows).max(axis=1)
+    assert rel.max() < 2 ** -4                                  # <= half an e4m3 ulp of the row maximum
+    # scaled value is exactly e4m3-representable after scaling, scale is a power of two <= 448/amax
+    for r, qr in zip(rows[:8], q[:8]):
+        e = oracle.lib().cgo_fp8_row_exponent(r.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float)), r.size)
+        assert np.abs(r).max() * 2.0 ** e <= 448.0 < np.abs(r).max() * 2.0 ** (e + 1)
+        assert np.array_equal(oracle.round_trip(qr * np.float32(2.0 ** e), oracle.FP8, scaled_fp8=False), qr * np.float32(2.0 ** e))
+    # cosine is scale invariant bit-for-bit (power-of-two scaling is exact)
+    assert oracle.cosine_avx2(q[0], q[1]) == oracle.cosine_avx2(q[0] * np.float32(256), q[1] * np.float32(0.125))
