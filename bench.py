@@ -20,6 +20,7 @@ queries already resident in HBM. Rank 0 prints ONE JSON line.
                  bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import collections
 import importlib
 import json
 import os
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly serial steps)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=32)
     args = ap.parse_args()
@@ -129,16 +131,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # `depth` batches in flight (the index' context pool: each batch on its own HIP stream), every
+    # one of the K steps begun AND completed inside the timed region.
+    depth = max(1, args.depth)
     for i in range(args.warmup):
         searcher.search(qpool[i % npool], k)
     sync_all()
     coarse_ms, coarse_rows = [], 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out_idx, out_sc = searcher.search(qpool[i % npool], k)
-        st = ix.stats()   # host-side read of the previous HIP-event pair; no extra device sync
+    pend = collections.deque()
+
+    def retire():
+        nonlocal coarse_rows
+        out = pend.popleft().wait()
+        st = ix.stats()   # host-side read of that batch's HIP-event pair; no extra device sync
         coarse_ms.append(st["last_coarse_ms"])
         coarse_rows = st["coarse_rows"]
+        return out
+
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pend.append(searcher.search_begin(qpool[i % npool], k))
+        if len(pend) >= depth:
+            out_idx, out_sc = retire()
+    while pend:
+        out_idx, out_sc = retire()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -177,7 +193,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {n_total} x {dim} {dtype} {metric} brute-force kNN, "
                                    f"batch={batch}, k={k}", "rows": n_total, "dim": dim, "batch": batch, "k": k,
-                       "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none"},
+                       "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
+                       "batches_in_flight": depth},
             "roofline": roof,
             "pipeline": {"device_ms_last_step": round(st["last_total_ms"], 4), "kprime": st["last_kprime"],
                          "fallback_queries": int(st["fallback_queries"]), "eps": st["last_eps"],

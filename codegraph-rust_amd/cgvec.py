@@ -79,6 +79,8 @@ def lib():
     L.cgv_update_row_f32.argtypes = [vp, u64, vp]
     L.cgv_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_search_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp]
+    L.cgv_search_begin_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp, C.POINTER(u64)]
+    L.cgv_search_end.argtypes = [vp, u64]
     L.cgv_get_row_f32.argtypes = [vp, u64, vp]
     L.cgv_batch_similarity_f32.argtypes = [vp, vp, i32, u64, vp]
     L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
@@ -92,7 +94,7 @@ def lib():
     L.cgv_set_force_exact.argtypes = [vp, i32]
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
     for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
-                 "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_get_row_f32",
+                 "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
                  "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
         getattr(L, name).restype = i32
@@ -111,6 +113,27 @@ def device_count():
 
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
+
+
+class PendingSearch:
+    """A batch in flight; keeps the query / output tensors alive until wait()."""
+
+    def __init__(self, index, ticket, q, idx, sc):
+        self._ix, self._t, self._q, self._idx, self._sc = index, ticket, q, idx, sc
+
+    def wait(self):
+        if self._t:
+            t, self._t = self._t, 0
+            _check(lib().cgv_search_end(self._ix._h, C.c_uint64(t)))
+        self._q = None
+        return self._idx, self._sc
+
+    def __del__(self):
+        try:
+            if self._t and self._ix._h:
+                lib().cgv_search_end(self._ix._h, C.c_uint64(self._t))
+        except Exception:
+            pass
 
 
 class HipKnnIndex:
@@ -200,6 +223,27 @@ class HipKnnIndex:
         out = np.empty(self.dim, dtype=np.float32)
         _check(lib().cgv_get_row_f32(self._h, int(i), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def search_begin(self, queries, k):
+        """Enqueue one batch (CUDA tensor [nq, dim]) and return a PendingSearch; .wait() gives
+        (idx, score) CUDA tensors. Up to the handle's context-pool depth batches overlap on the
+        device (cgv_search_begin_f32_dev / cgv_search_end)."""
+        import torch
+        k = int(k)
+        if not (_is_torch(queries) and queries.is_cuda):
+            raise CgvError(CGV_ERR_INVALID_ARG, "search_begin takes a CUDA tensor")
+        if queries.dim() != 2 or queries.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {tuple(queries.shape)} != {self.dim}")
+        q = queries.detach().to(torch.float32).contiguous()
+        nq = q.shape[0]
+        self.use_torch_stream()  # order after the producer of `queries`
+        idx = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        t = C.c_uint64(0)
+        if nq and k:
+            _check(lib().cgv_search_begin_f32_dev(self._h, C.c_void_p(q.data_ptr()), nq, k,
+                                                  C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr()), C.byref(t)))
+        return PendingSearch(self, t.value, q, idx, sc)
 
     def search(self, queries, k):
         """queries [nq, dim] -> (idx uint64 [nq,k], score f32 [nq,k]); numpy in -> numpy out,

@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -93,6 +94,43 @@ uint32_t kprime_of(uint32_t k) {
 
 }  // namespace
 
+// Per-search scratch + stream. A handle owns N_CTX of them so that consecutive batches (or
+// concurrent callers, SURVEY.md §8(b) "internal stream pool") overlap on the device: the short
+// latency-bound kernels of one batch (boot, select, re-score) run beside the coarse kernel of
+// the next one. Everything a search writes lives here; the corpus is shared and read-only.
+struct SearchCtx {
+    hipStream_t stream = nullptr;  // owned, non-blocking
+    hipEvent_t dep = nullptr;      // ordering after the caller's stream (ingest, query producer)
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* flags = nullptr;    // device, F_COUNT words
+    uint32_t* h_flags = nullptr;  // pinned host mirror
+    DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
+        keysA, keysB, outidx, outscore, dump;
+    bool busy = false;
+    // state of the search in flight (between begin and end)
+    uint32_t gen = 0, nq = 0, k = 0;
+    uint64_t* out_idx = nullptr;
+    float* out_score = nullptr;
+    bool mfma = false, timed_coarse = false;
+    uint64_t coarse_rows = 0;
+    float eps = 0.0f;
+    uint32_t kprime = 0;
+    size_t bytes() const {
+        const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
+                                &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump};
+        size_t b = 0;
+        for (const DevBuf* d : bufs) b += d->bytes;
+        return b;
+    }
+    void release_all() {
+        DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
+                          &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump};
+        for (DevBuf* d : bufs) d->release();
+    }
+};
+
+constexpr int N_CTX = 3;
+
 struct cgv_index {
     int device = 0;
     uint32_t D = 0, ld = 0;
@@ -105,18 +143,17 @@ struct cgv_index {
     float* blk_min = nullptr;
     float* blk_max = nullptr;
     int8_t* rexp = nullptr;       // fp8 only: per-row scale exponent
-    DevBuf qrexp;                 // fp8 only: per-query scale exponent
-    uint32_t* flags = nullptr;    // device, F_COUNT words
+    uint32_t* flags = nullptr;    // device, F_COUNT words (ingest side)
     float* max_norm_dev = nullptr;
     uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t own_stream = nullptr, stream = nullptr;  // ingest / caller-ordering stream
     int n_cu = 256;
     bool corpus_nonfinite = false;
     float max_norm_c = 0.0f;
-    DevBuf qstage, qrows, qnorm, qinvn, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt,
-        scores, keysA, keysB, outidx, outscore, addstage, dump;
+    DevBuf addstage;
+    SearchCtx ctx[N_CTX];
     std::mutex mu;
+    std::condition_variable cv;
     bool profiling = false, force_exact = false;
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
@@ -135,10 +172,8 @@ size_t storage_bytes(const cgv_index* h, uint64_t nrows) {
 size_t device_bytes(const cgv_index* h) {
     size_t b = 0;
     if (h->rows) b += storage_bytes(h, h->cap) + (size_t)h->cap * 8 + ((size_t)h->cap / 32 + 1) * 8;
-    const DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best,
-                            &h->overflow, &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores,
-                            &h->keysA, &h->keysB, &h->outidx, &h->outscore, &h->addstage, &h->dump};
-    for (const DevBuf* d : bufs) b += d->bytes;
+    b += h->addstage.bytes;
+    for (const SearchCtx& c : h->ctx) b += c.bytes();
     return b;
 }
 
@@ -262,16 +297,16 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
-int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
+int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
                   const float* dense, uint32_t n_dense, hipStream_t s) {
     SelectArgs sa;
-    sa.cand = h->cand.as<uint2>();
-    sa.cand_cnt = h->candcnt.as<uint32_t>();
+    sa.cand = c->cand.as<uint2>();
+    sa.cand_cnt = c->candcnt.as<uint32_t>();
     sa.dense = dense;
-    sa.best = h->best.as<uint64_t>();
-    sa.nbest = h->nbest.as<uint32_t>();
-    sa.tau = h->tau.as<float>();
-    sa.overflow = h->overflow.as<uint32_t>();
+    sa.best = c->best.as<uint64_t>();
+    sa.nbest = c->nbest.as<uint32_t>();
+    sa.tau = c->tau.as<float>();
+    sa.overflow = c->overflow.as<uint32_t>();
     sa.nq = nq;
     sa.nqt = nqt;
     sa.nsplit = nsplit;
@@ -295,15 +330,15 @@ int launch_select(cgv_index* h, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
 }
 
 template <int DT>
-void launch_exact_scores(cgv_index* h, const uint32_t* qlist, uint32_t nql, float* scores, int op, hipStream_t s) {
+void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint32_t nql, float* scores, int op, hipStream_t s) {
     uint64_t gx = ((uint64_t)h->n + 31) / 32;
     if (gx > 16384) gx = 16384;
     hipLaunchKernelGGL(exact_scores_kernel<DT>, dim3((unsigned)gx, nql), dim3(256), 0, s, h->rows,
-                       h->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, op, scores);
+                       c->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, op, scores);
 }
 
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
-int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
+int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
                  float* out_score, hipStream_t s, int op = -1) {
     if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : OP_COSINE;
     const uint64_t n = h->n;
@@ -312,31 +347,31 @@ int exact_search(cgv_index* h, const uint32_t* qlist_dev, uint32_t nql, uint32_t
     qg = std::min<uint64_t>(qg, nql);
     qg = std::min<uint64_t>(qg, 65535);
     int rc;
-    if ((rc = h->scores.ensure((size_t)qg * n * 4))) return rc;
+    if ((rc = c->scores.ensure((size_t)qg * n * 4))) return rc;
     const uint32_t nch0 = (uint32_t)((n + TOPK_CHUNK - 1) / TOPK_CHUNK);
-    if ((rc = h->keysA.ensure((size_t)qg * nch0 * K * 8))) return rc;
-    if ((rc = h->keysB.ensure((size_t)qg * ((size_t)nch0 * K / TOPK_CHUNK + 1) * K * 8))) return rc;
+    if ((rc = c->keysA.ensure((size_t)qg * nch0 * K * 8))) return rc;
+    if ((rc = c->keysB.ensure((size_t)qg * ((size_t)nch0 * K / TOPK_CHUNK + 1) * K * 8))) return rc;
     for (uint32_t q0 = 0; q0 < nql; q0 += (uint32_t)qg) {
         const uint32_t g = (uint32_t)std::min<uint64_t>(qg, nql - q0);
         const uint32_t* ql = qlist_dev + q0;
-        float* sc = h->scores.as<float>();
+        float* sc = c->scores.as<float>();
         switch (h->dtype) {
-            case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, ql, g, sc, op, s); break;
-            case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, ql, g, sc, op, s); break;
-            case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, ql, g, sc, op, s); break;
-            case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, ql, g, sc, op, s); break;
+            case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, c, ql, g, sc, op, s); break;
+            case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, c, ql, g, sc, op, s); break;
+            case CGV_DTYPE_FP16: launch_exact_scores<DT_FP16>(h, c, ql, g, sc, op, s); break;
+            case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, c, ql, g, sc, op, s); break;
             default: return fail(CGV_ERR_INTERNAL, "exact path: unsupported dtype");
         }
-        uint64_t* cur = h->keysA.as<uint64_t>();
-        uint64_t* nxt = h->keysB.as<uint64_t>();
+        uint64_t* cur = c->keysA.as<uint64_t>();
+        uint64_t* nxt = c->keysB.as<uint64_t>();
         uint32_t nch = nch0;
         hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch, g), dim3(256), 0, s, sc, (const uint64_t*)nullptr,
-                           (uint32_t)n, K, cur, h->flags + F_NAN);
+                           (uint32_t)n, K, cur, c->flags + F_NAN);
         while (nch > 1) {
             const uint32_t M = nch * K;
             const uint32_t nch2 = (M + TOPK_CHUNK - 1) / TOPK_CHUNK;
             hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch2, g), dim3(256), 0, s, (const float*)nullptr,
-                               (const uint64_t*)cur, M, K, nxt, h->flags + F_NAN);
+                               (const uint64_t*)cur, M, K, nxt, c->flags + F_NAN);
             std::swap(cur, nxt);
             nch = nch2;
         }
@@ -413,50 +448,58 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
 }
 
 template <int DT>
-void launch_boot(cgv_index* h, uint32_t n_boot, uint32_t nq, float* dense, hipStream_t s) {
+void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, hipStream_t s) {
     const uint32_t nrb = (n_boot + 63) / 64, nqb = (nq + 63) / 64;
     hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s, (const char*)h->rows,
-                       (const char*)h->qrows.p, (const float*)h->invn, (const float*)h->qinvn.p, n_boot, nq, h->ld,
+                       (const char*)c->qrows.p, (const float*)h->invn, (const float*)c->qinvn.p, n_boot, nq, h->ld,
                        h->metric, dense);
 }
 
-int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, uint64_t* out_idx,
-                      float* out_score) {
-    hipStream_t s = h->stream;
+// Enqueue one batch on the context's stream (no host synchronisation); search_finish() completes it.
+// Caller holds h->mu and owns the context.
+int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, uint32_t k, uint64_t* out_idx,
+                   float* out_score) {
+    hipStream_t s = c->stream;
     int rc;
     h->st.searches++;
     h->st.queries += nq;
+    c->nq = nq;
+    c->k = k;
+    c->out_idx = out_idx;
+    c->out_score = out_score;
+    c->mfma = false;
+    c->timed_coarse = false;
+    c->coarse_rows = 0;
+    c->kprime = 0;
+    HIPCHK(hipMemsetAsync(c->flags, 0, F_COUNT * 4, s));
     if (h->n == 0) {
         uint64_t tot = (uint64_t)nq * k;
         hipLaunchKernelGGL(pad_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, out_idx,
                            out_score, tot);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
+        c->mfma = true;  // nothing left to do in search_finish
+        HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
         return CGV_OK;
     }
     if (h->corpus_nonfinite)
         return fail(CGV_ERR_NONFINITE, "index holds NaN/Inf rows (the reference panics at simd_ops.rs:379)");
 
-    if (h->profiling) HIPCHK(hipEventRecord(h->ev[0], s));
+    if (h->profiling) HIPCHK(hipEventRecord(c->ev[0], s));
     // --- queries: round to storage dtype, norms ---
-    if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;  // whole 256-query tiles (DMA reads them)
-    if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->qrexp.ensure((size_t)nq + 16))) return rc;
-    if ((rc = h->fbflag.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->qlist.ensure((size_t)nq * 4))) return rc;
-    HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
-    rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
-                       h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
+    if ((rc = c->qrows.ensure(storage_bytes(h, nq)))) return rc;  // whole 256-query tiles (DMA reads them)
+    if ((rc = c->qnorm.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->qrexp.ensure((size_t)nq + 16))) return rc;
+    if ((rc = c->fbflag.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->qlist.ensure((size_t)nq * 4))) return rc;
+    rc = prep_dispatch(h->dtype, qdev, nq, h->D, h->ld, 0, c->qrows.as<char>(), c->qnorm.as<float>(),
+                       c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
 
     const uint32_t kprime = kprime_of(k);
     const bool mfma = !h->force_exact && h->dtype != CGV_DTYPE_F32 && kprime <= CAND_CAPS;
-    h->st.last_path = mfma ? 1u : 0u;
-    h->st.last_kprime = mfma ? kprime : 0u;
-    h->st.last_coarse_ms = 0.0f;
-    h->last_coarse_rows = 0;
-    bool timed_coarse = false;
+    c->mfma = mfma;
+    c->kprime = mfma ? kprime : 0u;
 
     if (mfma) {
         const uint32_t nqt = (nq + BN - 1) / BN;
@@ -464,37 +507,37 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         const StagePlan p = plan_stages(h->n, kprime, nsplit_max);
         const uint32_t Wmax = nqt * nsplit_max;
         const uint32_t n_boot = (uint32_t)std::min<uint64_t>((uint64_t)p.T1 * BM, h->n);
-        if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
-        if ((rc = h->nbest.ensure((size_t)nq * 4))) return rc;
-        if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
-        if ((rc = h->best.ensure((size_t)nq * kprime * 8))) return rc;
-        if ((rc = h->cand.ensure((size_t)Wmax * BN * CAND_CAPS * 8))) return rc;
-        if ((rc = h->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
-        if ((rc = h->dump.ensure((size_t)nq * n_boot * 4))) return rc;
-        HIPCHK(hipMemsetAsync(h->nbest.p, 0, (size_t)nq * 4, s));
-        HIPCHK(hipMemsetAsync(h->overflow.p, 0, (size_t)nq * 4, s));
+        if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
+        if ((rc = c->nbest.ensure((size_t)nq * 4))) return rc;
+        if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
+        if ((rc = c->best.ensure((size_t)nq * kprime * 8))) return rc;
+        if ((rc = c->cand.ensure((size_t)Wmax * BN * CAND_CAPS * 8))) return rc;
+        if ((rc = c->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
+        if ((rc = c->dump.ensure((size_t)nq * n_boot * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c->nbest.p, 0, (size_t)nq * 4, s));
+        HIPCHK(hipMemsetAsync(c->overflow.p, 0, (size_t)nq * 4, s));
 
         // boot: dense scores of the first n_boot rows -> top-k' -> first tau
         if (h->dtype == CGV_DTYPE_BF16)
-            launch_boot<DT_BF16>(h, n_boot, nq, h->dump.as<float>(), s);
+            launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), s);
         else if (h->dtype == CGV_DTYPE_FP16)
-            launch_boot<DT_FP16>(h, n_boot, nq, h->dump.as<float>(), s);
+            launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), s);
         else
-            launch_boot<DT_FP8>(h, n_boot, nq, h->dump.as<float>(), s);
+            launch_boot<DT_FP8>(h, c, n_boot, nq, c->dump.as<float>(), s);
         HIPCHK(hipGetLastError());
-        if ((rc = launch_select(h, nq, nqt, 0, kprime, h->dump.as<float>(), n_boot, s))) return rc;
+        if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s))) return rc;
 
         CoarseArgs a;
         a.rows = h->rows;
-        a.qrows = h->qrows.as<char>();
+        a.qrows = c->qrows.as<char>();
         a.invn_c = h->invn;
-        a.invn_q = h->qinvn.as<float>();
+        a.invn_q = c->qinvn.as<float>();
         a.blk_min = h->blk_min;
         a.blk_max = h->blk_max;
-        a.tau = h->tau.as<float>();
-        a.cand = h->cand.as<uint2>();
-        a.cand_cnt = h->candcnt.as<uint32_t>();
-        a.overflow = h->overflow.as<uint32_t>();
+        a.tau = c->tau.as<float>();
+        a.cand = c->cand.as<uint2>();
+        a.cand_cnt = c->candcnt.as<uint32_t>();
+        a.overflow = c->overflow.as<uint32_t>();
         a.dump = nullptr;
         a.n = (uint32_t)h->n;
         a.nq = nq;
@@ -512,29 +555,29 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
             a.cnt = cnt;
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
             const bool dominant = (st + 1 == p.counts.size());
-            if (h->profiling && dominant) HIPCHK(hipEventRecord(h->ev[1], s));
+            if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
             if ((rc = launch_coarse(h->dtype, false, a, nqt * a.nsplit, s))) return rc;
             if (h->profiling && dominant) {
-                HIPCHK(hipEventRecord(h->ev[2], s));
-                timed_coarse = true;
-                h->last_coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
+                HIPCHK(hipEventRecord(c->ev[2], s));
+                c->timed_coarse = true;
+                c->coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
-            if ((rc = launch_select(h, nq, nqt, a.nsplit, kprime, nullptr, 0, s))) return rc;
+            if ((rc = launch_select(c, nq, nqt, a.nsplit, kprime, nullptr, 0, s))) return rc;
             j0 += cnt;
         }
         RescoreArgs r;
-        r.best = h->best.as<uint64_t>();
-        r.nbest = h->nbest.as<uint32_t>();
-        r.tau = h->tau.as<float>();
+        r.best = c->best.as<uint64_t>();
+        r.nbest = c->nbest.as<uint32_t>();
+        r.tau = c->tau.as<float>();
         r.rows = h->rows;
-        r.qrows = h->qrows.as<char>();
-        r.norm_q = h->qnorm.as<float>();
-        r.overflow = h->overflow.as<uint32_t>();
+        r.qrows = c->qrows.as<char>();
+        r.norm_q = c->qnorm.as<float>();
+        r.overflow = c->overflow.as<uint32_t>();
         r.out_idx = out_idx;
         r.out_score = out_score;
-        r.fb_flag = h->fbflag.as<uint32_t>();
-        r.fb_count = h->flags + F_FB_COUNT;
-        r.stat_maxerr = h->flags + F_MAXERR;
+        r.fb_flag = c->fbflag.as<uint32_t>();
+        r.fb_count = c->flags + F_FB_COUNT;
+        r.stat_maxerr = c->flags + F_MAXERR;
         r.index_base = h->index_base;
         r.nq = nq;
         r.n = (uint32_t)h->n;
@@ -547,7 +590,7 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         // path adds D/16 partial sums, the reference D/8 per lane + a 3-level tree
         r.eps_scale = ((float)h->D * 0.5f + 64.0f) * 5.9604645e-8f;
         r.max_norm_c = h->max_norm_c;
-        h->st.last_eps = r.eps_scale;
+        c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
             const size_t budget = 48 * 1024;  // LDS for staged rows
@@ -573,36 +616,95 @@ int search_dev_locked(cgv_index* h, const float* qdev, uint32_t nq, uint32_t k, 
         }
         HIPCHK(hipGetLastError());
     }
-    if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
-    HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (h->h_flags[F_NONFINITE_Q])
-        return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
+    if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
+    return CGV_OK;
+}
 
-    if (!mfma) {
-        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->qlist.as<uint32_t>(), nq);
-        if ((rc = exact_search(h, h->qlist.as<uint32_t>(), nq, k, out_idx, out_score, s))) return rc;
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
+// Wait for the batch enqueued on `c`, run the exact path for the queries whose guarantee check
+// failed (or for all of them on an f32 / forced-exact index), fold the statistics in.
+// Called WITHOUT h->mu (the context is owned by the caller); takes it for the statistics.
+int search_finish(cgv_index* h, SearchCtx* c) {
+    hipStream_t s = c->stream;
+    const uint32_t nq = c->nq, k = c->k;
+    int rc;
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->h_flags[F_NONFINITE_Q])
+        return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
+    uint32_t nfb = 0;
+    float me = 0.0f;
+    if (!c->mfma) {
+        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
+        if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, c->out_idx, c->out_score, s))) return rc;
+        if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
-        float me;
-        memcpy(&me, &h->h_flags[F_MAXERR], 4);
-        h->st.max_observed_err = std::max(h->st.max_observed_err, me);
-        const uint32_t nfb = h->h_flags[F_FB_COUNT];
+        memcpy(&me, &c->h_flags[F_MAXERR], 4);
+        nfb = c->h_flags[F_FB_COUNT];
         if (nfb > 0) {
-            h->st.fallback_queries += nfb;
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
-                               h->fbflag.as<uint32_t>(), nq, h->qlist.as<uint32_t>(), h->flags + F_COMPACT);
-            if ((rc = exact_search(h, h->qlist.as<uint32_t>(), nfb, k, out_idx, out_score, s))) return rc;
-            if (h->profiling) HIPCHK(hipEventRecord(h->ev[3], s));
+                               c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
+            if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nfb, k, c->out_idx, c->out_score, s))) return rc;
+            if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
             HIPCHK(hipStreamSynchronize(s));
         }
     }
+    float coarse_ms = 0.0f, total_ms = 0.0f;
     if (h->profiling) {
         float ms = 0.0f;
-        if (timed_coarse && hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->st.last_coarse_ms = ms;
-        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[3]) == hipSuccess) h->st.last_total_ms = ms;
+        if (c->timed_coarse && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) coarse_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) total_ms = ms;
     }
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->st.max_observed_err = std::max(h->st.max_observed_err, me);
+    h->st.fallback_queries += nfb;
+    h->st.last_path = (c->mfma && h->n) ? 1u : 0u;
+    h->st.last_kprime = c->kprime;
+    h->st.last_eps = c->eps;
+    h->st.last_coarse_ms = coarse_ms;
+    h->st.last_total_ms = total_ms;
+    h->last_coarse_rows = c->coarse_rows;
+    return CGV_OK;
+}
+
+// ---- context pool ---------------------------------------------------------------
+// A search holds one context from acquire to release; writers (add / update / reserve /
+// set_stream) wait until every context is free and keep h->mu while they work.
+SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk) {
+    SearchCtx* got = nullptr;
+    h->cv.wait(lk, [&] {
+        for (SearchCtx& c : h->ctx)
+            if (!c.busy) {
+                got = &c;
+                return true;
+            }
+        return false;
+    });
+    got->busy = true;
+    got->gen++;
+    return got;
+}
+
+void release_ctx(cgv_index* h, SearchCtx* c) {
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        c->busy = false;
+    }
+    h->cv.notify_all();
+}
+
+void wait_all_idle(cgv_index* h, std::unique_lock<std::mutex>& lk) {
+    h->cv.wait(lk, [&] {
+        for (SearchCtx& c : h->ctx)
+            if (c.busy) return false;
+        return true;
+    });
+}
+
+// order the context's stream after everything the caller queued on the handle's stream
+int order_after_caller(cgv_index* h, SearchCtx* c) {
+    HIPCHK(hipEventRecord(c->dep, h->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->dep, 0));
     return CGV_OK;
 }
 
@@ -654,7 +756,14 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (e == hipSuccess) e = hipMalloc((void**)&h->flags, F_COUNT * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&h->max_norm_dev, 4);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, (F_COUNT + 1) * 4);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+    for (SearchCtx& c : h->ctx) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
+        if (e == hipSuccess) e = hipMalloc((void**)&c.flags, F_COUNT * 4);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4);
+        if (e == hipSuccess) e = hipMemset(c.flags, 0, F_COUNT * 4);
+    }
     if (e == hipSuccess) e = hipMemset(h->flags, 0, F_COUNT * 4);
     if (e == hipSuccess) e = hipMemset(h->max_norm_dev, 0, 4);
     if (e != hipSuccess) {
@@ -679,16 +788,20 @@ int cgv_destroy(cgv_index* h) {
         (void)hipFree(h->blk_max);
         (void)hipFree(h->rexp);
     }
-    h->qrexp.release();
-    DevBuf* bufs[] = {&h->qstage, &h->qrows, &h->qnorm, &h->qinvn, &h->tau, &h->nbest, &h->best, &h->overflow,
-                      &h->fbflag, &h->qlist, &h->cand, &h->candcnt, &h->scores, &h->keysA, &h->keysB,
-                      &h->outidx, &h->outscore, &h->addstage, &h->dump};
-    for (DevBuf* d : bufs) d->release();
+    h->addstage.release();
+    for (SearchCtx& c : h->ctx) {
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        c.release_all();
+        if (c.flags) (void)hipFree(c.flags);
+        if (c.h_flags) (void)hipHostFree(c.h_flags);
+        if (c.dep) (void)hipEventDestroy(c.dep);
+        for (int i = 0; i < 4; ++i)
+            if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+    }
     if (h->flags) (void)hipFree(h->flags);
     if (h->max_norm_dev) (void)hipFree(h->max_norm_dev);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
-    for (int i = 0; i < 4; ++i)
-        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return CGV_OK;
@@ -696,7 +809,8 @@ int cgv_destroy(cgv_index* h) {
 
 int cgv_reserve(cgv_index* h, uint64_t n_rows) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
     HIPCHK(hipSetDevice(h->device));
     return grow(h, n_rows);
 }
@@ -704,7 +818,8 @@ int cgv_reserve(cgv_index* h, uint64_t n_rows) {
 int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (n && !rows_dev) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
     HIPCHK(hipSetDevice(h->device));
     return add_dev_locked(h, rows_dev, n);
 }
@@ -712,7 +827,8 @@ int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n) {
 int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (n && !rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + n);
     if (rc) return rc;
@@ -729,7 +845,8 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
 
 int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     if (!h || !row_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     HIPCHK(hipSetDevice(h->device));
     int rc;
@@ -764,47 +881,107 @@ int cgv_set_index_base(cgv_index* h, uint64_t base) {
     return CGV_OK;
 }
 
+static int check_search_args(cgv_index* h, const void* q, uint32_t k, const void* oi, const void* os) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
+    if (!q || !oi || !os) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    return CGV_OK;
+}
+
+int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
+                             uint64_t* out_idx_dev, float* out_score_dev, uint64_t* ticket) {
+    if (!ticket) return fail(CGV_ERR_INVALID_ARG, "ticket is NULL");
+    *ticket = 0;
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || k == 0) return CGV_OK;  // surreal_store.rs:62-64; ticket 0 = nothing to wait for
+    int rc = check_search_args(h, queries_dev, k, out_idx_dev, out_score_dev);
+    if (rc) return rc;
+    std::unique_lock<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    SearchCtx* c = acquire_ctx(h, lk);
+    if ((rc = order_after_caller(h, c)) == CGV_OK)
+        rc = search_enqueue(h, c, queries_dev, nq, k, out_idx_dev, out_score_dev);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        c->busy = false;
+        lk.unlock();
+        h->cv.notify_all();
+        return rc;
+    }
+    *ticket = ((uint64_t)c->gen << 8) | (uint64_t)((c - h->ctx) + 1);
+    return CGV_OK;
+}
+
+int cgv_search_end(cgv_index* h, uint64_t ticket) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (ticket == 0) return CGV_OK;
+    const uint64_t slot = (ticket & 0xff);
+    if (slot == 0 || slot > (uint64_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "bad ticket");
+    SearchCtx* c = &h->ctx[slot - 1];
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!c->busy || c->gen != (uint32_t)(ticket >> 8)) return fail(CGV_ERR_INVALID_ARG, "stale ticket");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = search_finish(h, c);
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    release_ctx(h, c);
+    return rc;
+}
+
 int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint64_t* out_idx_dev,
                        float* out_score_dev) {
-    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    if (nq == 0 || k == 0) return CGV_OK;  // surreal_store.rs:62-64
-    if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
-    if (!queries_dev || !out_idx_dev || !out_score_dev) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
-    return search_dev_locked(h, queries_dev, nq, k, out_idx_dev, out_score_dev);
+    uint64_t t = 0;
+    int rc = cgv_search_begin_f32_dev(h, queries_dev, nq, k, out_idx_dev, out_score_dev, &t);
+    if (rc) return rc;
+    return cgv_search_end(h, t);
 }
 
 int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
                    float* out_score_host) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (nq == 0 || k == 0) return CGV_OK;
-    if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
-    if (!queries_host || !out_idx_host || !out_score_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
-    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = check_search_args(h, queries_host, k, out_idx_host, out_score_host);
+    if (rc) return rc;
+    std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
-    int rc;
-    if ((rc = h->qstage.ensure((size_t)nq * h->D * 4))) return rc;
-    if ((rc = h->outidx.ensure((size_t)nq * k * 8))) return rc;
-    if ((rc = h->outscore.ensure((size_t)nq * k * 4))) return rc;
-    HIPCHK(hipMemcpyAsync(h->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, h->stream));
-    if ((rc = search_dev_locked(h, h->qstage.as<float>(), nq, k, h->outidx.as<uint64_t>(), h->outscore.as<float>())))
-        return rc;
-    HIPCHK(hipMemcpyAsync(out_idx_host, h->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(out_score_host, h->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return CGV_OK;
+    SearchCtx* c = acquire_ctx(h, lk);
+    hipStream_t s = c->stream;
+    auto body = [&]() -> int {
+        int r;
+        if ((r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
+        if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
+        if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
+        if ((r = order_after_caller(h, c))) return r;
+        HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, s));
+        if ((r = search_enqueue(h, c, c->qstage.as<float>(), nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>())))
+            return r;
+        lk.unlock();
+        if ((r = search_finish(h, c))) return r;
+        HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out_score_host, c->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return CGV_OK;
+    };
+    rc = body();
+    if (lk.owns_lock()) lk.unlock();
+    if (rc) (void)hipStreamSynchronize(s);
+    release_ctx(h, c);
+    return rc;
 }
 
 int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
     if (!h || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    SearchCtx* c = &h->ctx[0];
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     HIPCHK(hipSetDevice(h->device));
     int rc;
-    if ((rc = h->qstage.ensure((size_t)h->D * 4))) return rc;
-    hipStream_t s = h->stream;
-    float* tmp = h->qstage.as<float>();
+    if ((rc = c->qstage.ensure((size_t)h->D * 4))) return rc;
+    hipStream_t s = c->stream;
+    if (int orc = order_after_caller(h, c)) return orc;
+    float* tmp = c->qstage.as<float>();
     if (h->dtype == CGV_DTYPE_F32)
         hipLaunchKernelGGL(gather_row_kernel<DT_F32>, dim3(1), dim3(256), 0, s, (const char*)h->rows, id, h->D, h->ld, (const int8_t*)h->rexp, tmp);
     else if (h->dtype == CGV_DTYPE_BF16)
@@ -821,19 +998,19 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
 
 // One query against the first `limit_rows` stored rows (0 = all): the reference's building blocks
 // evaluated on device with their exact f32 operation order.
-static int prep_single_query(cgv_index* h, const float* query_host, hipStream_t s) {
+static int prep_single_query(cgv_index* h, SearchCtx* c, const float* query_host, hipStream_t s) {
     int rc;
-    if ((rc = h->qstage.ensure((size_t)h->D * 4))) return rc;
-    if ((rc = h->qrows.ensure(storage_bytes(h, 1)))) return rc;
-    if ((rc = h->qnorm.ensure(4))) return rc;
-    if ((rc = h->qinvn.ensure(4))) return rc;
-    if ((rc = h->qrexp.ensure(16))) return rc;
-    if ((rc = h->qlist.ensure(4))) return rc;
-    HIPCHK(hipMemcpyAsync(h->qstage.p, query_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
-    HIPCHK(hipMemsetAsync(h->qlist.p, 0, 4, s));
-    return prep_dispatch(h->dtype, h->qstage.as<float>(), 1, h->D, h->ld, 0, h->qrows.as<char>(),
-                         h->qnorm.as<float>(), h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
+    if ((rc = c->qstage.ensure((size_t)h->D * 4))) return rc;
+    if ((rc = c->qrows.ensure(storage_bytes(h, 1)))) return rc;
+    if ((rc = c->qnorm.ensure(4))) return rc;
+    if ((rc = c->qinvn.ensure(4))) return rc;
+    if ((rc = c->qrexp.ensure(16))) return rc;
+    if ((rc = c->qlist.ensure(4))) return rc;
+    HIPCHK(hipMemcpyAsync(c->qstage.p, query_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
+    HIPCHK(hipMemsetAsync(c->qlist.p, 0, 4, s));
+    return prep_dispatch(h->dtype, c->qstage.as<float>(), 1, h->D, h->ld, 0, c->qrows.as<char>(),
+                         c->qnorm.as<float>(), c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s);
 }
 
 int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host) {
@@ -841,22 +1018,25 @@ int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint
     if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
     if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    SearchCtx* c = &h->ctx[0];
     HIPCHK(hipSetDevice(h->device));
     const uint64_t n = limit_rows ? std::min<uint64_t>(limit_rows, h->n) : h->n;
     if (n == 0) return CGV_OK;
-    hipStream_t s = h->stream;
+    hipStream_t s = c->stream;
+    if (int orc = order_after_caller(h, c)) return orc;
     int rc;
-    if ((rc = prep_single_query(h, query_host, s))) return rc;
-    if ((rc = h->scores.ensure((size_t)h->n * 4))) return rc;
+    if ((rc = prep_single_query(h, c, query_host, s))) return rc;
+    if ((rc = c->scores.ensure((size_t)h->n * 4))) return rc;
     switch (h->dtype) {
-        case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
-        case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
-        case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
-        default: launch_exact_scores<DT_FP16>(h, h->qlist.as<uint32_t>(), 1, h->scores.as<float>(), op, s); break;
+        case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, c, c->qlist.as<uint32_t>(), 1, c->scores.as<float>(), op, s); break;
+        case CGV_DTYPE_BF16: launch_exact_scores<DT_BF16>(h, c, c->qlist.as<uint32_t>(), 1, c->scores.as<float>(), op, s); break;
+        case CGV_DTYPE_FP8E4M3: launch_exact_scores<DT_FP8>(h, c, c->qlist.as<uint32_t>(), 1, c->scores.as<float>(), op, s); break;
+        default: launch_exact_scores<DT_FP16>(h, c, c->qlist.as<uint32_t>(), 1, c->scores.as<float>(), op, s); break;
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_host, h->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_host, c->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;
 }
@@ -866,21 +1046,24 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
     if (!h || !query_host || !out_idx_host || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     *out_n = 0;
     if (limit > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "limit exceeds CGV_MAX_K");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    SearchCtx* c = &h->ctx[0];
     if (h->n == 0 || limit == 0) return CGV_OK;  // optimization.rs:382-384
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
+    hipStream_t s = c->stream;
+    if (int orc = order_after_caller(h, c)) return orc;
     int rc;
-    if ((rc = prep_single_query(h, query_host, s))) return rc;
-    if ((rc = h->outidx.ensure((size_t)limit * 8))) return rc;
-    if ((rc = h->outscore.ensure((size_t)limit * 4))) return rc;
+    if ((rc = prep_single_query(h, c, query_host, s))) return rc;
+    if ((rc = c->outidx.ensure((size_t)limit * 8))) return rc;
+    if ((rc = c->outscore.ensure((size_t)limit * 4))) return rc;
     // ascending distance, stable (ties keep index order) == descending (-distance, index asc)
-    if ((rc = exact_search(h, h->qlist.as<uint32_t>(), 1, limit, h->outidx.as<uint64_t>(), h->outscore.as<float>(), s,
+    if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), 1, limit, c->outidx.as<uint64_t>(), c->outscore.as<float>(), s,
                            OP_NEG_COSINE_DISTANCE_SEQ)))
         return rc;
     std::vector<float> sc(limit);
-    HIPCHK(hipMemcpyAsync(out_idx_host, h->outidx.p, (size_t)limit * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(sc.data(), h->outscore.p, (size_t)limit * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)limit * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sc.data(), c->outscore.p, (size_t)limit * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     uint32_t m = 0;
     while (m < limit && out_idx_host[m] != UINT64_MAX) ++m;
@@ -942,6 +1125,7 @@ int cgv_synchronize(cgv_index* h) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (SearchCtx& c : h->ctx) HIPCHK(hipStreamSynchronize(c.stream));
     return CGV_OK;
 }
 
@@ -971,37 +1155,40 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     if (!h || !queries_dev || !out_dev) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     if (h->dtype == CGV_DTYPE_F32) return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16/fp8 index");
     if (nq == 0 || h->n == 0) return CGV_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    SearchCtx* c = &h->ctx[0];
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
+    hipStream_t s = c->stream;
+    if (int orc = order_after_caller(h, c)) return orc;
     int rc;
-    if ((rc = h->qrows.ensure(storage_bytes(h, nq)))) return rc;
-    if ((rc = h->qnorm.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->qinvn.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->qrexp.ensure((size_t)nq + 16))) return rc;
-    if ((rc = h->tau.ensure((size_t)nq * 4))) return rc;
-    if ((rc = h->overflow.ensure((size_t)nq * 4))) return rc;
-    rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, h->qrows.as<char>(), h->qnorm.as<float>(),
-                       h->qinvn.as<float>(), h->qrexp.as<int8_t>(), h->flags + F_NONFINITE_Q, s);
+    if ((rc = c->qrows.ensure(storage_bytes(h, nq)))) return rc;
+    if ((rc = c->qnorm.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->qinvn.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->qrexp.ensure((size_t)nq + 16))) return rc;
+    if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
+    if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
+    rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, c->qrows.as<char>(), c->qnorm.as<float>(),
+                       c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
     const uint32_t nqt = (nq + BN - 1) / BN;
     const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
     const uint32_t ntiles = (uint32_t)((h->n + BM - 1) / BM);
     const uint32_t nsplit = std::min(ntiles, nsplit_max);
-    if ((rc = h->cand.ensure((size_t)nqt * nsplit * BN * CAND_CAPS * 8))) return rc;
-    if ((rc = h->candcnt.ensure((size_t)nqt * nsplit * BN * 4))) return rc;
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, h->tau.as<float>(), -INFINITY, nq);
+    if ((rc = c->cand.ensure((size_t)nqt * nsplit * BN * CAND_CAPS * 8))) return rc;
+    if ((rc = c->candcnt.ensure((size_t)nqt * nsplit * BN * 4))) return rc;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->tau.as<float>(), -INFINITY, nq);
     CoarseArgs a;
     a.rows = h->rows;
-    a.qrows = h->qrows.as<char>();
+    a.qrows = c->qrows.as<char>();
     a.invn_c = h->invn;
-    a.invn_q = h->qinvn.as<float>();
+    a.invn_q = c->qinvn.as<float>();
     a.blk_min = h->blk_min;
     a.blk_max = h->blk_max;
-    a.tau = h->tau.as<float>();
-    a.cand = h->cand.as<uint2>();
-    a.cand_cnt = h->candcnt.as<uint32_t>();
-    a.overflow = h->overflow.as<uint32_t>();
+    a.tau = c->tau.as<float>();
+    a.cand = c->cand.as<uint2>();
+    a.cand_cnt = c->candcnt.as<uint32_t>();
+    a.overflow = c->overflow.as<uint32_t>();
     a.dump = out_dev;
     a.n = (uint32_t)h->n;
     a.nq = nq;

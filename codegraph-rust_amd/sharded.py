@@ -36,7 +36,21 @@ class ShardedKnn:
         self.merge = merge
 
     def search(self, queries, k):
-        idx, score = self.local.search(queries, k)
+        return self._exchange(*self.local.search(queries, k), k)
+
+    def search_begin(self, queries, k):
+        """Pipelined form: the local shard search is enqueued now; wait() completes it, then runs
+        the all-gather + merge. With two batches in flight the exchange of batch i overlaps the
+        shard search of batch i+1 (which runs on its own stream inside the index)."""
+        pending = self.local.search_begin(queries, k)
+        outer = self
+
+        class _Pending:
+            def wait(self_inner):
+                return outer._exchange(*pending.wait(), k)
+        return _Pending()
+
+    def _exchange(self, idx, score, k):
         if self.world == 1:
             return idx, score
         nq = idx.shape[0]

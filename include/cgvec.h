@@ -121,6 +121,18 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
 int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
                        uint64_t* out_idx_dev, float* out_score_dev);
 
+/* Split form of cgv_search_f32_dev for callers that keep several batches in flight (the handle
+ * owns a small pool of search contexts, each with its own HIP stream and scratch — SURVEY.md §8(b)
+ * "internal stream pool"): begin enqueues the whole batch behind whatever the caller has queued on
+ * the handle's stream (cgv_set_stream) and returns a ticket without waiting for the device; end
+ * waits for that batch, runs the exact path for any query whose guarantee check failed, and
+ * releases the context. queries / outputs must stay valid and untouched until end returns.
+ * begin blocks while all contexts are in flight. ticket 0 (nq == 0 or k == 0) needs no end.
+ * cgv_search_f32_dev == begin + end; concurrent callers on one handle overlap the same way. */
+int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
+                             uint64_t* out_idx_dev, float* out_score_dev, uint64_t* ticket);
+int cgv_search_end(cgv_index* h, uint64_t ticket);
+
 /* Copy stored row `id` (local id, without index_base) back as f32 (upcast of the
  * stored value). Replaces VectorStore::get_embedding (traits.rs:15) /
  * SurrealVectorBackend::get_node_embedding (surreal_store.rs:21). */

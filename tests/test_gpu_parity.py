@@ -387,3 +387,63 @@ def test_normalize_rows_on_device(oracle):
         rows = (rng.standard_normal((50, d)) * 3).astype(np.float32)
         rows[4] = 0.0
         assert np.array_equal(m.cgvec.normalize_rows(rows), oracle.normalize_rows(rows)), d
+
+
+def test_batches_in_flight_and_concurrent_callers(oracle):
+    """cgv_search_begin/_end: more batches begun than the pool holds contexts (begin blocks until a
+    context frees up from another thread's end), different nq / k per batch, results equal to the
+    oracle; a writer (add) issued while searches are in flight waits for them; SURVEY.md §8(b)
+    threading: concurrent callers on one handle."""
+    import threading
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(91)
+    rows, d = _unit(rng, 40_000, 128), 128
+    batches = [(_unit(rng, nq, d), k) for nq, k in ((300, 10), (17, 30), (1, 10), (513, 5), (64, 10), (256, 16))]
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows[:30_000])
+        ix.add(rows[30_000:])
+        refs = [oracle.batch_top_k(q, rows, k, dtype=1) for q, k in batches]
+        # (1) pipelined on one thread, two in flight
+        pend, outs = [], []
+        for q, k in batches:
+            pend.append(ix.search_begin(torch.from_numpy(q).cuda(), k))
+            if len(pend) == 2:
+                outs.append(pend.pop(0).wait())
+        outs += [p.wait() for p in pend]
+        for (gi, gs), (ri, rs) in zip(outs, refs):
+            assert np.array_equal(gi.cpu().numpy().view(np.uint64), ri) and np.array_equal(gs.cpu().numpy(), rs)
+        # (2) concurrent callers, each with its own torch stream
+        errs, res = [], [None] * len(batches)
+
+        def worker(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    q, k = batches[i]
+                    for _ in range(3):
+                        gi, gs = ix.search(torch.from_numpy(q).cuda(), k)
+                    res[i] = (gi.cpu().numpy().view(np.uint64), gs.cpu().numpy())
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(len(batches))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for (gi, gs), (ri, rs) in zip(res, refs):
+            assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+        # (3) a writer while a batch is in flight: the add must wait, the batch sees the old corpus
+        q, k = batches[0]
+        p = ix.search_begin(torch.from_numpy(q).cuda(), k)
+        extra = _unit(rng, 500, d)
+        t = threading.Thread(target=lambda: ix.add(extra))
+        t.start()
+        gi, gs = p.wait()
+        t.join()
+        assert np.array_equal(gi.cpu().numpy().view(np.uint64), refs[0][0])
+        assert len(ix) == 40_500
+        gi2, gs2 = ix.search(q, k)
+        ri2, rs2 = oracle.batch_top_k(q, np.vstack([rows, extra]), k, dtype=1)
+        assert np.array_equal(gi2, ri2) and np.array_equal(gs2, rs2)
+    finally:
+        ix.close()
