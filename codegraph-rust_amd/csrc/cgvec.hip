@@ -275,7 +275,8 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
 
 template <int DT, bool DUMP>
 int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128 + (size_t)BN * 4 + 2 * 256 * 4 + 2 * 16 * 4;
+    // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
+    constexpr size_t lds = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
     static bool attr_set = false;
     auto kern = coarse_kernel<DT, DUMP>;
     if (!attr_set) {
@@ -744,7 +745,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     cgv_index* h = new cgv_index();
     h->device = device_id;
     h->D = dim;
-    const uint32_t kch = kchunk_of(dtype);  // elements per 128-byte row chunk
+    const uint32_t kch = kchunk_of(dtype);  // elements per 64-byte row chunk
     h->ld = (dim + kch - 1) / kch * kch;
     h->metric = metric;
     h->dtype = dtype;

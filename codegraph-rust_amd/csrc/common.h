@@ -107,27 +107,28 @@ __host__ __device__ inline int fp8_row_exponent(float amax) {
 
 // ---- storage layouts ---------------------------------------------------------------
 // f32 corpora: plain row-major [rows][ld] (exact path only; the reference's own layout).
-// bf16/fp16 corpora: BLOCKED layout "B64", the unit the coarse kernel streams:
-//   rows are grouped in tiles of 256; K in chunks of 64 elements (128 B); block (tile t,
-//   chunk kc) is 32 KiB contiguous at byte ((t*KC + kc) << 15), KC = ld/64. Inside a block, row r
-//   (0..255) owns 128 B at r*128 and its 16-byte slot p holds elements 8c..8c+7 of the
-//   chunk with c = p ^ ((r>>1)&7). That is byte-for-byte the LDS image the MFMA kernel
-//   wants (bank-conflict-free ds_read_b128), so the global->LDS DMA is a linear 1-KiB copy
-//   per wave instruction: measured 64 KB / 1.05 us per CU vs 1.98 us for 128-B pieces at a
-//   1536-B row pitch (scripts/ubench/dma_ring.hip, dma_bw.hip).
-// (fp8: 1-byte elements, so a 128-byte row chunk holds 128 elements and KC = ld/128.)
-constexpr uint32_t TILE_ROWS = 256, BLOCK_BYTES = TILE_ROWS * 128;
+// bf16/fp16/fp8 corpora: BLOCKED layout "B32", the unit the coarse kernel streams:
+//   rows are grouped in tiles of 256; K in chunks of 64 BYTES (32 two-byte elements, 64 fp8
+//   codes); block (tile t, chunk kc) is 16 KiB contiguous at byte ((t*KC + kc) << 14),
+//   KC = ld*esize/64. Inside a block, row r (0..255) owns 64 B at r*64 and its 16-byte slot p
+//   holds piece c = p ^ ((r>>2)&3) of the chunk. That is byte-for-byte the LDS image of one
+//   pipeline stage of the MFMA kernel (bank-conflict-free ds_read_b128: the 16 lanes of a
+//   read group touch 16 distinct 16-byte bank quads), so the global->LDS DMA is a linear
+//   1-KiB copy per wave instruction: contiguous blocks move at ~60 GB/s/CU, row pieces at a
+//   1536-B pitch at ~33 (scripts/ubench/dma_ring.hip, dma_bw.hip).
+constexpr uint32_t TILE_ROWS = 256, CHUNK_BYTES = 64, BLOCK_BYTES = TILE_ROWS * CHUNK_BYTES;
 
-__host__ __device__ inline constexpr uint32_t kchunk_of(int dt) { return dt == DT_FP8 ? 128u : 64u; }
+// elements per 64-byte row chunk
+__host__ __device__ inline constexpr uint32_t kchunk_of(int dt) { return dt == DT_FP8 ? 64u : 32u; }
 
-// byte offset of 16-byte piece pc (= elements of one 128-B chunk slot) of a row, relative to its base
+// byte offset of 16-byte piece pc of a row (pieces numbered along K), relative to the row's base
 __host__ __device__ inline uint64_t blocked_piece_off(uint32_t pc, uint32_t key) {
-    return (uint64_t)(pc >> 3) * BLOCK_BYTES + (((pc & 7u) ^ key) << 4);
+    return (uint64_t)(pc >> 2) * BLOCK_BYTES + (((pc & 3u) ^ key) << 4);
 }
 __host__ __device__ inline uint64_t blocked_row_base(uint64_t R, uint32_t ld, uint32_t kchunk) {
-    return ((R >> 8) * (uint64_t)(ld / kchunk)) * BLOCK_BYTES + (R & 255u) * 128u;
+    return ((R >> 8) * (uint64_t)(ld / kchunk)) * BLOCK_BYTES + (R & 255u) * CHUNK_BYTES;
 }
-__host__ __device__ inline uint32_t blocked_row_key(uint64_t R) { return (uint32_t)((R & 255u) >> 1) & 7u; }
+__host__ __device__ inline uint32_t blocked_row_key(uint64_t R) { return (uint32_t)((R & 255u) >> 2) & 3u; }
 
 template <int DT>
 struct Elem;

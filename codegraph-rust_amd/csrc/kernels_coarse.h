@@ -14,7 +14,7 @@
 //   * workgroup = 256 x 256 output tile, 8 waves as 2(M) x 4(N), each wave 128 x 64 =
 //     4 x 2 blocks of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs); K streamed in
 //     64-element chunks through two 64-KiB LDS stages by global_load_lds_dwordx4;
-//   * both operands live in HBM in the BLOCKED layout B64 (common.h): a (tile, chunk)
+//   * both operands live in HBM in the BLOCKED layout B32 (common.h): a (tile, chunk)
 //     block is 32 KiB contiguous and byte-identical to its LDS image (XOR-swizzled so that
 //     ds_read_b128 fragment reads are bank-conflict-free), so every DMA instruction is a
 //     linear 1-KiB copy. The kernel is bound by the L2->LDS path (64 KB per chunk per CU):
@@ -75,8 +75,8 @@ struct Mfma<DT_FP8> {
 constexpr uint32_t CAND_CAPS = 256;  // entries per (workgroup, query) candidate list
 
 struct CoarseArgs {
-    const char* rows;       // corpus, blocked layout B64 (128-byte row chunks), zero padded
-    const char* qrows;      // queries, blocked layout B64
+    const char* rows;       // corpus, blocked layout B32 (64-byte row chunks), zero padded
+    const char* qrows;      // queries, blocked layout B32
     const float* invn_c;    // [n]
     const float* invn_q;    // [nq]
     const float* blk_min;   // [ceil(n/32)] min row norm per 32-row block
@@ -210,14 +210,14 @@ template <int DT, bool DUMP>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NW = 8, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
-    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    constexpr int LA = BM / (8 * NW), LB = BN / (8 * NW);  // 4 + 4 DMA instructions per wave per chunk
+    constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;  // one stage = one 64-byte K chunk of A and B
+    constexpr int NSTAGE = 4, NINV = 8;                       // stage ring; per-tile side-data ring
     typedef typename Mfma<DT>::frag frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t* cntq = (uint32_t*)(smem + 2 * STAGE);
-    float* invn_s = (float*)(smem + 2 * STAGE + BN * 4);  // [2][256], by tile parity
-    float* stat_s = invn_s + 2 * 256;                      // [2][16]: 8 block-min + 8 block-max norms
+    uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
+    float* invn_s = (float*)(smem + NSTAGE * STAGE + BN * 4);  // [NINV][256], by tile sequence number
+    float* stat_s = invn_s + NINV * 256;                        // [NINV][16]: 8 block-min + 8 block-max norms
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -248,58 +248,66 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     const uint32_t jlo = (uint32_t)(((uint64_t)split * a.cnt) / a.nsplit);
     const uint32_t jhi = (uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit);
     const uint32_t KC = a.kc;
-    const uint32_t total = (jhi - jlo) * KC;
+    const uint32_t total = (jhi - jlo) * KC;  // pipeline stages of this workgroup
 
-    // DMA sources (blocked layout): block (tile, kc) is 32 KiB contiguous; this wave copies its
-    // 4 KiB slab (rows 32w..32w+31) of the A block and of the B block, 1 KiB per instruction.
-    const uint32_t slab = (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
-    const char* bq = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES + slab;  // + kc * 32 KiB
-    const char* atile = a.rows + slab;                                  // + (tile*KC + kc) * 32 KiB
-    uint32_t lj = 0, lkc = 0, issued = 0, ltile = 0;
-    const char* acur = atile;
-    auto set_tile = [&](uint32_t j) {
-        ltile = stage_tile(a.T1, a.R, a.P, a.j0 + jlo + j);
-        acur = atile + (uint64_t)ltile * KC * BLOCK_BYTES;
+    // Tile sequence (stage_tile): t_{j+1} = t_j + P (mod R), kept incrementally on the issue side
+    // (lt) and on the consume side (ct) - the 64-bit modulo is paid once per kernel, not per tile.
+    const uint32_t t_first = (total > 0) ? stage_tile(a.T1, a.R, a.P, a.j0 + jlo) - a.T1 : 0u;
+    auto next_tile = [&](uint32_t t) {
+        const uint32_t u = t + a.P;  // P < R <= 2^24 tiles: no overflow
+        return u >= a.R ? u - a.R : u;
     };
-    if (total > 0) set_tile(0);
-    // DMA of chunk `issued`, split in two halves so the caller can interleave them with MFMAs.
-    auto issue_half = [&](int half) {
-        const int buf = (int)(issued & 1u);
+
+    // DMA sources (blocked layout): block (tile, kc) is 16 KiB contiguous; this wave copies KiB
+    // 2w and 2w+1 (rows 32w..32w+31) of the A block and of the B block, 1 KiB per instruction.
+    const uint32_t slab = (uint32_t)wave * 2048u + (uint32_t)lane * 16u;
+    const char* bq = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES + slab;  // + kc * 16 KiB
+    const char* atile = a.rows + slab;                                  // + (tile*KC + kc) * 16 KiB
+    uint32_t lj = 0, lkc = 0, issued = 0, lt = t_first;
+    const char* acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+    // One stage = 4 DMA instructions per wave (A0 A1 B0 B1), issued one at a time so the caller
+    // can spread them between MFMAs: a steady one-per-few-MFMAs stream instead of a burst that
+    // fills the address queue and stalls the wave (and with it the MFMAs behind it).
+    // The stream never ends: past the last stage it re-reads the last stage into the (free) ring
+    // slot, so the loop body needs no "is there a next stage" branches and the counted
+    // s_waitcnt vmcnt(8) below is valid in every iteration (<= 3 x 32 KiB of extra L2 reads).
+    auto issue_q = [&](int q) {
+        char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
         const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
-        if (half == 0) {
-            char* dA = smem + buf * STAGE + wave * 4096;
-#pragma unroll
-            for (int jj = 0; jj < LA; ++jj) glds16(acur + koff + jj * 1024, dA + jj * 1024);
-        } else {
-            char* dB = smem + buf * STAGE + A_BYTES + wave * 4096;
-#pragma unroll
-            for (int jj = 0; jj < LB; ++jj) glds16(bq + koff + jj * 1024, dB + jj * 1024);
-            if (lkc == 0 && wave == 0)  // the tile's 256 inverse norms ride along with its first chunk
-                glds16((const char*)a.invn_c + (uint64_t)ltile * 1024 + lane * 16, (char*)(invn_s + (lj & 1u) * 256));
-            if (lkc == 0 && wave == 1 && lane < 4) {  // and its 8 + 8 per-32-row-block norm bounds (4 lanes x 16 B)
-                const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)ltile * 8 + (lane & 1) * 4;
-                glds16((const char*)sp, (char*)(stat_s + (lj & 1u) * 16));
+        if (q == 0) {
+            if (lkc == 0 && issued < total) {
+                if (wave == 0)  // the tile's 256 inverse norms ride along with its first stage
+                    glds16((const char*)a.invn_c + (uint64_t)(a.T1 + lt) * 1024 + lane * 16,
+                           (char*)(invn_s + (lj & (NINV - 1)) * 256));
+                if (wave == 1 && lane < 4) {  // and its 8 + 8 per-32-row-block norm bounds
+                    const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + lt) * 8 + (lane & 1) * 4;
+                    glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
+                }
             }
+            glds16(acur + koff, dst);
+        } else if (q == 1) {
+            glds16(acur + koff + 1024, dst + 1024);
+        } else if (q == 2) {
+            glds16(bq + koff, dst + A_BYTES);
+        } else {
+            glds16(bq + koff + 1024, dst + A_BYTES + 1024);
             ++issued;
-            if (++lkc == KC) {
+            if (issued < total && ++lkc == KC) {
                 lkc = 0;
                 ++lj;
-                if (issued < total) set_tile(lj);
+                lt = next_tile(lt);
+                acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
             }
         }
     };
-    auto issue_next = [&]() {
-        issue_half(0);
-        issue_half(1);
-    };
 
-    // fragment read offsets (bytes): row r = base32 + (lane&31), chunk c = 2*kk + (lane>>5),
-    // stored at slot c ^ ((r>>1)&7)
-    uint32_t xo[4];
+    // fragment read offsets (bytes): row r = base32 + (lane&31); the lane's piece of k-step kk
+    // (0/1 within the stage) is c = 2*kk + (lane>>5), stored at slot c ^ ((r>>2)&3)
+    uint32_t xo[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xo[kk] = (uint32_t)((((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7))) << 4);
-    const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 128;
-    const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 128;
+    for (int kk = 0; kk < 2; ++kk) xo[kk] = (uint32_t)((((2 * kk + (lane >> 5)) ^ ((lane >> 2) & 3))) << 4);
+    const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 64;
+    const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 64;
 
     f32x16_t acc[MB][NB];
 #pragma unroll
@@ -309,112 +317,142 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-    f32x16_t zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
     frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
 #define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                         \
     {                                                                                            \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) FA[mb] =                               \
-            *(const frag*)((BASE) + aoff + mb * 32 * 128 + xo[KK]);                              \
+            *(const frag*)((BASE) + aoff + mb * 32 * 64 + xo[KK]);                               \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) FB[nb] =                               \
-            *(const frag*)((BASE) + boff + nb * 32 * 128 + xo[KK]);                              \
+            *(const frag*)((BASE) + boff + nb * 32 * 64 + xo[KK]);                               \
     }
-#define CGV_MMA_FIRST(FA, FB) \
+#define CGV_SB __builtin_amdgcn_sched_barrier(0)
+// the 8 MFMAs of one k-step in four groups (1 + 3 + 2 + 2) so that fragment loads and DMA issue
+// can be pinned between them
+#define CGV_MMA_G0(FA, FB) \
     { acc[0][0] = Mfma<DT>::mma(FA[0], FB[0], acc[0][0]); }
-#define CGV_MMA_REST(FA, FB)                                                                     \
-    {                                                                                            \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) \
-            if (mb + nb > 0) acc[mb][nb] = Mfma<DT>::mma(FA[mb], FB[nb], acc[mb][nb]);           \
+#define CGV_MMA_G1(FA, FB)                                      \
+    {                                                           \
+        acc[0][1] = Mfma<DT>::mma(FA[0], FB[1], acc[0][1]);     \
+        acc[1][0] = Mfma<DT>::mma(FA[1], FB[0], acc[1][0]);     \
+        acc[1][1] = Mfma<DT>::mma(FA[1], FB[1], acc[1][1]);     \
     }
-// first k-step of a tile: C operand = 0 (an inline constant in the MFMA encoding) instead of
-// 128 v_mov per wave per tile to clear the accumulators
-#define CGV_MMA_FIRST_Z(FA, FB) \
-    { acc[0][0] = Mfma<DT>::mma(FA[0], FB[0], zero16); }
-#define CGV_MMA_REST_Z(FA, FB)                                                                   \
-    {                                                                                            \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) \
-            if (mb + nb > 0) acc[mb][nb] = Mfma<DT>::mma(FA[mb], FB[nb], zero16);                \
+#define CGV_MMA_G2(FA, FB)                                      \
+    {                                                           \
+        acc[2][0] = Mfma<DT>::mma(FA[2], FB[0], acc[2][0]);     \
+        acc[2][1] = Mfma<DT>::mma(FA[2], FB[1], acc[2][1]);     \
     }
-// One k-step: hipcc's waitcnt pass emits lgkmcnt(0) (not a counted wait) in front of the first
-// MFMA that consumes fragments, so the next step's ds_reads are issued right AFTER that first
-// MFMA: they then have the remaining 7 MFMAs (224 matrix-pipe cycles) to land.
-#define CGV_STEP(FA, FB, NEXT_LOADS)              \
-    {                                             \
-        CGV_MMA_FIRST(FA, FB);                    \
-        __builtin_amdgcn_sched_barrier(0);        \
-        NEXT_LOADS;                               \
-        __builtin_amdgcn_sched_barrier(0);        \
-        CGV_MMA_REST(FA, FB);                     \
-        __builtin_amdgcn_sched_barrier(0);        \
+#define CGV_MMA_G3(FA, FB)                                      \
+    {                                                           \
+        acc[3][0] = Mfma<DT>::mma(FA[3], FB[0], acc[3][0]);     \
+        acc[3][1] = Mfma<DT>::mma(FA[3], FB[1], acc[3][1]);     \
     }
 
-    if (total > 0) issue_next();
-    if (total > 1) issue_next();
-    if (issued == 2)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk 0 landed, chunk 1 (8 DMA instr) in flight
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: three stages in flight --------------------------------------------
+    if (total == 0) {  // uniform: nothing to stream for this workgroup
+        for (int i = tid; i < BN; i += NT) a.cand_cnt[(uint64_t)g * BN + i] = 0;
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < NSTAGE - 1; ++i) {
+        issue_q(0);
+        issue_q(1);
+        issue_q(2);
+        issue_q(3);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // stage 0 landed; stages 1, 2 may be in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
     __builtin_amdgcn_s_barrier();
-    if (total > 0) CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
+    CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
 
-    uint32_t cj = 0, ckc = 0;
-    for (uint32_t it = 0; it < total; ++it) {
-        const char* sb = smem + (it & 1u) * STAGE;
-        const char* sn = smem + ((it + 1) & 1u) * STAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        if (ckc == 0) {  // kk = 0 of a new tile: accumulate from zero
-            CGV_MMA_FIRST_Z(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            CGV_LOAD_FRAGS(fa1, fb1, sb, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            CGV_MMA_REST_Z(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            CGV_STEP(fa0, fb0, CGV_LOAD_FRAGS(fa1, fb1, sb, 1));  // kk = 0
-        }
-        CGV_STEP(fa1, fb1, CGV_LOAD_FRAGS(fa0, fb0, sb, 2));  // kk = 1
-        CGV_STEP(fa0, fb0, CGV_LOAD_FRAGS(fa1, fb1, sb, 3));  // kk = 2
-        // chunk it+1 landed (this wave's DMA) + all my reads of chunk it done -> barrier
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        CGV_MMA_FIRST(fa1, fb1);  // kk = 3
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < total) CGV_LOAD_FRAGS(fa0, fb0, sn, 0);  // first fragments of chunk it+1
-        __builtin_amdgcn_sched_barrier(0);
-        // chunk it+2 -> the buffer chunk it used; its 8 DMA instructions are spread over the
-        // shadows of this step's MFMAs instead of stalling the matrix pipe in one burst
-        const bool more = issued < total;
-        acc[0][1] = Mfma<DT>::mma(fa1[0], fb1[1], acc[0][1]);
-        acc[1][0] = Mfma<DT>::mma(fa1[1], fb1[0], acc[1][0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) issue_half(0);
-        __builtin_amdgcn_sched_barrier(0);
-        acc[1][1] = Mfma<DT>::mma(fa1[1], fb1[1], acc[1][1]);
-        acc[2][0] = Mfma<DT>::mma(fa1[2], fb1[0], acc[2][0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) issue_half(1);
-        __builtin_amdgcn_sched_barrier(0);
-        acc[2][1] = Mfma<DT>::mma(fa1[2], fb1[1], acc[2][1]);
-        acc[3][0] = Mfma<DT>::mma(fa1[3], fb1[0], acc[3][0]);
-        acc[3][1] = Mfma<DT>::mma(fa1[3], fb1[1], acc[3][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ckc == KC - 1)
-            tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, stage_tile(a.T1, a.R, a.P, a.j0 + jlo + cj), wm,
-                                                          wn, lane, g, qt, tq, tauv, invq, cntq,
-                                                          invn_s + (cj & 1u) * 256, stat_s + (cj & 1u) * 16);
-        if (++ckc == KC) {
-            ckc = 0;
-            ++cj;
-        }
+    // Stage s holds k-steps (s,0) [fragments fa0/fb0] and (s,1) [fa1/fb1]. Iteration s runs the
+    // MFMAs of (s-1,1) then of (s,0); the single barrier of the iteration sits after the first MFMA
+    // of (s-1,1): by then every wave has all its reads of stage s-1 back (lgkmcnt(0) in front of
+    // that MFMA), so slot (s-1)&3 is free for the DMA of stage s+3, and each wave has waited for
+    // its own share of stage s (counted vmcnt: the 8 younger DMA instructions are stages s+1,
+    // s+2), so stage s may be read. DMA lead: 3 stages. All MFMAs are unconditional (no
+    // accumulator phis for the register allocator to copy around).
+#define CGV_A_PHASE(SB)                      \
+    {                                        \
+        CGV_SB;                              \
+        CGV_MMA_G0(fa0, fb0);                \
+        CGV_SB;                              \
+        CGV_LOAD_FRAGS(fa1, fb1, SB, 1);     \
+        CGV_SB;                              \
+        CGV_MMA_G1(fa0, fb0);                \
+        CGV_SB;                              \
+        issue_q(2);                          \
+        CGV_SB;                              \
+        CGV_MMA_G2(fa0, fb0);                \
+        CGV_SB;                              \
+        issue_q(3);                          \
+        CGV_SB;                              \
+        CGV_MMA_G3(fa0, fb0);                \
+        CGV_SB;                              \
     }
-#undef CGV_STEP
-#undef CGV_MMA_FIRST
-#undef CGV_MMA_REST
-#undef CGV_MMA_FIRST_Z
-#undef CGV_MMA_REST_Z
+#define CGV_EPILOGUE()                                                                                         \
+    {                                                                                                          \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
+                                                      invn_s + (pj & (NINV - 1)) * 256,                        \
+                                                      stat_s + (pj & (NINV - 1)) * 16);                        \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)    \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;                              \
+    }
+#define CGV_ADVANCE()            \
+    if (++ckc == KC) {           \
+        ckc = 0;                 \
+        ptile = a.T1 + ct;       \
+        pj = cj;                 \
+        ++cj;                    \
+        ct = next_tile(ct);      \
+    }
+
+    uint32_t cj = 0, ckc = 0, ct = t_first, ptile = 0, pj = 0;
+    issue_q(0);  // stage 3 -> slot 3 (never used so far)
+    issue_q(1);
+    CGV_A_PHASE(smem);
+    CGV_ADVANCE();
+#pragma unroll 1
+    for (uint32_t s = 1; s < total; ++s) {
+        const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+        CGV_SB;
+        CGV_MMA_G0(fa1, fb1);
+        CGV_SB;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        CGV_SB;
+        CGV_LOAD_FRAGS(fa0, fb0, sb, 0);
+        CGV_SB;
+        CGV_MMA_G1(fa1, fb1);
+        CGV_SB;
+        issue_q(0);
+        CGV_SB;
+        CGV_MMA_G2(fa1, fb1);
+        CGV_SB;
+        issue_q(1);
+        CGV_SB;
+        CGV_MMA_G3(fa1, fb1);
+        CGV_SB;
+        if (ckc == 0) CGV_EPILOGUE();  // (s-1,1) was the last k-step of tile ptile
+        CGV_A_PHASE(sb);
+        CGV_ADVANCE();
+    }
+    // tail: (total-1, 1), then the last tile's epilogue
+    CGV_SB;
+    CGV_MMA_G0(fa1, fb1);
+    CGV_MMA_G1(fa1, fb1);
+    CGV_MMA_G2(fa1, fb1);
+    CGV_MMA_G3(fa1, fb1);
+    CGV_SB;
+    CGV_EPILOGUE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail before the LDS is released
+#undef CGV_A_PHASE
+#undef CGV_EPILOGUE
+#undef CGV_ADVANCE
+#undef CGV_SB
+#undef CGV_MMA_G0
+#undef CGV_MMA_G1
+#undef CGV_MMA_G2
+#undef CGV_MMA_G3
 #undef CGV_LOAD_FRAGS
 
     __syncthreads();
@@ -467,11 +505,9 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
     const uint32_t ks = ld * Elem<DT>::bytes / 32;  // pairs of 16-byte pieces per row
 #pragma unroll 4
     for (uint32_t k = 0; k < ks; ++k) {
-        // this lane's 16-byte piece 2k + hi = slot (2k + hi) & 7 of 128-byte row chunk k >> 2
-        const uint64_t blk = (uint64_t)(k >> 2) * BLOCK_BYTES;
-        const uint32_t c = (2 * k + hi) & 7u;
-        frag a0 = *(const frag*)(ap[0] + blk + ((c ^ akey[0]) << 4)), a1 = *(const frag*)(ap[1] + blk + ((c ^ akey[1]) << 4));
-        frag b0 = *(const frag*)(bp[0] + blk + ((c ^ bkey[0]) << 4)), b1 = *(const frag*)(bp[1] + blk + ((c ^ bkey[1]) << 4));
+        const uint32_t pc = 2 * k + hi;  // this lane's 16-byte piece of k-step k
+        frag a0 = *(const frag*)(ap[0] + blocked_piece_off(pc, akey[0])), a1 = *(const frag*)(ap[1] + blocked_piece_off(pc, akey[1]));
+        frag b0 = *(const frag*)(bp[0] + blocked_piece_off(pc, bkey[0])), b1 = *(const frag*)(bp[1] + blocked_piece_off(pc, bkey[1]));
         acc[0][0] = Mfma<DT>::mma(a0, b0, acc[0][0]);
         acc[0][1] = Mfma<DT>::mma(a0, b1, acc[0][1]);
         acc[1][0] = Mfma<DT>::mma(a1, b0, acc[1][0]);
