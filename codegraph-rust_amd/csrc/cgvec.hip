@@ -283,6 +283,24 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // timing-only ablations of the bf16 kernel (scripts/gpu_ablate.sh; results are wrong when set)
+    static const int abl = getenv("CGV_ABLATE") ? atoi(getenv("CGV_ABLATE")) : 0;
+    if (abl && DT == DT_BF16 && !DUMP) {
+#define CGV_ABLK(N)                                                                                              \
+    case N: {                                                                                                    \
+        auto k2 = coarse_kernel<DT_BF16, false, N>;                                                              \
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                                                   \
+        break;                                                                                                   \
+    }
+        switch (abl) {
+            CGV_ABLK(1) CGV_ABLK(2) CGV_ABLK(4) CGV_ABLK(8) CGV_ABLK(10) CGV_ABLK(15) CGV_ABLK(16)
+            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE: unknown mask");
+        }
+#undef CGV_ABLK
+        HIPCHK(hipGetLastError());
+        return CGV_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
     HIPCHK(hipGetLastError());
     return CGV_OK;

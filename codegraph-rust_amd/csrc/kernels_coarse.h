@@ -206,7 +206,10 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
     }
 }
 
-template <int DT, bool DUMP>
+// ABL: timing-only ablation mask for scripts/gpu_ablate.sh (results are WRONG for ABL != 0):
+// 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
+// (MFMA on zeros), 16 = skip the vmcnt wait. DESIGN.md §5.1 quotes the numbers.
+template <int DT, bool DUMP, int ABL = 0>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NW = 8, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -272,6 +275,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // slot, so the loop body needs no "is there a next stage" branches and the counted
     // s_waitcnt vmcnt(8) below is valid in every iteration (<= 3 x 32 KiB of extra L2 reads).
     auto issue_q = [&](int q) {
+        if (ABL & 2) {
+            if (q == 3) ++issued;
+            return;
+        }
         char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
         const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
         if (q == 0) {
@@ -318,6 +325,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
     frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
+    if (ABL & 8) {
+        for (int i = 0; i < MB; ++i) fa0[i] = fa1[i] = (frag)0;
+        for (int i = 0; i < NB; ++i) fb0[i] = fb1[i] = (frag)0;
+    }
 #define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                         \
     {                                                                                            \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) FA[mb] =                               \
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_SB;                              \
         CGV_MMA_G0(fa0, fb0);                \
         CGV_SB;                              \
-        CGV_LOAD_FRAGS(fa1, fb1, SB, 1);     \
+        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa1, fb1, SB, 1); \
         CGV_SB;                              \
         CGV_MMA_G1(fa0, fb0);                \
         CGV_SB;                              \
@@ -417,10 +428,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_SB;
         CGV_MMA_G0(fa1, fb1);
         CGV_SB;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         CGV_SB;
-        CGV_LOAD_FRAGS(fa0, fb0, sb, 0);
+        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa0, fb0, sb, 0);
         CGV_SB;
         CGV_MMA_G1(fa1, fb1);
         CGV_SB;
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_SB;
         CGV_MMA_G3(fa1, fb1);
         CGV_SB;
-        if (ckc == 0) CGV_EPILOGUE();  // (s-1,1) was the last k-step of tile ptile
+        if (ckc == 0 && !(ABL & 1)) CGV_EPILOGUE();  // (s-1,1) was the last k-step of tile ptile
         CGV_A_PHASE(sb);
         CGV_ADVANCE();
     }

@@ -1,7 +1,9 @@
 #!/bin/bash
+# Timing-only ablations of the bf16 coarse kernel on C2 (CGV_ABLATE mask, kernels_coarse.h):
+# 1 no epilogue, 2 no DMA, 4 no barrier, 8 no fragment reads, 16 no vmcnt wait. Results are wrong
+# for any non-zero mask (fallback counts explode) - only the coarse launch time is meaningful.
 export TMPDIR=/tmp
-for X in 0 4 5 13 21 29; do
-echo -n "CGV_DBG=$X (1=noDMA 4=noEPI 8=noBAR 16=noFRAG): "; CGV_DBG=$X timeout 600 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | grep -v amdgpu.ids | tail -1 | python -c "
-import sys,json
-r=json.loads(sys.stdin.read()); print('coarse_ms', r['roofline']['avg_launch_ms'])"
+for abl in 0 1 2 4 8 10 15 16 0; do
+CGV_ABLATE=$abl timeout 300 python bench.py --steps 30 --warmup 5 --cpu-seconds 0 --depth 1 2>&1 | tail -1 | python -c "
+import json,sys; r=json.loads(sys.stdin.read()); print('mask $abl','coarse_ms',r['roofline']['avg_launch_ms'],'ms_per_step',r['ms_per_step'])"
 done
