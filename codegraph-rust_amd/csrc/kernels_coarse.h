@@ -211,7 +211,7 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
 // (MFMA on zeros), 16 = skip the vmcnt wait. DESIGN.md §5.1 quotes the numbers.
 template <int DT, bool DUMP, int ABL = 0>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
-    constexpr int BM = 256, BN = 256, WN = 4, NW = 8, NT = 512;
+    constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
     constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;  // one stage = one 64-byte K chunk of A and B
     constexpr int NSTAGE = 4, NINV = 8;                       // stage ring; per-tile side-data ring
@@ -514,7 +514,6 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const uint32_t ks = ld * Elem<DT>::bytes / 32;  // pairs of 16-byte pieces per row
-#pragma unroll 4
     for (uint32_t k = 0; k < ks; ++k) {
         const uint32_t pc = 2 * k + hi;  // this lane's 16-byte piece of k-step k
         frag a0 = *(const frag*)(ap[0] + blocked_piece_off(pc, akey[0])), a1 = *(const frag*)(ap[1] + blocked_piece_off(pc, akey[1]));

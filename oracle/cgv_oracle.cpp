@@ -422,7 +422,7 @@ void cgo_hash_embed(const uint8_t* text, size_t len, uint32_t dim, float* out) {
 void cgo_quantize_u8(const float* v, size_t len, uint8_t* out) {
     for (size_t i = 0; i < len; ++i) {
         float c = v[i] < -1.0f ? -1.0f : (v[i] > 1.0f ? 1.0f : v[i]);
-        int q = (int)roundf(c * 127.0f);
+        int q = (c != c) ? 0 : (int)roundf(c * 127.0f);  // Rust: NaN.round() as i32 == 0
         if (q < -127) q = -127;
         if (q > 127) q = 127;
         out[i] = (uint8_t)(q + 128);
@@ -436,7 +436,7 @@ uint64_t cgo_search_optimized_u8(const float* query, const uint8_t* data, uint64
     std::vector<int8_t> qq(dim);
     for (uint64_t i = 0; i < dim; ++i) {
         float c = query[i] < -1.0f ? -1.0f : (query[i] > 1.0f ? 1.0f : query[i]);
-        int q = (int)roundf(c * 127.0f);
+        int q = (c != c) ? 0 : (int)roundf(c * 127.0f);
         if (q < -127) q = -127;
         if (q > 127) q = 127;
         qq[i] = (int8_t)q;

@@ -10,7 +10,8 @@ from _util import ROOT, pkg
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cgvec.h")).read() + open(os.path.join(ROOT, "include", "cgvec_store.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include")))
+                   if f.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cgvs?_[a-z0-9_]+)\s*\(", text)))
 
@@ -20,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     m.build_library()
     L = ctypes.CDLL(m.cgvec.LIB_PATH)
     syms = _declared_symbols()
-    assert len(syms) >= 45
+    assert len(syms) >= 55 and "cgv_i8_search_optimized" in syms and "cgv_search_begin_f32_dev" in syms
     for s in syms:
         assert hasattr(L, s), f"{s} declared in cgvec.h but not exported"
 
@@ -40,6 +41,17 @@ def test_no_cpu_fallback_without_gpu():
         m.HipKnnIndex(384)
     assert ei.value.code == m.cgvec.CGV_ERR_HIP
     assert "no CPU fallback" in str(ei.value)
+
+
+def test_int8_scan_fails_loudly_without_gpu():
+    m = pkg()
+    if m.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(m.CgvError) as ei:
+        m.Int8ScanIndex(128)
+    assert "no CPU fallback" in str(ei.value)
+    with pytest.raises(m.CgvError):
+        m.quantize_u8([[0.5, 0.25]])
 
 
 def test_argument_validation_needs_no_gpu():
