@@ -18,7 +18,7 @@ DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
 
 CGV_OK = 0
 CGV_ERR_INVALID_ARG, CGV_ERR_DIM_MISMATCH, CGV_ERR_HIP, CGV_ERR_OOM = 1, 2, 3, 4
-CGV_ERR_NONFINITE, CGV_ERR_OUT_OF_RANGE, CGV_ERR_INTERNAL = 5, 6, 7
+CGV_ERR_NONFINITE, CGV_ERR_OUT_OF_RANGE, CGV_ERR_INTERNAL, CGV_ERR_IO = 5, 6, 7, 8
 PAD_IDX = np.uint64(2**64 - 1)
 
 
@@ -71,6 +71,10 @@ def lib():
     L.cgv_reserve.argtypes = [vp, u64]
     L.cgv_add_f32.argtypes = [vp, vp, u64]
     L.cgv_add_f32_dev.argtypes = [vp, vp, u64]
+    L.cgv_add_f64.argtypes = [vp, vp, u64]
+    L.cgv_load_mmap.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
+    L.cgv_write_mmap_f32.argtypes = [C.c_char_p, vp, u64, u32]
+    L.cgv_save_mmap.argtypes = [vp, C.c_char_p]
     L.cgv_count.argtypes = [vp]
     L.cgv_count.restype = u64
     L.cgv_dim.argtypes = [vp]
@@ -93,7 +97,7 @@ def lib():
     L.cgv_set_profiling.argtypes = [vp, i32]
     L.cgv_set_force_exact.argtypes = [vp, i32]
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
-    for name in ("cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
+    for name in ("cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
                  "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
@@ -213,6 +217,22 @@ class HipKnnIndex:
             raise CgvError(CGV_ERR_DIM_MISMATCH, f"expected [n,{self.dim}] rows, got {r.shape}")
         _check(lib().cgv_add_f32(self._h, r.ctypes.data_as(C.c_void_p), r.shape[0]))
 
+    def add_f64(self, rows):
+        """Rows as float64 (the SurrealDB embedding_<dim> column type), narrowed `as f32` on device."""
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        if r.ndim != 2 or r.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"rows shape {r.shape} != (*, {self.dim})")
+        _check(lib().cgv_add_f64(self._h, r.ctypes.data_as(C.c_void_p), r.shape[0]))
+
+    def load_mmap(self, path):
+        """Append the rows of a corpus file in the reference's mmap format (memory.rs:310-374)."""
+        n = C.c_uint64(0)
+        _check(lib().cgv_load_mmap(self._h, os.fsencode(path), C.byref(n)))
+        return int(n.value)
+
+    def save_mmap(self, path):
+        _check(lib().cgv_save_mmap(self._h, os.fsencode(path)))
+
     def update_row(self, i, row):
         r = np.ascontiguousarray(row, dtype=np.float32)
         if r.size != self.dim:
@@ -316,6 +336,14 @@ def normalize_rows(rows, device=0):
         r = r[None, :]
     _check(lib().cgv_normalize_rows_f32(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1]))
     return r
+
+
+def write_mmap(path, rows):
+    """MemoryOptimizer::save_to_mmap (memory.rs:242-307) for host rows."""
+    r = np.ascontiguousarray(rows, dtype=np.float32)
+    if r.ndim != 2:
+        raise CgvError(CGV_ERR_INVALID_ARG, "rows must be [n, dim]")
+    _check(lib().cgv_write_mmap_f32(os.fsencode(path), r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1]))
 
 
 def merge_topk(idx, score, device=None):

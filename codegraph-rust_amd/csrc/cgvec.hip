@@ -19,6 +19,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
@@ -246,20 +252,25 @@ int grow(cgv_index* h, uint64_t need) {
     return CGV_OK;
 }
 
-int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
-    if (cnt == 0) return CGV_OK;
-    int rc = grow(h, h->n + cnt);
-    if (rc) return rc;
+// Enqueue the ingest of cnt f32 rows (device memory) at absolute rows [row0, row0+cnt): storage
+// conversion, norms, per-32-row-block norm bounds, running max norm. No synchronisation; capacity
+// must already be there. ingest_finish() reads the flags back and publishes the new row count.
+int ingest_enqueue(cgv_index* h, const float* rows_dev, uint64_t cnt, uint64_t row0) {
     hipStream_t s = h->stream;
-    rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, h->n, h->rows, h->norm, h->invn, h->rexp,
-                       h->flags + F_NONFINITE_C, s);
+    int rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, row0, h->rows, h->norm, h->invn, h->rexp,
+                           h->flags + F_NONFINITE_C, s);
     if (rc) return rc;
-    const uint64_t n_new = h->n + cnt;
-    const uint64_t b0 = h->n / 32, b1 = (n_new + 31) / 32;
+    const uint64_t n_new = row0 + cnt;
+    const uint64_t b0 = row0 / 32, b1 = (n_new + 31) / 32;
     hipLaunchKernelGGL(block_norm_stats_kernel, dim3((unsigned)((b1 - b0 + 255) / 256)), dim3(256), 0, s,
                        h->norm, n_new, b0, b1, h->blk_min, h->blk_max);
-    hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, h->n, n_new, h->max_norm_dev);
+    hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, row0, n_new, h->max_norm_dev);
     HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+int ingest_finish(cgv_index* h, uint64_t n_new) {
+    hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -271,6 +282,19 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
                     "corpus rows contain NaN/Inf (the reference panics on NaN at simd_ops.rs:379)");
     }
     return CGV_OK;
+}
+
+int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
+    if (cnt == 0) return CGV_OK;
+    int rc = grow(h, h->n + cnt);
+    if (rc) return rc;
+    if ((rc = ingest_enqueue(h, rows_dev, cnt, h->n))) return rc;
+    return ingest_finish(h, h->n + cnt);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, uint64_t total, float* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];  // `as f32`: round to nearest even
 }
 
 template <int DT, bool DUMP>
@@ -859,6 +883,180 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
                               h->stream));
         if ((rc = add_dev_locked(h, h->addstage.as<float>(), c))) return rc;
     }
+    return CGV_OK;
+}
+
+int cgv_add_f64(cgv_index* h, const double* rows_host, uint64_t n) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (n && !rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    HIPCHK(hipSetDevice(h->device));
+    int rc = grow(h, h->n + n);
+    if (rc) return rc;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)h->D * 8));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
+        const uint64_t total = c * h->D;
+        // staging: [c*D doubles][c*D floats]
+        if ((rc = h->addstage.ensure((size_t)total * 12))) return rc;
+        double* d64 = h->addstage.as<double>();
+        float* d32 = (float*)(h->addstage.as<char>() + (size_t)total * 8);
+        HIPCHK(hipMemcpyAsync(d64, rows_host + r0 * h->D, (size_t)total * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)std::min<uint64_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                           h->stream, (const double*)d64, total, d32);
+        HIPCHK(hipGetLastError());
+        if ((rc = add_dev_locked(h, d32, c))) return rc;
+    }
+    return CGV_OK;
+}
+
+// ---- corpus files in the reference's mmap format (memory.rs:242-374) -------------------------
+// 16-byte header {u64 vector_count, u64 dimension} (native endian) + row-major f32.
+namespace {
+struct MappedFile {
+    int fd = -1;
+    void* p = MAP_FAILED;
+    size_t len = 0;
+    ~MappedFile() {
+        if (p != MAP_FAILED) munmap(p, len);
+        if (fd >= 0) close(fd);
+    }
+};
+}  // namespace
+
+int cgv_load_mmap(cgv_index* h, const char* path, uint64_t* out_rows) {
+    if (out_rows) *out_rows = 0;
+    if (!h || !path) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    MappedFile mf;
+    mf.fd = open(path, O_RDONLY);
+    if (mf.fd < 0) return fail(CGV_ERR_IO, std::string("Failed to open mmap file: ") + strerror(errno));
+    struct stat st;
+    if (fstat(mf.fd, &st) != 0) return fail(CGV_ERR_IO, std::string("Failed to map file: ") + strerror(errno));
+    mf.len = (size_t)st.st_size;
+    if (mf.len < 16) return fail(CGV_ERR_IO, "Invalid mmap file: too small");  // memory.rs:318-322
+    mf.p = mmap(nullptr, mf.len, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if (mf.p == MAP_FAILED) return fail(CGV_ERR_IO, std::string("Failed to map file: ") + strerror(errno));
+    (void)madvise(mf.p, mf.len, MADV_SEQUENTIAL);
+    uint64_t hdr[2];
+    memcpy(hdr, mf.p, 16);
+    const uint64_t count = hdr[0], dim = hdr[1];
+    if (dim != h->D)  // memory.rs:329-334
+        return fail(CGV_ERR_DIM_MISMATCH,
+                    "Dimension mismatch: expected " + std::to_string(h->D) + ", found " + std::to_string(dim));
+    const unsigned __int128 want = (unsigned __int128)16 + (unsigned __int128)count * dim * 4;
+    if (want != (unsigned __int128)mf.len)  // memory.rs:337-348
+        return fail(CGV_ERR_IO, "Invalid mmap file size: expected " + std::to_string((uint64_t)want) + ", got " +
+                                    std::to_string(mf.len));
+    if (count == 0) return CGV_OK;
+    const float* src = (const float*)((const char*)mf.p + 16);
+
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    HIPCHK(hipSetDevice(h->device));
+    int rc = grow(h, h->n + count);
+    if (rc) return rc;
+    // page cache -> pinned staging -> device, double buffered: the CPU copy of chunk i+1 overlaps the
+    // H2D copy + conversion kernels of chunk i (all on the handle's stream, no host sync per chunk).
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (dim * 4));
+    const size_t chunk_bytes = (size_t)chunk_rows * dim * 4;
+    float* pin[2] = {nullptr, nullptr};
+    float* dev[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (dev[i]) (void)hipFree(dev[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+    };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void**)&pin[i], chunk_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&dev[i], chunk_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(CGV_ERR_OOM, std::string("cgv_load_mmap staging: ") + hipGetErrorString(e));
+    }
+    const uint64_t base = h->n;
+    uint64_t ci = 0;
+    for (uint64_t r0 = 0; r0 < count && rc == CGV_OK; r0 += chunk_rows, ++ci) {
+        const int b = (int)(ci & 1);
+        const uint64_t c = std::min<uint64_t>(chunk_rows, count - r0);
+        if (ci >= 2 && hipEventSynchronize(done[b]) != hipSuccess) rc = fail(CGV_ERR_HIP, "cgv_load_mmap: event wait");
+        if (rc) break;
+        memcpy(pin[b], src + r0 * dim, (size_t)c * dim * 4);
+        if (hipMemcpyAsync(dev[b], pin[b], (size_t)c * dim * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rc = fail(CGV_ERR_HIP, "cgv_load_mmap: H2D copy");
+            break;
+        }
+        rc = ingest_enqueue(h, dev[b], c, base + r0);
+        if (rc == CGV_OK && hipEventRecord(done[b], h->stream) != hipSuccess) rc = fail(CGV_ERR_HIP, "cgv_load_mmap: event");
+    }
+    if (rc == CGV_OK)
+        rc = ingest_finish(h, base + count);
+    else
+        (void)hipStreamSynchronize(h->stream);
+    cleanup();
+    if (rc == CGV_OK && out_rows) *out_rows = count;
+    return rc;
+}
+
+int cgv_write_mmap_f32(const char* path, const float* rows_host, uint64_t n, uint32_t dim) {
+    if (!path) return fail(CGV_ERR_INVALID_ARG, "path is NULL");
+    if (n == 0) return CGV_OK;  // memory.rs:243-245: empty input writes no file
+    if (!rows_host || dim == 0) return fail(CGV_ERR_INVALID_ARG, "rows is NULL or dim is 0");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(CGV_ERR_IO, std::string("Failed to create mmap file: ") + strerror(errno));
+    const uint64_t hdr[2] = {n, dim};
+    bool ok = fwrite(hdr, 8, 2, f) == 2;
+    const size_t total = (size_t)n * dim;
+    ok = ok && fwrite(rows_host, 4, total, f) == total;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(CGV_ERR_IO, std::string("Failed to write to file: ") + strerror(errno));
+    return CGV_OK;
+}
+
+int cgv_save_mmap(cgv_index* h, const char* path) {
+    if (!h || !path) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    if (h->n == 0) return CGV_OK;
+    HIPCHK(hipSetDevice(h->device));
+    SearchCtx* c = &h->ctx[0];
+    hipStream_t s = c->stream;
+    if (int orc = order_after_caller(h, c)) return orc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(CGV_ERR_IO, std::string("Failed to create mmap file: ") + strerror(errno));
+    const uint64_t hdr[2] = {h->n, h->D};
+    bool ok = fwrite(hdr, 8, 2, f) == 2;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)h->D * 4));
+    std::vector<float> host((size_t)std::min<uint64_t>(chunk_rows, h->n) * h->D);
+    int rc = CGV_OK;
+    for (uint64_t r0 = 0; r0 < h->n && ok && rc == CGV_OK; r0 += chunk_rows) {
+        const uint64_t cnt = std::min<uint64_t>(chunk_rows, h->n - r0);
+        if ((rc = c->qstage.ensure((size_t)cnt * h->D * 4))) break;
+        float* tmp = c->qstage.as<float>();
+        const dim3 grid((unsigned)cnt), blk(256);
+        switch (h->dtype) {
+            case CGV_DTYPE_F32: hipLaunchKernelGGL(gather_row_kernel<DT_F32>, grid, blk, 0, s, (const char*)h->rows, r0, h->D, h->ld, (const int8_t*)h->rexp, tmp); break;
+            case CGV_DTYPE_BF16: hipLaunchKernelGGL(gather_row_kernel<DT_BF16>, grid, blk, 0, s, (const char*)h->rows, r0, h->D, h->ld, (const int8_t*)h->rexp, tmp); break;
+            case CGV_DTYPE_FP16: hipLaunchKernelGGL(gather_row_kernel<DT_FP16>, grid, blk, 0, s, (const char*)h->rows, r0, h->D, h->ld, (const int8_t*)h->rexp, tmp); break;
+            default: hipLaunchKernelGGL(gather_row_kernel<DT_FP8>, grid, blk, 0, s, (const char*)h->rows, r0, h->D, h->ld, (const int8_t*)h->rexp, tmp); break;
+        }
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(host.data(), tmp, (size_t)cnt * h->D * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(CGV_ERR_HIP, "cgv_save_mmap: device gather failed");
+            break;
+        }
+        ok = fwrite(host.data(), 4, (size_t)cnt * h->D, f) == (size_t)cnt * h->D;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (rc) return rc;
+    if (!ok) return fail(CGV_ERR_IO, std::string("Failed to write to file: ") + strerror(errno));
     return CGV_OK;
 }
 

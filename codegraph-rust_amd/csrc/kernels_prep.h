@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
 template <int DT>
 __global__ void gather_row_kernel(const char* __restrict__ rows, uint64_t R, uint32_t D, uint32_t ld,
                                   const int8_t* __restrict__ rexp, float* __restrict__ out) {
+    R += blockIdx.x;  // one block per row: rows [R, R + gridDim.x) -> out[gridDim.x][D]
+    out += (uint64_t)blockIdx.x * D;
     const Row<DT> r = make_row<DT>(rows, R, ld);
     const int e = (DT == DT_FP8 && rexp) ? (int)rexp[R] : 0;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) out[i] = ldexpf(r.at(i), -e);

@@ -61,6 +61,7 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_ERR_NONFINITE 5    /* NaN/Inf in corpus or query: the reference panics (simd_ops.rs:379) */
 #define CGV_ERR_OUT_OF_RANGE 6 /* VectorError::IndexOutOfBounds, error.rs:14-15 */
 #define CGV_ERR_INTERNAL 7
+#define CGV_ERR_IO 8           /* corpus file errors; messages follow memory.rs:242-374 */
 
 #define CGV_MAX_K 256u
 
@@ -120,6 +121,25 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
  * returns after the work is enqueued and the exactness check has been read back). */
 int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
                        uint64_t* out_idx_dev, float* out_score_dev);
+
+/* Append n rows given as f64 (flat [n][dim], HOST): the SurrealDB `embedding_<dim>` columns hold
+ * Vec<f64> (crates/codegraph-graph/src/surrealdb_storage.rs:1955-1977); narrowed with `as f32`
+ * (round to nearest even) on the device, then ingested like cgv_add_f32. */
+int cgv_add_f64(cgv_index* h, const double* rows_host, uint64_t n);
+
+/* Corpus files in the reference's mmap format, MemoryOptimizer::save_to_mmap / load_from_mmap
+ * (crates/codegraph-vector/src/memory.rs:242-374): 16-byte header {u64 vector_count, u64 dimension}
+ * (native endian) followed by row-major f32.
+ *   cgv_load_mmap: map the file, validate it like load_from_mmap (too small / dimension mismatch
+ *     against the handle's dim / size mismatch -> CGV_ERR_IO or CGV_ERR_DIM_MISMATCH with the
+ *     reference's messages), and APPEND its rows: page cache -> pinned staging -> device,
+ *     double-buffered so the host copy of one 64-MiB chunk overlaps the H2D + conversion of the
+ *     previous one. *out_rows = rows appended.
+ *   cgv_write_mmap_f32: save_to_mmap for host rows (n == 0 writes no file, memory.rs:243-245).
+ *   cgv_save_mmap: the handle's stored rows (upcast to f32) in the same format. */
+int cgv_load_mmap(cgv_index* h, const char* path, uint64_t* out_rows);
+int cgv_write_mmap_f32(const char* path, const float* rows_host, uint64_t n, uint32_t dim);
+int cgv_save_mmap(cgv_index* h, const char* path);
 
 /* Split form of cgv_search_f32_dev for callers that keep several batches in flight (the handle
  * owns a small pool of search contexts, each with its own HIP stream and scratch — SURVEY.md §8(b)
