@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcgvec_hip.so")
 
-METRICS = {"cosine": 0, "dot": 1}
+METRICS = {"cosine": 0, "dot": 1, "cosine_seq": 2}
 DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
 
 CGV_OK = 0

@@ -383,7 +383,7 @@ void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
 int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
                  float* out_score, hipStream_t s, int op = -1) {
-    if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : OP_COSINE;
+    if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : (h->metric == CGV_METRIC_COSINE_SEQ ? OP_COSINE_SEQ : OP_COSINE);
     const uint64_t n = h->n;
     const uint32_t K = next_pow2(std::max<uint32_t>(k, 2));
     uint64_t qg = std::max<uint64_t>(1, (512ull << 20) / (n * 4));
@@ -631,7 +631,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.metric = h->metric;
         // |coarse - exact| <= (accumulation depth of both sums + norm terms) * u * |q||c|: the MFMA
         // path adds D/16 partial sums, the reference D/8 per lane + a 3-level tree
-        r.eps_scale = ((float)h->D * 0.5f + 64.0f) * 5.9604645e-8f;
+        // (the sequential formula of CGV_METRIC_COSINE_SEQ sums D deep in one chain)
+        r.eps_scale = ((float)h->D * (h->metric == CGV_METRIC_COSINE_SEQ ? 1.0f : 0.5f) + 64.0f) * 5.9604645e-8f;
         r.max_norm_c = h->max_norm_c;
         c->eps = r.eps_scale;
         {
@@ -775,10 +776,11 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (dim == 0 || dim > 8192) return fail(CGV_ERR_INVALID_ARG, "dim must be in 1..=8192");
-    if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT) return fail(CGV_ERR_INVALID_ARG, "bad metric");
+    if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT && metric != CGV_METRIC_COSINE_SEQ)
+        return fail(CGV_ERR_INVALID_ARG, "bad metric");
     if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16 && dtype != CGV_DTYPE_FP8E4M3)
         return fail(CGV_ERR_INVALID_ARG, "unknown dtype (f32, bf16, fp16, fp8e4m3)");
-    if (dtype == CGV_DTYPE_FP8E4M3 && metric != CGV_METRIC_COSINE)
+    if (dtype == CGV_DTYPE_FP8E4M3 && metric == CGV_METRIC_DOT)
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage keeps a per-row scale: cosine only in this build");
     int ndev = cgv_device_count();
     if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");

@@ -6,7 +6,7 @@
 namespace cgv {
 
 constexpr int DT_F32 = 0, DT_BF16 = 1, DT_FP16 = 2, DT_FP8 = 3;
-constexpr int METRIC_COSINE = 0, METRIC_DOT = 1;
+constexpr int METRIC_COSINE = 0, METRIC_DOT = 1, METRIC_COSINE_SEQ = 2;
 
 // ---- sortable keys: larger key == better (score desc, row asc) -----------------
 __host__ __device__ inline uint32_t f2ord(float f) {
@@ -272,10 +272,6 @@ __device__ inline float exact_dot_group8(const RQ& q, const RC& c, uint32_t D, i
     return result;
 }
 
-template <class RQ, class RC>
-__device__ inline float exact_score_group8(int metric, const RQ& q, const RC& c, uint32_t D, int l) {
-    return metric == METRIC_DOT ? exact_dot_group8(q, c, D, l) : exact_cosine_group8(q, c, D, l);
-}
 
 // l2_distance_avx2, simd_ops.rs:105-143 (8 lanes: diff, fused square-accumulate; h-sum; scalar
 // tail with separate rounding; sqrt of the total)
@@ -316,6 +312,12 @@ __device__ inline float exact_cosine_seq(const RQ& q, const RC& c, uint32_t D, b
     if (norm_a == 0.0f || norm_b == 0.0f) return distance ? INFINITY : 0.0f;
     const float cs = dot / (norm_a * norm_b);
     return distance ? 1.0f - cs : cs;
+}
+
+template <class RQ, class RC>
+__device__ inline float exact_score_group8(int metric, const RQ& q, const RC& c, uint32_t D, int l) {
+    if (metric == METRIC_COSINE_SEQ) return l == 0 ? exact_cosine_seq(q, c, D, false) : 0.0f;
+    return metric == METRIC_DOT ? exact_dot_group8(q, c, D, l) : exact_cosine_group8(q, c, D, l);
 }
 
 constexpr int OP_COSINE = 0, OP_DOT = 1, OP_L2 = 2, OP_COSINE_SEQ = 3, OP_COSINE_DISTANCE_SEQ = 4,

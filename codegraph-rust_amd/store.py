@@ -56,6 +56,15 @@ def _lib():
         L.cgvs_normalize_scores.restype = None
         L.cgvs_cosine_similarity.argtypes = [vp, vp, u32]
         L.cgvs_cosine_similarity.restype = C.c_float
+        L.cgvs_resolver_create.argtypes = [u32, C.c_int, C.c_int, C.POINTER(vp)]
+        L.cgvs_resolver_destroy.argtypes = [vp]
+        L.cgvs_resolver_add_symbols.argtypes = [vp, u32, C.POINTER(C.c_char_p), vp]
+        L.cgvs_resolver_count.argtypes = [vp]
+        L.cgvs_resolver_count.restype = C.c_uint64
+        L.cgvs_resolver_match.argtypes = [vp, u32, C.POINTER(C.c_char_p), vp, C.c_float, vp, vp]
+        L.cgvs_trigram_jaccard.argtypes = [C.c_char_p, C.c_char_p]
+        L.cgvs_trigram_jaccard.restype = C.c_float
+        L.cgvs_symbol_name_eligible.argtypes = [C.c_char_p, C.c_char_p]
         _bound = True
     return L
 
@@ -251,3 +260,58 @@ def combine_embeddings(embs):
     out = np.empty(e.shape[1], np.float32)
     _check(_lib().cgvs_combine_embeddings(e.ctypes.data_as(C.c_void_p), e.shape[0], e.shape[1], out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def trigram_jaccard(a, b):
+    """indexer.rs:2901-2932 on the lower-cased names."""
+    return float(_lib().cgvs_trigram_jaccard(a.encode(), b.encode()))
+
+
+def symbol_name_eligible(target, name):
+    """The candidate pre-filter of ai_semantic_match_sync (indexer.rs:2804-2821)."""
+    return bool(_lib().cgvs_symbol_name_eligible(target.encode(), name.encode()))
+
+
+class SymbolResolver:
+    """Embedding phase of the index-time symbol resolver (indexer.rs:2790-2843) over the HIP kNN:
+    add the known symbols once, then match whole batches of unresolved symbols."""
+
+    def __init__(self, dim, dtype="f32", device=0):
+        self.dim = int(dim)
+        h = C.c_void_p()
+        cgvec._check(_lib().cgvs_resolver_create(self.dim, cgvec.DTYPES[dtype], int(device), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            _lib().cgvs_resolver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(_lib().cgvs_resolver_count(self._h))
+
+    def add_symbols(self, names, embeddings):
+        e = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if e.ndim != 2 or e.shape[1] != self.dim or e.shape[0] != len(names):
+            raise cgvec.CgvError(cgvec.CGV_ERR_DIM_MISMATCH, f"embeddings {e.shape} vs {len(names)} names x {self.dim}")
+        arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        cgvec._check(_lib().cgvs_resolver_add_symbols(self._h, len(names), arr, e.ctypes.data_as(C.c_void_p)))
+
+    def match(self, targets, embeddings, threshold=0.75):
+        """-> (index int64[nq] (-1 = unresolved), similarity f32[nq])"""
+        e = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if e.ndim != 2 or e.shape[1] != self.dim or e.shape[0] != len(targets):
+            raise cgvec.CgvError(cgvec.CGV_ERR_DIM_MISMATCH, f"embeddings {e.shape} vs {len(targets)} targets x {self.dim}")
+        arr = (C.c_char_p * len(targets))(*[s.encode() for s in targets])
+        idx = np.empty(len(targets), dtype=np.int64)
+        sc = np.empty(len(targets), dtype=np.float32)
+        cgvec._check(_lib().cgvs_resolver_match(self._h, len(targets), arr, e.ctypes.data_as(C.c_void_p),
+                                                float(threshold), idx.ctypes.data_as(C.c_void_p),
+                                                sc.ctypes.data_as(C.c_void_p)))
+        return idx, sc

@@ -45,6 +45,8 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 /* similarity metric */
 #define CGV_METRIC_COSINE 0 /* SIMDVectorOps::adaptive_cosine_similarity, simd_ops.rs:281-295 */
 #define CGV_METRIC_DOT 1    /* SIMDVectorOps::dot_product_avx2, simd_ops.rs:149-183 */
+#define CGV_METRIC_COSINE_SEQ 2 /* the sequential dot/(sqrt(na)*sqrt(nb)) cosine of SemanticSearch (search.rs:519-533)
+                                  and of the symbol resolver (crates/codegraph-mcp/src/indexer.rs:2965-2979) */
 
 /* storage dtype of the corpus in HBM (queries are rounded to the same dtype) */
 #define CGV_DTYPE_F32 0     /* the reference's own Vec<f32> (node.rs:14) */

@@ -114,6 +114,27 @@ int cgvs_multi_vector_search(cgvs_store* s, const float* queries, uint32_t nq, u
 /* SemanticSearch::combine_embeddings (search.rs:232-266): mean then L2-normalise. */
 int cgvs_combine_embeddings(const float* embeddings, uint32_t n, uint32_t dim, float* out);
 
+/* ---- index-time symbol resolution, embedding phase -----------------------------
+ * Mirror of ai_semantic_match_sync PHASE 2 (crates/codegraph-mcp/src/indexer.rs:2790-2843) with
+ * cosine_similarity_static (:2965-2979) and the char-trigram / Jaccard name filter (:2804-2821,
+ * :2901-2932): for each unresolved symbol, the known symbol that passes the name filter with the
+ * highest similarity, if it is > threshold (0.75 in the reference). The |unresolved| x |known|
+ * similarities are ONE batched device search (CGV_METRIC_COSINE_SEQ); the name filter runs on the
+ * host for the best-ranked candidates only. Ties (the reference iterates a HashMap) -> lowest index.
+ * dtype F32 reproduces the reference's similarities bit for bit; bf16/fp16/fp8 evaluate them on the
+ * rounded embeddings. */
+typedef struct cgvs_resolver cgvs_resolver;
+int cgvs_resolver_create(uint32_t dim, int dtype, int device_id, cgvs_resolver** out);
+int cgvs_resolver_destroy(cgvs_resolver* r);
+/* symbol_embeddings (indexer.rs:1808-1867): names + flat f32 [n][dim]; index = insertion order */
+int cgvs_resolver_add_symbols(cgvs_resolver* r, uint32_t n, const char* const* names, const float* embeddings);
+uint64_t cgvs_resolver_count(const cgvs_resolver* r);
+/* out_index[q] = index of the matched known symbol or -1; out_score[q] (may be NULL) = its similarity */
+int cgvs_resolver_match(cgvs_resolver* r, uint32_t nq, const char* const* targets, const float* target_embeddings,
+                        float threshold, int64_t* out_index, float* out_score);
+float cgvs_trigram_jaccard(const char* a, const char* b);            /* indexer.rs:2901-2932 on lower-cased names */
+int cgvs_symbol_name_eligible(const char* target, const char* name); /* indexer.rs:2804-2821 */
+
 /* Free functions of the mirrored surface. */
 const char* cgvs_embedding_column_for_dimension(uint32_t dim);            /* surrealdb_storage.rs:1932-1952 */
 int cgvs_normalize_node_id(const char* raw, char* out, size_t out_len);   /* surreal_store.rs:123-128 */

@@ -40,6 +40,8 @@
 
 #include <algorithm>
 #include <limits>
+#include <set>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -224,6 +226,8 @@ static void parallel_sort_pairs(std::vector<Pair>& v, int threads) {
     }
 }
 
+float cgo_search_cosine(const float* a, const float* b, size_t len);
+
 int cgo_parallel_top_k(const float* query, const float* const* rows, uint64_t n, uint64_t dim,
                        uint64_t k, int metric, int threads, uint64_t* out_idx, float* out_score) {
     if (threads <= 0) {
@@ -237,8 +241,9 @@ int cgo_parallel_top_k(const float* query, const float* const* rows, uint64_t n,
     int has_nan = 0;
 #pragma omp parallel for num_threads(threads) schedule(static) reduction(| : has_nan)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
-        float s = metric == 1 ? cgo_dot_avx2(query, rows[i], dim)
-                              : cgo_cosine_adaptive(query, rows[i], dim);
+        float s = metric == 1   ? cgo_dot_avx2(query, rows[i], dim)
+                  : metric == 2 ? cgo_search_cosine(query, rows[i], dim)  // search.rs:519-533 == indexer.rs:2965-2979
+                                : cgo_cosine_adaptive(query, rows[i], dim);
         if (s != s) has_nan |= 1;
         sims[i].s = s;
         sims[i].i = (uint64_t)i;
@@ -622,6 +627,71 @@ int cgo_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Symbol resolver, embedding phase: crates/codegraph-mcp/src/indexer.rs:2790-2843
+// (ai_semantic_match_sync PHASE 2) with char_trigrams / jaccard (:2901-2932) and
+// cosine_similarity_static (:2965-2979, same arithmetic as cgo_search_cosine). Literal
+// per-target loop over all known symbols; the reference's HashMap order is unspecified, the
+// restatement visits symbols in index order and keeps the first strictly greater similarity.
+// Lower-casing is ASCII-only (test names are ASCII identifiers).
+// ---------------------------------------------------------------------------
+static std::string o_lower(const char* s) {
+    std::string r(s ? s : "");
+    for (size_t i = 0; i < r.size(); ++i)
+        if (r[i] >= 'A' && r[i] <= 'Z') r[i] = (char)(r[i] + 32);
+    return r;
+}
+static std::set<std::string> o_trigrams(const std::string& s) {
+    std::vector<std::string> chars;  // s.chars()
+    for (size_t i = 0; i < s.size();) {
+        size_t j = i + 1;
+        while (j < s.size() && ((unsigned char)s[j] & 0xC0) == 0x80) ++j;
+        chars.push_back(s.substr(i, j - i));
+        i = j;
+    }
+    std::set<std::string> out;
+    if (chars.size() < 3) {
+        if (!s.empty()) out.insert(s);
+        return out;
+    }
+    for (size_t i = 0; i + 3 <= chars.size(); ++i) out.insert(chars[i] + chars[i + 1] + chars[i + 2]);
+    return out;
+}
+static float o_jaccard(const std::set<std::string>& a, const std::set<std::string>& b) {
+    if (a.empty() || b.empty()) return 0.0f;
+    float inter = 0.0f;
+    for (std::set<std::string>::const_iterator it = a.begin(); it != a.end(); ++it)
+        if (b.count(*it)) inter += 1.0f;
+    float uni = (float)(a.size() + b.size()) - inter;
+    return uni == 0.0f ? 0.0f : inter / uni;
+}
+float cgo_trigram_jaccard(const char* a, const char* b) { return o_jaccard(o_trigrams(o_lower(a)), o_trigrams(o_lower(b))); }
+
+int64_t cgo_symbol_match_phase2(const char* target, const float* target_emb, uint64_t n, const char* const* names,
+                                const float* embs, uint64_t dim, float threshold, float* out_score) {
+    const std::string tl = o_lower(target);
+    const std::set<std::string> tt = o_trigrams(tl);
+    int64_t best = -1;
+    float best_s = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) {
+        const std::string nl = o_lower(names[i]);
+        const float a = (float)tl.size(), b = (float)nl.size();
+        const float r1 = a / b, r2 = b / a;
+        const float ratio = r1 < r2 ? r1 : r2;
+        if (!(ratio >= 0.5f)) continue;                    // len_ok (:2808-2815)
+        if (!(o_jaccard(tt, o_trigrams(nl)) >= 0.2f)) continue;  // overlap >= 0.2 (:2817-2819)
+        const float sim = cgo_search_cosine(target_emb, embs + i * dim, dim);
+        if (sim > threshold) {                            // :2828
+            if (best < 0 || sim > best_s) {               // :2829-2835
+                best = (int64_t)i;
+                best_s = sim;
+            }
+        }
+    }
+    if (out_score) *out_score = best >= 0 ? best_s : 0.0f;
+    return best;
 }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 F32, BF16, FP16, FP8 = 0, 1, 2, 3
-COSINE, DOT = 0, 1
+COSINE, DOT, COSINE_SEQ = 0, 1, 2
 
 
 def build(force=False):
@@ -232,6 +232,27 @@ def search_optimized_u8(query, data_u8, limit):
     m = lib().cgo_search_optimized_u8(pq, d.ctypes.data_as(C.POINTER(C.c_uint8)), n, dim, limit,
                                       idx.ctypes.data_as(C.POINTER(C.c_uint64)))
     return idx[:m]  # optimization.rs:63-150
+
+
+def trigram_jaccard(a, b):
+    L = lib()
+    L.cgo_trigram_jaccard.restype = C.c_float
+    L.cgo_trigram_jaccard.argtypes = [C.c_char_p, C.c_char_p]
+    return float(L.cgo_trigram_jaccard(a.encode(), b.encode()))  # indexer.rs:2901-2932
+
+
+def symbol_match_phase2(target, target_emb, names, embs, threshold=0.75):
+    """indexer.rs:2790-2843 for one unresolved symbol -> (index or -1, similarity)."""
+    L = lib()
+    L.cgo_symbol_match_phase2.restype = C.c_int64
+    L.cgo_symbol_match_phase2.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_float), C.c_uint64, C.c_float, C.POINTER(C.c_float)]
+    t, pt = _f(target_emb)
+    e, pe = _f(embs)
+    arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+    sc = C.c_float(0.0)
+    i = L.cgo_symbol_match_phase2(target.encode(), pt, len(names), arr, pe, e.shape[1], threshold, C.byref(sc))
+    return int(i), float(np.float32(sc.value))
 
 
 def round_trip(a, dtype, scaled_fp8=True, fp8_codes=False):

@@ -11,7 +11,7 @@ from _util import pkg
 pytestmark = pytest.mark.gpu
 
 ODT = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
-OMETRIC = {"cosine": 0, "dot": 1}
+OMETRIC = {"cosine": 0, "dot": 1, "cosine_seq": 2}
 
 
 def _unit(rng, n, d):
@@ -82,7 +82,8 @@ def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
 
 @pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "cosine"), ("bf16", "dot"),
                                           ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot"),
-                                          ("fp8", "cosine")])
+                                          ("fp8", "cosine"), ("bf16", "cosine_seq"), ("f32", "cosine_seq"),
+                                          ("fp8", "cosine_seq")])
 def test_parity_small(oracle, dtype, metric):
     _run(oracle, n=1000, d=256, nq=7, k=10, dtype=dtype, metric=metric)
 
@@ -123,6 +124,14 @@ def test_parity_medium_staged(oracle, dtype, metric):
     st = _run(oracle, n=70_000, d=1536 // 4 if dtype == "fp16" else 768, nq=300, k=10, dtype=dtype, metric=metric, seed=3)
     assert st["last_path"] == 1
     assert st["fallback_queries"] == 0
+    assert st["max_observed_err"] <= st["last_eps"]
+
+
+def test_parity_sequential_cosine_metric_staged(oracle):
+    """CGV_METRIC_COSINE_SEQ: the sequential cosine of search.rs:519-533 / indexer.rs:2965-2979 as the
+    exact arithmetic behind the MFMA coarse pass (un-normalised rows, several stages)."""
+    st = _run(oracle, n=40_000, d=384, nq=130, k=10, dtype="bf16", metric="cosine_seq", seed=14, unit=False)
+    assert st["last_path"] == 1 and st["fallback_queries"] == 0
     assert st["max_observed_err"] <= st["last_eps"]
 
 
