@@ -40,6 +40,7 @@ WORKLOADS = {
     "c4": (1_000_000, 1536, "fp16", "dot", 256, 10),
     "c3shard": (1_250_000, 768, "bf16", "cosine", 4096, 10),   # one GPU's share of C3 (10M rows / 8)
     "small": (100_000, 768, "bf16", "cosine", 1024, 10),
+    "c2shard8": (125_000, 768, "bf16", "cosine", 1024, 10),    # one rank's share of C2 at 8 GPUs (fixed-cost probe)
     # C5 = 500M x 768 fp8 over 8 GPUs, batch 8192: one GPU's share is 62.5M rows = 48 GB of codes
     "c5shard": (62_500_000, 768, "fp8", "cosine", 8192, 10),
     "c5mini": (4_000_000, 768, "fp8", "cosine", 8192, 10),   # same kernel shape, 1/16 of the shard

@@ -24,10 +24,16 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
                                                         float* __restrict__ norm,
                                                         float* __restrict__ invn,
                                                         int8_t* __restrict__ rexp,
-                                                        uint32_t* __restrict__ nonfinite) {
+                                                        uint32_t* __restrict__ nonfinite,
+                                                        uint32_t* __restrict__ zero0,
+                                                        uint32_t* __restrict__ zero1) {
     const int lane = threadIdx.x & 63;
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (lane == 0) {  // query batches: per-query state cleared here instead of by two extra memset launches
+        if (zero0) zero0[row0 + row] = 0u;
+        if (zero1) zero1[row0 + row] = 0u;
+    }
     const float* src = in + row * (uint64_t)D;
     int e = 0;
     if (DT == DT_FP8) {  // per-row power-of-two scale: amax * 2^e <= 448 (common.h)

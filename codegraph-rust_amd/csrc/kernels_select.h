@@ -104,37 +104,88 @@ __device__ inline void cmpx_desc(uint64_t& x, uint64_t& y) {  // compare-exchang
     y = lo;
 }
 
+// 8-input sorting network (19 compare-exchanges), descending
+__device__ inline void sort8_desc(uint64_t* r) {
+    cmpx_desc(r[0], r[1]); cmpx_desc(r[2], r[3]); cmpx_desc(r[4], r[5]); cmpx_desc(r[6], r[7]);
+    cmpx_desc(r[0], r[2]); cmpx_desc(r[1], r[3]); cmpx_desc(r[4], r[6]); cmpx_desc(r[5], r[7]);
+    cmpx_desc(r[1], r[2]); cmpx_desc(r[5], r[6]); cmpx_desc(r[0], r[4]); cmpx_desc(r[3], r[7]);
+    cmpx_desc(r[1], r[5]); cmpx_desc(r[2], r[6]);
+    cmpx_desc(r[1], r[4]); cmpx_desc(r[3], r[6]);
+    cmpx_desc(r[2], r[4]); cmpx_desc(r[3], r[5]);
+    cmpx_desc(r[3], r[4]);
+}
+
+// Register-resident extraction: every lane keeps its NPL keys SORTED IN REGISTERS; a round is one
+// wave-wide max (DPP) + a register shift in the owner lane. keys are unique, 0 = empty.
+template <int NPL, class LOAD>
+__device__ inline void extract_regs(LOAD load, uint32_t M, uint32_t keep, uint64_t* part, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    uint64_t r[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const uint32_t e = (uint32_t)tid + 256u * i;
+        r[i] = e < M ? load(e) : 0ull;
+    }
+    sort8_desc(r);
+    if (NPL == 16) {  // second run, then a bitonic merge of the two sorted runs
+        sort8_desc(r + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t t = r[8 + i];
+            r[8 + i] = r[15 - i];
+            r[15 - i] = t;
+        }
+#pragma unroll
+        for (int stride = 8; stride > 0; stride >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((i & stride) == 0) cmpx_desc(r[i], r[i + stride]);
+    }
+    for (uint32_t rd = 0; rd < keep; ++rd) {
+        const uint64_t w = wave_max_u64(r[0]);
+        if (w != 0ull && r[0] == w) {  // exactly one owner
+#pragma unroll
+            for (int i = 0; i < NPL - 1; ++i) r[i] = r[i + 1];
+            r[NPL - 1] = 0ull;
+        }
+        if (lane == 0) part[wv * 64 + rd] = w;
+    }
+}
+
+// 4-way merge of the four sorted per-wave lists part[4][64] -> outk[0..keep), by one lane
+__device__ inline void merge4(const uint64_t* part, uint32_t keep, uint64_t* outk, int tid) {
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t h[4] = {0, 0, 0, 0};
+        for (uint32_t rd = 0; rd < keep; ++rd) {
+            uint64_t best = 0ull;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t v = h[i] < keep ? part[i * 64 + h[i]] : 0ull;
+                if (v > best) {
+                    best = v;
+                    bi = i;
+                }
+            }
+            h[bi]++;
+            outk[rd] = best;
+        }
+    }
+    __syncthreads();
+}
+
 // Top-`keep` (keep <= 64) of keys[0..M) -> outk[0..keep) sorted descending. 256 threads.
-// M <= 2048: every lane keeps its <= 8 keys SORTED IN REGISTERS, a round is one wave-wide max
-// (DPP) + a register shift in the owner; larger M: lane-private LDS rescans. The four per-wave
-// lists (already sorted) are merged by one lane.
+// M <= 4096: register-resident extraction (8 or 16 keys per lane); larger M: lane-private LDS
+// rescans. The four per-wave lists (already sorted) are merged by one lane.
 __device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, uint64_t* part /*[4*64]*/,
                                     uint64_t* outk /*[64]*/, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
+    auto from_lds = [&](uint32_t e) { return keys[e]; };
     if (M <= 2048) {
-        uint64_t r[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t e = (uint32_t)tid + 256u * i;
-            r[i] = e < M ? keys[e] : 0ull;
-        }
-        // 8-input sorting network (19 compare-exchanges), descending
-        cmpx_desc(r[0], r[1]); cmpx_desc(r[2], r[3]); cmpx_desc(r[4], r[5]); cmpx_desc(r[6], r[7]);
-        cmpx_desc(r[0], r[2]); cmpx_desc(r[1], r[3]); cmpx_desc(r[4], r[6]); cmpx_desc(r[5], r[7]);
-        cmpx_desc(r[1], r[2]); cmpx_desc(r[5], r[6]); cmpx_desc(r[0], r[4]); cmpx_desc(r[3], r[7]);
-        cmpx_desc(r[1], r[5]); cmpx_desc(r[2], r[6]);
-        cmpx_desc(r[1], r[4]); cmpx_desc(r[3], r[6]);
-        cmpx_desc(r[2], r[4]); cmpx_desc(r[3], r[5]);
-        cmpx_desc(r[3], r[4]);
-        for (uint32_t rd = 0; rd < keep; ++rd) {
-            const uint64_t w = wave_max_u64(r[0]);
-            if (w != 0ull && r[0] == w) {  // keys are unique: exactly one owner
-#pragma unroll
-                for (int i = 0; i < 7; ++i) r[i] = r[i + 1];
-                r[7] = 0ull;
-            }
-            if (lane == 0) part[wv * 64 + rd] = w;
-        }
+        extract_regs<8>(from_lds, M, keep, part, tid);
+    } else if (M <= 4096) {
+        extract_regs<16>(from_lds, M, keep, part, tid);
     } else {
         auto lane_max = [&](uint32_t& at) {
             uint64_t mx = 0ull;
@@ -159,25 +210,7 @@ __device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, u
             if (lane == 0) part[wv * 64 + rd] = w;
         }
     }
-    __syncthreads();
-    if (tid == 0) {  // 4-way merge of the sorted per-wave lists
-        uint32_t h[4] = {0, 0, 0, 0};
-        for (uint32_t rd = 0; rd < keep; ++rd) {
-            uint64_t best = 0ull;
-            int bi = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint64_t v = h[i] < keep ? part[i * 64 + h[i]] : 0ull;
-                if (v > best) {
-                    best = v;
-                    bi = i;
-                }
-            }
-            h[bi]++;
-            outk[rd] = best;
-        }
-    }
-    __syncthreads();
+    merge4(part, keep, outk, tid);
 }
 
 // One workgroup (256 threads) per query: merge best[q] with the nsplit candidate
@@ -193,6 +226,24 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     bool trunc = false;
+    if (a.dense && a.lds_keys == 0) {
+        // boot stage (nothing selected yet, n_dense <= 4096, k' <= 64): keys straight from the dense
+        // scores into registers - no LDS staging, so 8 workgroups fit a CU instead of 2
+        const uint32_t M0 = a.n_dense, keep0 = M0 < a.kprime ? M0 : a.kprime;
+        const float* d = a.dense + (uint64_t)q * a.n_dense;
+        auto from_dense = [&](uint32_t e) { return make_key(d[e], e); };
+        if (M0 <= 2048)
+            extract_regs<8>(from_dense, M0, keep0, part, tid);
+        else
+            extract_regs<16>(from_dense, M0, keep0, part, tid);
+        merge4(part, keep0, outk, tid);
+        for (uint32_t i = tid; i < keep0; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
+        if (tid == 0) {
+            a.nbest[q] = keep0;
+            a.tau[q] = (M0 >= a.kprime) ? key_score(outk[a.kprime - 1]) : -INFINITY;
+        }
+        return;
+    }
     const uint32_t M = gather_keys(a, q, keys, pre, tid, &trunc);
     const uint32_t keep = M < a.kprime ? M : a.kprime;
     if (a.kprime <= 64) {
