@@ -34,6 +34,7 @@
 #include "../../include/cgvec.h"
 #include "common.h"
 #include "kernels_coarse.h"
+#include "kernels_coarse_fp8.h"
 #include "kernels_exact.h"
 #include "kernels_prep.h"
 #include "kernels_select.h"
@@ -331,13 +332,32 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     return CGV_OK;
 }
 
+template <bool DUMP>
+int launch_coarse_fp8s(const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
+    static bool attr_set = false;
+    auto kern = coarse_fp8s_kernel<DUMP>;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
 int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStream_t s) {
     if (dtype == CGV_DTYPE_BF16)
         return dump ? launch_coarse_t<DT_BF16, true>(a, W, s) : launch_coarse_t<DT_BF16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP16)
         return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
-    if (dtype == CGV_DTYPE_FP8E4M3)
-        return dump ? launch_coarse_t<DT_FP8, true>(a, W, s) : launch_coarse_t<DT_FP8, false>(a, W, s);
+    if (dtype == CGV_DTYPE_FP8E4M3) {
+        // block-scaled K=64 MFMA kernel; CGV_FP8_NONSCALED=1 selects the v_mfma_f32_32x32x16_fp8_fp8
+        // variant of the generic kernel (same results; kept for A/B timing)
+        static const bool nonscaled = getenv("CGV_FP8_NONSCALED") && atoi(getenv("CGV_FP8_NONSCALED")) != 0;
+        if (nonscaled) return dump ? launch_coarse_t<DT_FP8, true>(a, W, s) : launch_coarse_t<DT_FP8, false>(a, W, s);
+        return dump ? launch_coarse_fp8s<true>(a, W, s) : launch_coarse_fp8s<false>(a, W, s);
+    }
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 

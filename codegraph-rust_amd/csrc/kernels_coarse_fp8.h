@@ -1,0 +1,245 @@
+// kernels_coarse_fp8.h — the coarse kernel for fp8 (e4m3) corpora on the gfx950 block-scaled MFMA
+// v_mfma_scale_f32_32x32x64_f8f6f4 (both scales 2^0): K = 64 per instruction at twice the FLOP rate
+// of the bf16 / non-scaled fp8 MFMA (MI355X_MICROARCH.md: ~5 PF dense). Same tile, ring, barrier and
+// epilogue as coarse_kernel (kernels_coarse.h); what changes is the fragment pipeline:
+//   * one pipeline stage (a 64-byte K chunk) is exactly ONE K=64 MFMA per 32x32 block: a lane's
+//     operand is its row's 32 bytes of the chunk half lane>>5, i.e. two 16-byte LDS pieces;
+//   * a full fragment set would be 48 VGPRs and cannot be double-buffered next to 128 accumulators,
+//     so a stage runs as two phases of 4 MFMAs: phase 1 = rows 0-63 of the wave tile (A01) x B,
+//     phase 2 = rows 64-127 (A23) x B. A01/A23 are single-buffered (each is reloaded while the other
+//     phase's MFMAs run), B is double-buffered by stage parity (the loop body is two stages).
+// Any K permutation inside the instruction is harmless: A and B use the same one.
+#pragma once
+#include "kernels_coarse.h"
+
+namespace cgv {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+struct Fp8Frag {
+    i32x4_t p0, p1;  // the two 16-byte pieces of this lane's 32 bytes
+};
+
+__device__ inline f32x16_t mma_fp8_k64(const Fp8Frag& a, const Fp8Frag& b, f32x16_t c) {
+    const i32x8_t av = __builtin_shufflevector(a.p0, a.p1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8_t bv = __builtin_shufflevector(b.p0, b.p1, 0, 1, 2, 3, 4, 5, 6, 7);
+    // cbsz = blgp = 0: both operands OCP e4m3; E8M0 scale 0x7F = 2^0 for every 32-element block
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+template <bool DUMP>
+__global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
+    constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
+    constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
+    constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
+    constexpr int NSTAGE = 4, NINV = 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
+    float* invn_s = (float*)(smem + NSTAGE * STAGE + BN * 4);
+    float* stat_s = invn_s + NINV * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const uint32_t W = gridDim.x;
+    uint32_t g = blockIdx.x;
+    if ((W & 7u) == 0) g = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
+    const uint32_t qt = g % a.nqt, split = g / a.nqt;
+
+    for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+
+    float tauv[NB], tq[NB], invq[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const bool valid = q < a.nq;
+        const float tau = valid ? a.tau[q] : INFINITY;
+        const float iq = valid ? a.invn_q[q] : 0.0f;  // fp8 is cosine-only
+        tauv[nb] = tau;
+        invq[nb] = iq;
+        tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
+    }
+
+    const uint32_t jlo = (uint32_t)(((uint64_t)split * a.cnt) / a.nsplit);
+    const uint32_t jhi = (uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit);
+    const uint32_t KC = a.kc;
+    const uint32_t total = (jhi - jlo) * KC;
+    const uint32_t t_first = (total > 0) ? stage_tile(a.T1, a.R, a.P, a.j0 + jlo) - a.T1 : 0u;
+    auto next_tile = [&](uint32_t t) {
+        const uint32_t u = t + a.P;
+        return u >= a.R ? u - a.R : u;
+    };
+
+    // ---- DMA issue side: identical to coarse_kernel (endless stream, one instruction at a time) ----
+    const uint32_t slab = (uint32_t)wave * 2048u + (uint32_t)lane * 16u;
+    const char* bq = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES + slab;
+    const char* atile = a.rows + slab;
+    uint32_t lj = 0, lkc = 0, issued = 0, lt = t_first;
+    const char* acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+    auto issue_q = [&](int q) {
+        char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
+        const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
+        if (q == 0) {
+            if (lkc == 0 && issued < total) {
+                if (wave == 0)
+                    glds16((const char*)a.invn_c + (uint64_t)(a.T1 + lt) * 1024 + lane * 16,
+                           (char*)(invn_s + (lj & (NINV - 1)) * 256));
+                if (wave == 1 && lane < 4) {
+                    const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + lt) * 8 + (lane & 1) * 4;
+                    glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
+                }
+            }
+            glds16(acur + koff, dst);
+        } else if (q == 1) {
+            glds16(acur + koff + 1024, dst + 1024);
+        } else if (q == 2) {
+            glds16(bq + koff, dst + A_BYTES);
+        } else {
+            glds16(bq + koff + 1024, dst + A_BYTES + 1024);
+            ++issued;
+            if (issued < total && ++lkc == KC) {
+                lkc = 0;
+                ++lj;
+                lt = next_tile(lt);
+                acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+            }
+        }
+    };
+
+    if (total == 0) {
+        for (int i = tid; i < BN; i += NT) a.cand_cnt[(uint64_t)g * BN + i] = 0;
+        return;
+    }
+
+    // fragment read offsets: row r = base32 + (lane&31); this lane's 32 bytes are pieces 2h, 2h+1 of
+    // the chunk (h = lane>>5), stored at slots piece ^ ((r>>2)&3)
+    const uint32_t key = (uint32_t)(lane >> 2) & 3u, h2 = (uint32_t)(lane >> 5) * 2u;
+    const uint32_t xo0 = ((h2 ^ key) << 4), xo1 = (((h2 + 1u) ^ key) << 4);
+    const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 64;
+    const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 64;
+
+    f32x16_t acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    Fp8Frag fa01[2], fa23[2], fbx[2], fby[2];
+#define F8_LOAD(F, BASE, OFF)                                  \
+    {                                                          \
+        F.p0 = *(const i32x4_t*)((BASE) + (OFF) + xo0);        \
+        F.p1 = *(const i32x4_t*)((BASE) + (OFF) + xo1);        \
+    }
+#define F8_LOAD_A01(BASE) { F8_LOAD(fa01[0], BASE, aoff); F8_LOAD(fa01[1], BASE, aoff + 32 * 64); }
+#define F8_LOAD_A23(BASE) { F8_LOAD(fa23[0], BASE, aoff + 64 * 64); F8_LOAD(fa23[1], BASE, aoff + 96 * 64); }
+#define F8_LOAD_B(FB, BASE) { F8_LOAD(FB[0], BASE, boff); F8_LOAD(FB[1], BASE, boff + 32 * 64); }
+#define F8_SB __builtin_amdgcn_sched_barrier(0)
+#define F8_EPILOGUE()                                                                                          \
+    {                                                                                                          \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
+                                                      invn_s + (pj & (NINV - 1)) * 256,                        \
+                                                      stat_s + (pj & (NINV - 1)) * 16);                        \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)    \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;                              \
+    }
+// One stage s (fragments A01(s) in fa01, B(s) in BC already loaded). BN_ receives B(s+1).
+//   phase 1: 4 MFMAs A01 x BC; A23(s) is read behind the first one; DMA quarters 2,3 of stage s+3
+//   phase 2: 4 MFMAs A23 x BC; behind the first one: wait for my share of stage s+1, barrier, read
+//            A01(s+1) and B(s+1); DMA quarters 0,1 of stage s+4. Then the tile epilogue if s ended a tile.
+#define F8_STAGE(BC, BN_, SB, SNEXT)                                                             \
+    {                                                                                            \
+        F8_SB;                                                                                   \
+        acc[0][0] = mma_fp8_k64(fa01[0], BC[0], acc[0][0]);                                      \
+        F8_SB;                                                                                   \
+        F8_LOAD_A23(SB);                                                                         \
+        F8_SB;                                                                                   \
+        acc[0][1] = mma_fp8_k64(fa01[0], BC[1], acc[0][1]);                                      \
+        F8_SB;                                                                                   \
+        issue_q(2);                                                                              \
+        F8_SB;                                                                                   \
+        acc[1][0] = mma_fp8_k64(fa01[1], BC[0], acc[1][0]);                                      \
+        F8_SB;                                                                                   \
+        issue_q(3);                                                                              \
+        F8_SB;                                                                                   \
+        acc[1][1] = mma_fp8_k64(fa01[1], BC[1], acc[1][1]);                                      \
+        F8_SB;                                                                                   \
+        acc[2][0] = mma_fp8_k64(fa23[0], BC[0], acc[2][0]);                                      \
+        F8_SB;                                                                                   \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                            \
+        F8_SB;                                                                                   \
+        F8_LOAD_A01(SNEXT);                                                                      \
+        F8_LOAD_B(BN_, SNEXT);                                                                   \
+        F8_SB;                                                                                   \
+        acc[2][1] = mma_fp8_k64(fa23[0], BC[1], acc[2][1]);                                      \
+        F8_SB;                                                                                   \
+        issue_q(0);                                                                              \
+        F8_SB;                                                                                   \
+        acc[3][0] = mma_fp8_k64(fa23[1], BC[0], acc[3][0]);                                      \
+        F8_SB;                                                                                   \
+        issue_q(1);                                                                              \
+        F8_SB;                                                                                   \
+        acc[3][1] = mma_fp8_k64(fa23[1], BC[1], acc[3][1]);                                      \
+        F8_SB;                                                                                   \
+        if (++ckc == KC) {                                                                       \
+            ckc = 0;                                                                             \
+            ptile = a.T1 + ct;                                                                   \
+            pj = cj;                                                                             \
+            ++cj;                                                                                \
+            ct = next_tile(ct);                                                                  \
+            if (done < total) F8_EPILOGUE();                                                     \
+        }                                                                                        \
+        ++done;                                                                                  \
+    }
+
+    // ---- prologue: stages 0..2 in flight, stage 0 landed, first fragments, stage 3 half issued ----
+#pragma unroll 1
+    for (int i = 0; i < NSTAGE - 1; ++i) {
+        issue_q(0);
+        issue_q(1);
+        issue_q(2);
+        issue_q(3);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    F8_LOAD_A01(smem);
+    F8_LOAD_B(fbx, smem);
+    issue_q(0);
+    issue_q(1);
+
+    // Stages are processed in pairs (B double-buffered by parity). When `total` is odd the last pair's
+    // second stage is a dummy: it multiplies the re-read tail of the DMA stream into accumulators that
+    // were already consumed by the last tile's epilogue (tiles end exactly at stage total-1).
+    uint32_t cj = 0, ckc = 0, ct = t_first, ptile = 0, pj = 0, done = 0;
+#pragma unroll 1
+    for (uint32_t s = 0; s < total; s += 2) {
+        const char* s0 = smem + (s & (NSTAGE - 1)) * STAGE;
+        const char* s1 = smem + ((s + 1) & (NSTAGE - 1)) * STAGE;
+        const char* s2 = smem + ((s + 2) & (NSTAGE - 1)) * STAGE;
+        F8_STAGE(fbx, fby, s0, s1);
+        F8_STAGE(fby, fbx, s1, s2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the DMA tail before the LDS is released
+#undef F8_STAGE
+#undef F8_EPILOGUE
+#undef F8_SB
+#undef F8_LOAD_B
+#undef F8_LOAD_A23
+#undef F8_LOAD_A01
+#undef F8_LOAD
+
+    __syncthreads();
+    for (int i = tid; i < BN; i += NT) {
+        const uint32_t c = cntq[i];
+        a.cand_cnt[(uint64_t)g * BN + i] = c < CAND_CAPS ? c : CAND_CAPS;
+    }
+}
+
+}  // namespace cgv
