@@ -8,7 +8,11 @@ brute-force cosine kNN at BASELINE.json config C2 (1M x 768 bf16, batch = 1024, 
    per-shard partial top-k are combined with one RCCL all-gather + a merge kernel.)
 
 A "step" is one batched search (1024 queries against the whole corpus) with corpus AND
-queries already resident in HBM. Rank 0 prints ONE JSON line.
+queries already resident in HBM. `--depth` (default 2) batches are kept in flight through the
+library's search-context pool (each batch on its own HIP stream); all K steps are begun and
+completed inside the timed region. Rank 0 prints ONE JSON line.
+Other workloads (--workload): c4, c3shard, c5shard, c5mini, c2shard8, small — parity / sizing
+cases of BASELINE.json, not the headline line.
 
   roofline     : the dominant kernel (MFMA coarse GEMM with fused top-k') — algorithmic
                  FLOPs 2*B*rows*D of one launch / its HIP-event duration (events recorded by
@@ -79,8 +83,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly serial steps)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 = skip)")
-    ap.add_argument("--cpu-max-queries", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--cpu-max-queries", type=int, default=128)
     args = ap.parse_args()
 
     n_total, dim, dtype, metric, batch, k = WORKLOADS[args.workload]

@@ -38,6 +38,14 @@ class _OracleShard:
                 idx[i], sc[i] = np.uint64(2**64 - 1), -np.inf
         return torch.from_numpy(idx.view(np.int64)), torch.from_numpy(sc)
 
+    def search_begin(self, queries, k):   # same shape as HipKnnIndex.search_begin -> PendingSearch
+        outer = self
+
+        class _P:
+            def wait(self_inner):
+                return outer.search(queries, k)
+        return _P()
+
 
 def _oracle_merge(g_idx, g_score):
     from oracle import oracle as o
@@ -65,6 +73,13 @@ def _worker(rank, world, port, n, d, nq, k, out):
     lo, hi = m.shard_range(n, rank, world)
     sh = m.ShardedKnn(_OracleShard(rows[lo:hi], lo), merge=_oracle_merge)
     idx, sc = sh.search(torch.from_numpy(queries), k)
+    # the pipelined form bench.py drives (two batches begun before the first is awaited)
+    p1 = sh.search_begin(torch.from_numpy(queries), k)
+    p2 = sh.search_begin(torch.from_numpy(queries[::-1].copy()), k)
+    i1, s1 = p1.wait()
+    i2, s2 = p2.wait()
+    assert torch.equal(i1, idx) and torch.equal(s1, sc)
+    assert torch.equal(i2, torch.flip(idx, dims=[0])) and torch.equal(s2, torch.flip(sc, dims=[0]))
     if rank == 0:
         np.save(out + ".idx.npy", idx.numpy().view(np.uint64))
         np.save(out + ".sc.npy", sc.numpy())
