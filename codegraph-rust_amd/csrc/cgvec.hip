@@ -362,7 +362,7 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
 }
 
 int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
-                  const float* dense, uint32_t n_dense, hipStream_t s) {
+                  const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0) {
     SelectArgs sa;
     sa.cand = c->cand.as<uint2>();
     sa.cand_cnt = c->candcnt.as<uint32_t>();
@@ -382,6 +382,14 @@ int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
     sa.lds_keys = dense ? next_pow2(kprime + n_dense) : SELECT_LDS_KEYS;
     if (sa.lds_keys > SELECT_LDS_KEYS) sa.lds_keys = SELECT_LDS_KEYS;
     if (dense && n_dense <= 4096 && kprime <= 64) sa.lds_keys = 0;  // boot stage: register-only path
+    // Candidate stages: size the key buffer from the planner's expected per-query count (x8 head room,
+    // >= 1024 keys) instead of always 64 KiB: at <= 16 KiB the workgroup fits beside a coarse
+    // workgroup of the NEXT batch (141 KB of the CU's 160 KB), so the two overlap. More candidates
+    // than the buffer holds only flags the query for the exact path (correct, slower).
+    if (!dense && expected > 0) {
+        const uint64_t want = next_pow2((uint32_t)std::min<uint64_t>(8 * expected + kprime, SELECT_LDS_KEYS));
+        sa.lds_keys = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1024), SELECT_LDS_KEYS);
+    }
     const size_t lds = (size_t)sa.lds_keys * 8 + ((size_t)nsplit + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -633,7 +641,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                 c->timed_coarse = true;
                 c->coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
-            if ((rc = launch_select(c, nq, nqt, a.nsplit, kprime, nullptr, 0, s))) return rc;
+            // expected emissions per query of this launch: k' * rows / rows seen before it
+            const uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)p.T1 + j0) + 1;
+            if ((rc = launch_select(c, nq, nqt, a.nsplit, kprime, nullptr, 0, s, expected))) return rc;
             j0 += cnt;
         }
         RescoreArgs r;
@@ -665,7 +675,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
-            const size_t budget = 48 * 1024;  // LDS for staged rows
+            // LDS for staged rows: small enough (with the query row) to fit beside a coarse workgroup of the
+            // next batch in flight; k' candidates then take one or two passes
+            const size_t budget = 15 * 1024;
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
             const size_t lds = rowb + (size_t)rpb * pitch;
