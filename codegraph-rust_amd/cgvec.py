@@ -90,6 +90,10 @@ def lib():
     L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
     L.cgv_normalize_rows_f32.argtypes = [i32, vp, u64, u32]
     L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.cgv_packed_width.argtypes = [u32]
+    L.cgv_packed_width.restype = u32
+    L.cgv_pack_topk_dev.argtypes = [i32, vp, vp, u32, u32, vp, vp]
+    L.cgv_merge_packed_dev.argtypes = [i32, vp, u32, u32, u32, vp, vp, vp]
     L.cgv_set_stream.argtypes = [vp, vp]
     L.cgv_use_own_stream.argtypes = [vp]
     L.cgv_synchronize.argtypes = [vp]
@@ -97,7 +101,7 @@ def lib():
     L.cgv_set_profiling.argtypes = [vp, i32]
     L.cgv_set_force_exact.argtypes = [vp, i32]
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
-    for name in ("cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
+    for name in ("cgv_pack_topk_dev", "cgv_merge_packed_dev", "cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
                  "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
@@ -359,4 +363,32 @@ def merge_topk(idx, score, device=None):
     stream = torch.cuda.current_stream(idx.device).cuda_stream
     _check(lib().cgv_merge_topk_dev(device, C.c_void_p(idx.data_ptr()), C.c_void_p(score.data_ptr()), g, nq, k,
                                     C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(stream)))
+    return oi, os_
+
+
+def packed_width(k):
+    return int(lib().cgv_packed_width(int(k)))
+
+
+def pack_topk(idx, score):
+    """[nq, k] CUDA results -> one int32 record buffer [nq, packed_width(k)] (ids | scores)."""
+    import torch
+    nq, k = idx.shape
+    rec = torch.empty((nq, packed_width(k)), dtype=torch.int32, device=idx.device)
+    stream = torch.cuda.current_stream(idx.device).cuda_stream
+    _check(lib().cgv_pack_topk_dev(idx.device.index or 0, C.c_void_p(idx.contiguous().data_ptr()),
+                                   C.c_void_p(score.contiguous().data_ptr()), nq, k, C.c_void_p(rec.data_ptr()),
+                                   C.c_void_p(stream)))
+    return rec
+
+
+def merge_packed(gathered, k):
+    """[g, nq, packed_width(k)] int32 (the all-gather output) -> merged ([nq, k] int64 ids, f32 scores)."""
+    import torch
+    g, nq, _ = gathered.shape
+    oi = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    stream = torch.cuda.current_stream(gathered.device).cuda_stream
+    _check(lib().cgv_merge_packed_dev(gathered.device.index or 0, C.c_void_p(gathered.data_ptr()), g, nq, k,
+                                      C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(stream)))
     return oi, os_

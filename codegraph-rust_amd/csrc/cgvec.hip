@@ -1360,8 +1360,38 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
     if ((uint64_t)g * k > 4096) return fail(CGV_ERR_INVALID_ARG, "g*k exceeds 4096");
     HIPCHK(hipSetDevice(device_id));
     const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream, idx_dev,
-                       score_dev, g, nq, k, out_idx_dev, out_score_dev);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream,
+                       (const char*)idx_dev, (uint64_t)k * 8, (const char*)score_dev, (uint64_t)k * 4, g, nq, k,
+                       out_idx_dev, out_score_dev);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+uint32_t cgv_packed_width(uint32_t k) { return packed_width(k); }
+
+int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t nq, uint32_t k,
+                      uint32_t* out_rec_dev, void* stream) {
+    if (nq == 0 || k == 0) return CGV_OK;
+    if (!idx_dev || !score_dev || !out_rec_dev) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    HIPCHK(hipSetDevice(device_id));
+    const uint64_t total = (uint64_t)nq * packed_width(k);
+    hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)std::min<uint64_t>(1024, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, idx_dev, score_dev, nq, k, out_rec_dev);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
+int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
+                         uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
+    if (nq == 0 || k == 0) return CGV_OK;
+    if (!rec_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
+    if ((uint64_t)g * k > 4096) return fail(CGV_ERR_INVALID_ARG, "g*k exceeds 4096");
+    HIPCHK(hipSetDevice(device_id));
+    const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
+    const uint64_t stride = (uint64_t)packed_width(k) * 4;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream,
+                       (const char*)rec_dev, stride, (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k,
+                       out_idx_dev, out_score_dev);
     HIPCHK(hipGetLastError());
     return CGV_OK;
 }

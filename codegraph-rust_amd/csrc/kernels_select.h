@@ -382,12 +382,34 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     }
 }
 
+// Per-shard results -> one packed record row per query for the single all-gather of SURVEY.md §8(e):
+// w int32 per query = k u64 ids | k f32 scores | (k odd: one pad word, keeps the next row 8-byte aligned).
+__host__ __device__ inline uint32_t packed_width(uint32_t k) { return 3u * k + (k & 1u); }
+__global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ score, uint32_t nq,
+                                 uint32_t k, uint32_t* __restrict__ out) {
+    const uint32_t w = packed_width(k);
+    const uint64_t total = (uint64_t)nq * w;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = (uint32_t)(i / w), c = (uint32_t)(i % w);
+        uint32_t v = 0u;
+        if (c < 2 * k) {
+            const uint64_t id = idx[(uint64_t)q * k + (c >> 1)];
+            v = (c & 1u) ? (uint32_t)(id >> 32) : (uint32_t)id;
+        } else if (c < 3 * k) {
+            v = __float_as_uint(score[(uint64_t)q * k + (c - 2 * k)]);
+        }
+        out[i] = v;
+    }
+}
+
 // Merge G partial top-k lists per query (after the all-gather of per-shard results,
 // SURVEY.md §8(e)). Input [g][nq][k]; one workgroup per query; G*k <= 4096.
-__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restrict__ idx,
-                                                         const float* __restrict__ score, uint32_t G,
-                                                         uint32_t nq, uint32_t k,
-                                                         uint64_t* __restrict__ out_idx,
+// (rank g, query q) lists are addressed as base + (g*nq + q) * stride bytes, so the same kernel reads
+// separate [g][nq][k] id / score arrays or the packed records of the all-gather (pack_topk_kernel).
+__global__ __launch_bounds__(256) void merge_topk_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
+                                                         const char* __restrict__ score_base,
+                                                         uint64_t score_stride, uint32_t G, uint32_t nq,
+                                                         uint32_t k, uint64_t* __restrict__ out_idx,
                                                          float* __restrict__ out_score) {
     // Global ids are 64-bit, so sort (ordered score, position) keys and carry the id
     // through the position; ties on score are resolved by a second pass on the id.
@@ -402,8 +424,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restr
         uint64_t key = 0ull, id = UINT64_MAX;
         if (i < M) {
             const uint32_t gi = i / k, j = i % k;
-            id = idx[((uint64_t)gi * nq + q) * k + j];
-            const float s = score[((uint64_t)gi * nq + q) * k + j];
+            id = *(const uint64_t*)(idx_base + ((uint64_t)gi * nq + q) * idx_stride + (uint64_t)j * 8);
+            const float s = *(const float*)(score_base + ((uint64_t)gi * nq + q) * score_stride + (uint64_t)j * 4);
             if (id != UINT64_MAX) key = make_key(s, i);
         }
         keys[i] = key;

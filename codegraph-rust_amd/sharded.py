@@ -30,6 +30,7 @@ class ShardedKnn:
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
+        self._device_merge = merge is None   # default: packed records + the HIP merge kernel
         if merge is None:
             from .cgvec import merge_topk
             merge = merge_topk
@@ -54,8 +55,14 @@ class ShardedKnn:
         if self.world == 1:
             return idx, score
         nq = idx.shape[0]
-        # ONE all-gather of nq*k packed 12-byte records (8 B id + 4 B score) per rank:
+        # ONE all-gather of nq packed records (k u64 ids + k f32 scores, 12 B per hit) per rank:
         # latency-bound (<= 1 MiB per rank at nq=8192, k=10), so a single collective.
+        if idx.is_cuda and self._device_merge:
+            from .cgvec import merge_packed, pack_topk
+            rec = pack_topk(idx, score)                       # one kernel instead of cat + 2 slice copies
+            gathered = torch.empty((self.world,) + tuple(rec.shape), dtype=torch.int32, device=rec.device)
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+            return merge_packed(gathered, k)
         rec = torch.cat([idx.contiguous().view(torch.int32).reshape(nq, 2 * k),
                          score.contiguous().view(torch.int32).reshape(nq, k)], dim=1).contiguous()
         gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=rec.device)

@@ -193,6 +193,16 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
                        uint32_t nq, uint32_t k, uint64_t* out_idx_dev, float* out_score_dev,
                        void* stream);
 
+/* The same exchange with ONE packed buffer per rank (what sharded.py all-gathers): cgv_pack_topk_dev
+ * writes, per query, cgv_packed_width(k) = 3k (+1 if k is odd) int32 words: k u64 ids | k f32 scores;
+ * cgv_merge_packed_dev merges g such buffers laid out [g][nq][width] (the all-gather output) with
+ * (score desc, id asc). Saves the concatenate / slice copies around the collective. */
+uint32_t cgv_packed_width(uint32_t k);
+int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t nq, uint32_t k,
+                      uint32_t* out_rec_dev, void* stream);
+int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
+                         uint64_t* out_idx_dev, float* out_score_dev, void* stream);
+
 /* Run this handle's work on an external hipStream_t (e.g. PyTorch's current stream).
  * The value is used as-is: NULL is HIP's legacy default ("null") stream — which is what
  * PyTorch uses unless told otherwise — NOT "no stream". */

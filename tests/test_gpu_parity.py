@@ -494,3 +494,31 @@ def test_batches_in_flight_and_concurrent_callers(oracle):
         assert np.array_equal(gi2, ri2) and np.array_equal(gs2, rs2)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("k", [10, 7])
+def test_packed_exchange_kernels(oracle, k):
+    """cgv_pack_topk_dev + cgv_merge_packed_dev (the sharded path's single all-gather buffer) against the
+    oracle's merge, including padding entries, cross-shard ties and an odd k (padded record rows)."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(k)
+    g, nq = 4, 33
+    idx = rng.integers(0, 1 << 40, (g, nq, k)).astype(np.uint64)
+    sc = np.sort(rng.standard_normal((g, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    sc[1, :, 0] = sc[0, :, 0]                       # cross-shard score ties -> id ascending
+    idx[2, 5, k - 3:] = np.uint64(2**64 - 1)        # a short shard: padding entries
+    sc[2, 5, k - 3:] = -np.inf
+    recs = []
+    for r in range(g):
+        ti = torch.from_numpy(idx[r].view(np.int64)).cuda()
+        ts = torch.from_numpy(sc[r]).cuda()
+        rec = m.cgvec.pack_topk(ti, ts)
+        assert rec.shape == (nq, m.cgvec.packed_width(k)) and m.cgvec.packed_width(k) % 2 == 0
+        recs.append(rec)
+    oi, os_ = m.cgvec.merge_packed(torch.stack(recs).contiguous(), k)
+    oi2, os2 = m.merge_topk(torch.from_numpy(idx.view(np.int64)).cuda(), torch.from_numpy(sc).cuda())
+    for q in range(nq):
+        ri, rs = oracle.merge_topk(idx[:, q, :], sc[:, q, :], k)
+        assert np.array_equal(oi[q].cpu().numpy().view(np.uint64), ri) and np.array_equal(os_[q].cpu().numpy(), rs)
+    assert torch.equal(oi, oi2) and torch.equal(os_, os2)

@@ -159,3 +159,45 @@ def test_semantic_hybrid_and_multi_vector(oracle):
     assert [g[0] for g in got] == [e[0] for e in exp]
     assert st.multi_vector_search(np.zeros((0, 128), np.float32), 0, None, 5) == []
     st.close()
+
+
+def test_sharded_device_exchange_single_process(oracle, monkeypatch):
+    """The device branch of ShardedKnn._exchange (pack -> ONE all-gather -> merge_packed) with the
+    collective replaced by an in-process stand-in: two row shards on one GPU, results must equal the
+    oracle's search over the whole corpus. (RCCL itself needs >1 GPU: the driver's --gpus N runs.)"""
+    import importlib
+    import torch
+    m = pkg()
+    sharded = importlib.import_module("codegraph-rust_amd.sharded")
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 9001, 96, 40, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[17] = rows[n - 5]                           # cross-shard tie
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    shards = []
+    for r in range(2):
+        lo, hi = m.shard_range(n, r, 2)
+        ix = m.HipKnnIndex(d, dtype="bf16")
+        ix.add(rows[lo:hi])
+        ix.set_index_base(lo)
+        shards.append(ix)
+    try:
+        qd = torch.from_numpy(q).cuda()
+        peer = {}
+
+        def fake_all_gather(out, rec, group=None):   # rank 0's view: [its own records, the peer's]
+            out[0].copy_(rec)
+            out[1].copy_(peer["rec"])
+        monkeypatch.setattr(sharded.dist, "all_gather_into_tensor", fake_all_gather)
+        pi, ps = shards[1].search(qd, k)
+        peer["rec"] = m.cgvec.pack_topk(pi, ps)
+        sk = m.ShardedKnn(shards[0], rank=0, world=2)
+        idx, sc = sk.search(qd, k)
+        pend = sk.search_begin(qd, k)                # pipelined form
+        idx2, sc2 = pend.wait()
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+        assert np.array_equal(idx.cpu().numpy().view(np.uint64), ri) and np.array_equal(sc.cpu().numpy(), rs)
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+    finally:
+        for ix in shards:
+            ix.close()
