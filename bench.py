@@ -48,17 +48,21 @@ WORKLOADS = {
     # C5 = 500M x 768 fp8 over 8 GPUs, batch 8192: one GPU's share is 62.5M rows = 48 GB of codes
     "c5shard": (62_500_000, 768, "fp8", "cosine", 8192, 10),
     "c5mini": (4_000_000, 768, "fp8", "cosine", 8192, 10),   # same kernel shape, 1/16 of the shard
+    # C2's shape on UNROUNDED f32 rows (results = the reference's own f32 arithmetic): f32 + bf16 shadow
+    "c2f32": (1_000_000, 768, "f32s", "cosine", 1024, 10),
 }
 CHUNK = 125_000
 # dense MFMA peaks (MI355X_MICROARCH.md); the fp8 path runs on the block-scaled K=64 MFMA (5 PF class)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp8": 5000.0}
-ESIZE = {"bf16": 2, "fp16": 2, "fp8": 1}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp8": 5000.0, "f32s": 2500.0}
+ESIZE = {"bf16": 2, "fp16": 2, "fp8": 1, "f32s": 2}   # bytes per element the coarse kernel streams
 SEED_CORPUS, SEED_QUERY = 0xC0DE6001, 0xC0DE6002
 
 
 def storage_values(x, dtype):
     """f32 values the index scores on (rounded-then-upcast); fp8 = e4m3fn codes
     under the per-row power-of-two scale (largest e with amax * 2^e <= 448)."""
+    if dtype == "f32s":
+        return x
     if dtype == "bf16":
         return x.to(torch.bfloat16).float()
     if dtype == "fp16":

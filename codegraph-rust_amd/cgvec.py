@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcgvec_hip.so")
 
 METRICS = {"cosine": 0, "dot": 1, "cosine_seq": 2}
-DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
+DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3, "f32s": 4}
 
 CGV_OK = 0
 CGV_ERR_INVALID_ARG, CGV_ERR_DIM_MISMATCH, CGV_ERR_HIP, CGV_ERR_OOM = 1, 2, 3, 4

@@ -88,7 +88,7 @@ struct DevBuf {
     }
 };
 
-enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_COUNT = 8 };
+enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_MAXEPS, F_COUNT = 8 };
 
 constexpr int BM = 256, BN = 256;  // coarse tile (corpus rows x queries)
 
@@ -112,7 +112,7 @@ struct SearchCtx {
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres;
     bool busy = false;
     // state of the search in flight (between begin and end)
     uint32_t gen = 0, nq = 0, k = 0;
@@ -124,14 +124,16 @@ struct SearchCtx {
     uint32_t kprime = 0;
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
-                                &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump};
+                                &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
+                                &qshadow, &qres};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
     }
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
-                          &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump};
+                          &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
+                          &qshadow, &qres};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -150,6 +152,12 @@ struct cgv_index {
     float* blk_min = nullptr;
     float* blk_max = nullptr;
     int8_t* rexp = nullptr;       // fp8 only: per-row scale exponent
+    // CGV_DTYPE_F32_SHADOW: dtype == F32 (rows, exact paths) + a bf16 blocked copy for the coarse pass
+    bool shadow = false;
+    char* srows = nullptr;
+    uint32_t lds = 0;             // leading dimension (elements) of the shadow
+    uint32_t* resmax_dev = nullptr;  // [2] max rounding residual over the corpus: relative, absolute (float bits)
+    float res_rel_c = 0.0f, res_abs_c = 0.0f;
     uint32_t* flags = nullptr;    // device, F_COUNT words (ingest side)
     float* max_norm_dev = nullptr;
     uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
@@ -176,8 +184,14 @@ size_t storage_bytes(const cgv_index* h, uint64_t nrows) {
     return (size_t)r * h->ld * h->esize;
 }
 
+size_t shadow_bytes(const cgv_index* h, uint64_t nrows) {
+    const uint64_t r = (nrows + 255) / 256 * 256;
+    return (size_t)r * h->lds * 2;
+}
+
 size_t device_bytes(const cgv_index* h) {
     size_t b = 0;
+    if (h->srows) b += shadow_bytes(h, h->cap);
     if (h->rows) b += storage_bytes(h, h->cap) + (size_t)h->cap * 8 + ((size_t)h->cap / 32 + 1) * 8;
     b += h->addstage.bytes;
     for (const SearchCtx& c : h->ctx) b += c.bytes();
@@ -226,6 +240,12 @@ int grow(cgv_index* h, uint64_t need) {
     HIPCHK(hipMalloc((void**)&bmin, nblk * 4));
     HIPCHK(hipMalloc((void**)&bmax, nblk * 4));
     HIPCHK(hipMalloc((void**)&rexp, ncap));
+    char* srows = nullptr;
+    if (h->shadow) {
+        HIPCHK(hipMalloc((void**)&srows, shadow_bytes(h, ncap)));
+        HIPCHK(hipMemsetAsync(srows, 0, shadow_bytes(h, ncap), h->stream));
+        if (h->n) HIPCHK(hipMemcpyAsync(srows, h->srows, shadow_bytes(h, h->n), hipMemcpyDeviceToDevice, h->stream));
+    }
     if (h->n) {
         HIPCHK(hipMemcpyAsync(rows, h->rows, storage_bytes(h, h->n), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(norm, h->norm, h->n * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -243,7 +263,9 @@ int grow(cgv_index* h, uint64_t need) {
         (void)hipFree(h->blk_min);
         (void)hipFree(h->blk_max);
         (void)hipFree(h->rexp);
+        if (h->srows) (void)hipFree(h->srows);
     }
+    h->srows = srows;
     h->rows = rows;
     h->rexp = rexp;
     h->norm = norm;
@@ -257,15 +279,21 @@ int grow(cgv_index* h, uint64_t need) {
 // Enqueue the ingest of cnt f32 rows (device memory) at absolute rows [row0, row0+cnt): storage
 // conversion, norms, per-32-row-block norm bounds, running max norm. No synchronisation; capacity
 // must already be there. ingest_finish() reads the flags back and publishes the new row count.
-int ingest_enqueue(cgv_index* h, const float* rows_dev, uint64_t cnt, uint64_t row0) {
+int ingest_enqueue(cgv_index* h, const float* rows_dev, uint64_t cnt, uint64_t row0, uint64_t n_valid = 0) {
     hipStream_t s = h->stream;
     int rc = prep_dispatch(h->dtype, rows_dev, cnt, h->D, h->ld, row0, h->rows, h->norm, h->invn, h->rexp,
                            h->flags + F_NONFINITE_C, s);
     if (rc) return rc;
+    if (h->shadow) {  // second pass: bf16 copy, ITS norms (the coarse pass works on it), rounding residuals
+        hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, s, rows_dev, cnt, h->D, h->lds,
+                           row0, h->srows, h->norm, h->invn, (float*)nullptr, h->resmax_dev);
+        HIPCHK(hipGetLastError());
+    }
     const uint64_t n_new = row0 + cnt;
+    if (n_valid < n_new) n_valid = n_new;  // rows that exist once this ingest is done (update_row: unchanged count)
     const uint64_t b0 = row0 / 32, b1 = (n_new + 31) / 32;
     hipLaunchKernelGGL(block_norm_stats_kernel, dim3((unsigned)((b1 - b0 + 255) / 256)), dim3(256), 0, s,
-                       h->norm, n_new, b0, b1, h->blk_min, h->blk_max);
+                       h->norm, n_valid, b0, b1, h->blk_min, h->blk_max);
     hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, row0, n_new, h->max_norm_dev);
     HIPCHK(hipGetLastError());
     return CGV_OK;
@@ -275,9 +303,14 @@ int ingest_finish(cgv_index* h, uint64_t n_new) {
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
+    if (h->shadow) HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT + 1, h->resmax_dev, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     h->n = n_new;
     memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
+    if (h->shadow) {
+        memcpy(&h->res_rel_c, h->h_flags + F_COUNT + 1, 4);
+        memcpy(&h->res_abs_c, h->h_flags + F_COUNT + 2, 4);
+    }
     if (h->h_flags[F_NONFINITE_C]) {
         h->corpus_nonfinite = true;
         return fail(CGV_ERR_NONFINITE,
@@ -528,9 +561,10 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
 template <int DT>
 void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, hipStream_t s) {
     const uint32_t nrb = (n_boot + 63) / 64, nqb = (nq + 63) / 64;
-    hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s, (const char*)h->rows,
-                       (const char*)c->qrows.p, (const float*)h->invn, (const float*)c->qinvn.p, n_boot, nq, h->ld,
-                       h->metric, dense);
+    hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s,
+                       (const char*)(h->shadow ? h->srows : h->rows),
+                       (const char*)(h->shadow ? c->qshadow.p : c->qrows.p), (const float*)h->invn,
+                       (const float*)c->qinvn.p, n_boot, nq, h->shadow ? h->lds : h->ld, h->metric, dense);
 }
 
 // Enqueue one batch on the context's stream (no host synchronisation); search_finish() completes it.
@@ -576,9 +610,19 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                        c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s,
                        c->nbest.as<uint32_t>(), c->overflow.as<uint32_t>());  // also clears nbest / overflow
     if (rc) return rc;
+    if (h->shadow) {  // bf16 copy of the queries + their rounding residuals
+        if ((rc = c->qshadow.ensure(shadow_bytes(h, nq)))) return rc;
+        if ((rc = c->qres.ensure((size_t)nq * 8))) return rc;
+        hipLaunchKernelGGL(shadow_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, qdev, (uint64_t)nq, h->D, h->lds,
+                           (uint64_t)0, c->qshadow.as<char>(), c->qnorm.as<float>(), c->qinvn.as<float>(),
+                           c->qres.as<float>(), (uint32_t*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
 
-    const uint32_t kprime = kprime_of(k);
-    const bool mfma = !h->force_exact && h->dtype != CGV_DTYPE_F32 && kprime <= CAND_CAPS;
+    // f32 + shadow: the coarse scores carry bf16 rounding error (~2e-3), so more candidates are re-scored
+    const uint32_t kprime = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
+    const bool mfma = !h->force_exact && (h->dtype != CGV_DTYPE_F32 || h->shadow) && kprime <= CAND_CAPS &&
+                      (!h->shadow || k <= 60);
     c->mfma = mfma;
     c->kprime = mfma ? kprime : 0u;
 
@@ -597,7 +641,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         if ((rc = c->dump.ensure((size_t)nq * n_boot * 4))) return rc;
 
         // boot: dense scores of the first n_boot rows -> top-k' -> first tau
-        if (h->dtype == CGV_DTYPE_BF16)
+        if (h->dtype == CGV_DTYPE_BF16 || h->shadow)
             launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), s);
         else if (h->dtype == CGV_DTYPE_FP16)
             launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), s);
@@ -606,9 +650,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         HIPCHK(hipGetLastError());
         if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s))) return rc;
 
+        const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;  // dtype the coarse pass runs in
         CoarseArgs a;
-        a.rows = h->rows;
-        a.qrows = c->qrows.as<char>();
+        a.rows = h->shadow ? h->srows : h->rows;
+        a.qrows = h->shadow ? c->qshadow.as<char>() : c->qrows.as<char>();
         a.invn_c = h->invn;
         a.invn_q = c->qinvn.as<float>();
         a.blk_min = h->blk_min;
@@ -620,8 +665,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.dump = nullptr;
         a.n = (uint32_t)h->n;
         a.nq = nq;
-        a.ld = h->ld;
-        a.kc = h->ld / kchunk_of(h->dtype);
+        a.ld = h->shadow ? h->lds : h->ld;
+        a.kc = a.ld / kchunk_of(cdt);
         a.T1 = p.T1;
         a.R = p.R;
         a.P = p.P;
@@ -635,7 +680,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
             const bool dominant = (st + 1 == p.counts.size());
             if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
-            if ((rc = launch_coarse(h->dtype, false, a, nqt * a.nsplit, s))) return rc;
+            if ((rc = launch_coarse(cdt, false, a, nqt * a.nsplit, s))) return rc;
             if (h->profiling && dominant) {
                 HIPCHK(hipEventRecord(c->ev[2], s));
                 c->timed_coarse = true;
@@ -672,12 +717,17 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         // (the sequential formula of CGV_METRIC_COSINE_SEQ sums D deep in one chain)
         r.eps_scale = ((float)h->D * (h->metric == CGV_METRIC_COSINE_SEQ ? 1.0f : 0.5f) + 64.0f) * 5.9604645e-8f;
         r.max_norm_c = h->max_norm_c;
+        r.qres = h->shadow ? c->qres.as<float>() : nullptr;
+        r.res_rel_c = h->res_rel_c;
+        r.res_abs_c = h->res_abs_c;
+        r.stat_maxeps = c->flags + F_MAXEPS;
+        if (h->shadow) r.eps_scale *= 2.0f;  // two accumulation-order terms: MFMA-on-shadow and the reference on f32
         c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
             // LDS for staged rows: small enough (with the query row) to fit beside a coarse workgroup of the
             // next batch in flight; k' candidates then take one or two passes
-            const size_t budget = 15 * 1024;
+            const size_t budget = h->shadow ? 45 * 1024 : 15 * 1024;  // (the f32 rows of 4k+16 candidates)
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
             const size_t lds = rowb + (size_t)rpb * pitch;
@@ -689,9 +739,13 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_F32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set = true;
             }
-            if (h->dtype == CGV_DTYPE_BF16)
+            if (h->dtype == CGV_DTYPE_F32)
+                hipLaunchKernelGGL(rescore_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, r);
+            else if (h->dtype == CGV_DTYPE_BF16)
                 hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r);
             else if (h->dtype == CGV_DTYPE_FP16)
                 hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r);
@@ -724,6 +778,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         HIPCHK(hipStreamSynchronize(s));
     } else {
         memcpy(&me, &c->h_flags[F_MAXERR], 4);
+        if (h->shadow) memcpy(&c->eps, &c->h_flags[F_MAXEPS], 4);  // largest per-query bound of this batch
         nfb = c->h_flags[F_FB_COUNT];
         if (nfb > 0) {
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
@@ -818,8 +873,10 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (dim == 0 || dim > 8192) return fail(CGV_ERR_INVALID_ARG, "dim must be in 1..=8192");
     if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT && metric != CGV_METRIC_COSINE_SEQ)
         return fail(CGV_ERR_INVALID_ARG, "bad metric");
+    const bool shadow = dtype == CGV_DTYPE_F32_SHADOW;
+    if (shadow) dtype = CGV_DTYPE_F32;  // rows, exact paths and get_row are the f32 index; + a bf16 copy for the coarse pass
     if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16 && dtype != CGV_DTYPE_FP8E4M3)
-        return fail(CGV_ERR_INVALID_ARG, "unknown dtype (f32, bf16, fp16, fp8e4m3)");
+        return fail(CGV_ERR_INVALID_ARG, "unknown dtype (f32, bf16, fp16, fp8e4m3, f32+shadow)");
     if (dtype == CGV_DTYPE_FP8E4M3 && metric == CGV_METRIC_DOT)
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage keeps a per-row scale: cosine only in this build");
     int ndev = cgv_device_count();
@@ -834,13 +891,17 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     h->metric = metric;
     h->dtype = dtype;
     h->esize = esize_of(dtype);
+    h->shadow = shadow;
+    h->lds = (dim + 31) / 32 * 32;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         h->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->flags, F_COUNT * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&h->max_norm_dev, 4);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, (F_COUNT + 1) * 4);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, (F_COUNT + 3) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->resmax_dev, 8);
+    if (e == hipSuccess) e = hipMemset(h->resmax_dev, 0, 8);
     for (SearchCtx& c : h->ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
@@ -872,7 +933,9 @@ int cgv_destroy(cgv_index* h) {
         (void)hipFree(h->blk_min);
         (void)hipFree(h->blk_max);
         (void)hipFree(h->rexp);
+        if (h->srows) (void)hipFree(h->srows);
     }
+    if (h->resmax_dev) (void)hipFree(h->resmax_dev);
     h->addstage.release();
     for (SearchCtx& c : h->ctx) {
         if (c.stream) (void)hipStreamSynchronize(c.stream);
@@ -1112,22 +1175,8 @@ int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     if ((rc = h->addstage.ensure((size_t)h->D * 4))) return rc;
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->addstage.p, row_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
-    rc = prep_dispatch(h->dtype, h->addstage.as<float>(), 1, h->D, h->ld, id, h->rows, h->norm, h->invn, h->rexp,
-                       h->flags + F_NONFINITE_C, s);
-    if (rc) return rc;
-    const uint64_t b0 = id / 32;
-    hipLaunchKernelGGL(block_norm_stats_kernel, dim3(1), dim3(256), 0, s, h->norm, h->n, b0, b0 + 1, h->blk_min,
-                       h->blk_max);
-    hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(1024), 0, s, h->norm, id, id + 1, h->max_norm_dev);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
-    if (h->h_flags[F_NONFINITE_C]) {
-        h->corpus_nonfinite = true;
-        return fail(CGV_ERR_NONFINITE, "row contains NaN/Inf (the reference panics on NaN at simd_ops.rs:379)");
-    }
+    if ((rc = ingest_enqueue(h, h->addstage.as<float>(), 1, id, h->n))) return rc;
+    if ((rc = ingest_finish(h, h->n))) return rc;
     return CGV_OK;
 }
 
@@ -1442,7 +1491,8 @@ int cgv_set_force_exact(cgv_index* h, int enabled) {
 
 int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t nq, float* out_dev) {
     if (!h || !queries_dev || !out_dev) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    if (h->dtype == CGV_DTYPE_F32) return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16/fp8 index");
+    if (h->dtype == CGV_DTYPE_F32 && !h->shadow)
+        return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16/fp8 index or an f32 index with a shadow");
     if (nq == 0 || h->n == 0) return CGV_OK;
     std::unique_lock<std::mutex> lk(h->mu);
     wait_all_idle(h, lk);
@@ -1460,6 +1510,15 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, c->qrows.as<char>(), c->qnorm.as<float>(),
                        c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s);
     if (rc) return rc;
+    if (h->shadow) {
+        if ((rc = c->qshadow.ensure(shadow_bytes(h, nq)))) return rc;
+        if ((rc = c->qres.ensure((size_t)nq * 8))) return rc;
+        hipLaunchKernelGGL(shadow_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, queries_dev, (uint64_t)nq, h->D, h->lds,
+                           (uint64_t)0, c->qshadow.as<char>(), c->qnorm.as<float>(), c->qinvn.as<float>(),
+                           c->qres.as<float>(), (uint32_t*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;
     const uint32_t nqt = (nq + BN - 1) / BN;
     const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
     const uint32_t ntiles = (uint32_t)((h->n + BM - 1) / BM);
@@ -1468,8 +1527,8 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     if ((rc = c->candcnt.ensure((size_t)nqt * nsplit * BN * 4))) return rc;
     hipLaunchKernelGGL(fill_f32_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->tau.as<float>(), -INFINITY, nq);
     CoarseArgs a;
-    a.rows = h->rows;
-    a.qrows = c->qrows.as<char>();
+    a.rows = h->shadow ? h->srows : h->rows;
+    a.qrows = h->shadow ? c->qshadow.as<char>() : c->qrows.as<char>();
     a.invn_c = h->invn;
     a.invn_q = c->qinvn.as<float>();
     a.blk_min = h->blk_min;
@@ -1481,8 +1540,8 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.dump = out_dev;
     a.n = (uint32_t)h->n;
     a.nq = nq;
-    a.ld = h->ld;
-    a.kc = h->ld / kchunk_of(h->dtype);
+    a.ld = h->shadow ? h->lds : h->ld;
+    a.kc = a.ld / kchunk_of(cdt);
     a.T1 = 0;
     a.R = ntiles;
     a.P = 1;
@@ -1491,7 +1550,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.nsplit = nsplit;
     a.nqt = nqt;
     a.metric = h->metric;
-    if ((rc = launch_coarse(h->dtype, true, a, nqt * nsplit, s))) return rc;
+    if ((rc = launch_coarse(cdt, true, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;
 }

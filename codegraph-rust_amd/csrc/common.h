@@ -190,6 +190,12 @@ __device__ inline Row<DT> make_row(const char* base, uint64_t R, uint32_t ld) {
     }
     return r;
 }
+// address of 16-byte piece pc (consecutive along K) of a stored row
+template <int DT>
+__device__ inline const char* piece_ptr(const Row<DT>& r, uint32_t pc) {
+    if (DT == DT_F32) return r.p + (size_t)pc * 16;
+    return r.p + blocked_piece_off(pc, r.key);
+}
 template <int DT>
 __device__ inline char* elem_ptr(char* base, uint64_t R, uint32_t ld, uint32_t i) {
     if (DT == DT_F32) return base + (R * (uint64_t)ld + i) * 4;

@@ -62,6 +62,52 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
 }
 
+// f32 index with a bf16 SHADOW for the coarse pass (CGV_DTYPE_F32_SHADOW): second ingest pass over the
+// same f32 input. Writes the bf16-rounded copy in the blocked layout, the shadow's norm / inverse norm
+// (the coarse pass works on the shadow), and the rounding residual of each row:
+//   abs = |x - x^|,  rel = abs / min(|x|, |x^|)      (x^ = RNE(x) to bf16)
+// which bound how far a coarse score can be from the exact f32 score (kernels_select.h). Per-row values
+// go to res[2*row..] when res != NULL (queries); the maxima over all rows are folded into
+// res_max[0] (rel) and res_max[1] (abs) as non-negative float bits (corpus).
+__global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restrict__ in, uint64_t n, uint32_t D,
+                                                          uint32_t lds, uint64_t row0, char* __restrict__ out,
+                                                          float* __restrict__ norm, float* __restrict__ invn,
+                                                          float* __restrict__ res, uint32_t* __restrict__ res_max) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* src = in + row * (uint64_t)D;
+    float sh = 0.0f, sx = 0.0f, sd = 0.0f;
+    for (uint32_t i = lane; i < lds; i += 64) {
+        const float x = (i < D) ? src[i] : 0.0f;
+        Elem<DT_BF16>::cvt_store(elem_ptr<DT_BF16>(out, row0 + row, lds, i), x);
+        const float xr = Elem<DT_BF16>::round_trip(x), d = x - xr;
+        sh = fmaf(xr, xr, sh);
+        sx = fmaf(x, x, sx);
+        sd = fmaf(d, d, sd);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sh += __shfl_xor(sh, off, 64);
+        sx += __shfl_xor(sx, off, 64);
+        sd += __shfl_xor(sd, off, 64);
+    }
+    if (lane == 0) {
+        const float nh = sqrtf(sh), nx = sqrtf(sx), ra = sqrtf(sd);
+        const float mn = fminf(nh, nx);
+        const float rr = mn > 0.0f ? ra / mn : 0.0f;  // zero rows never become candidates (score 0 via the exact rule)
+        norm[row0 + row] = nh;
+        invn[row0 + row] = nh > 0.0f ? 1.0f / nh : 0.0f;
+        if (res) {
+            res[2 * (row0 + row)] = rr;
+            res[2 * (row0 + row) + 1] = ra;
+        }
+        if (res_max && rr == rr && ra == ra) {  // NaN/Inf rows are rejected by the first pass
+            atomicMax(res_max, __float_as_uint(rr));
+            atomicMax(res_max + 1, __float_as_uint(ra));
+        }
+    }
+}
+
 // Stored row -> f32 (get_embedding); fp8 rows are returned de-scaled (value * 2^-e).
 template <int DT>
 __global__ void gather_row_kernel(const char* __restrict__ rows, uint64_t R, uint32_t D, uint32_t ld,

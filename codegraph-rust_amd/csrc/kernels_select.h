@@ -286,6 +286,11 @@ struct RescoreArgs {
     uint32_t rows_per_batch;  // candidate rows staged in LDS per pass
     float eps_scale;        // cosine: eps; dot: eps = eps_scale * |q| * max|c|
     float max_norm_c;
+    // f32 index with a bf16 shadow (coarse scores come from ROUNDED operands): rounding residuals
+    const float* qres;      // [nq][2]: relative |dq|/min(|q|,|q^|) and absolute |dq| of each query; NULL otherwise
+    float res_rel_c;        // max over the corpus of |dc| / min(|c|, |c^|)
+    float res_abs_c;        // max over the corpus of |dc|
+    uint32_t* stat_maxeps;  // [1] f2ord-free max of the eps actually used (non-negative float bits)
 };
 
 // Exact reference arithmetic on the k' candidates of each query, exact (score desc, row asc)
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     {   // query row -> LDS (linear element order)
         const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
         for (uint32_t pc = tid; pc < pieces; pc += 256)
-            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)(qr.p + blocked_piece_off(pc, qr.key));
+            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)piece_ptr<DT>(qr, pc);
     }
     for (uint32_t c0 = 0; c0 < nb; c0 += a.rows_per_batch) {
         const uint32_t nbat = (nb - c0) < a.rows_per_batch ? (nb - c0) : a.rows_per_batch;
@@ -328,8 +333,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
                 if (e < total) {
                     const uint32_t c = e / pieces, pc = e % pieces;
                     const uint32_t row = key_row(a.best[(uint64_t)q * a.kprime + c0 + c]);
-                    v[i] = *(const uint4*)(a.rows + blocked_row_base(row, a.ld, kchunk_of(DT)) +
-                                           blocked_piece_off(pc, blocked_row_key(row)));
+                    v[i] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pc);
                 }
             }
 #pragma unroll
@@ -374,6 +378,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
             const float ek = key_score(ekeys[kk - 1]);
             float eps = a.eps_scale;
             if (a.metric == METRIC_DOT) eps = a.eps_scale * a.norm_q[q] * a.max_norm_c;
+            if (a.qres) {
+                // |cos(q^,c^) - cos(q,c)| <= |u^-u| + |v^-v| <= res_rel(q) + res_rel(c)   (unit vectors u, v);
+                // |q^.c^ - q.c| <= |dq||c^| + |q||dc|. 1 % head room for the f32 rounding of the residual sums.
+                const float rq_rel = a.qres[2 * q], rq_abs = a.qres[2 * q + 1];
+                if (a.metric == METRIC_DOT)
+                    eps += 1.01f * (rq_abs * a.max_norm_c + (a.norm_q[q] + rq_abs) * a.res_abs_c);
+                else
+                    eps += 1.01f * (rq_rel + a.res_rel_c);
+            }
+            if (a.stat_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
             if (!(ek > tau + eps)) fb = true;
             if (nb < a.k) fb = true;
         }

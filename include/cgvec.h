@@ -53,6 +53,10 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_DTYPE_BF16 1
 #define CGV_DTYPE_FP16 2
 #define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale; cosine metric only */
+#define CGV_DTYPE_F32_SHADOW 4 /* f32 rows (results = the reference's f32 arithmetic on the UNROUNDED inputs, like
+                                  CGV_DTYPE_F32) + a bf16 copy that only feeds the MFMA coarse pass of batched
+                                  searches; the exactness check accounts for the copy's rounding residual. 1.5x
+                                  the memory of CGV_DTYPE_F32, which always takes the exact scan. */
 
 /* status codes */
 #define CGV_OK 0

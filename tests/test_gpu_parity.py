@@ -10,7 +10,7 @@ from _util import pkg
 
 pytestmark = pytest.mark.gpu
 
-ODT = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3}
+ODT = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3, "f32s": 0}   # f32s: f32 rows + bf16 shadow -> f32 oracle
 OMETRIC = {"cosine": 0, "dot": 1, "cosine_seq": 2}
 
 
@@ -48,7 +48,7 @@ def test_device_visible():
     assert pkg().device_count() >= 1
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8", "f32s"])
 @pytest.mark.parametrize("d", [64, 128, 768, 100])
 def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
     """Dense coarse scores of the MFMA kernel vs an fp32 matmul of the rounded inputs
@@ -69,7 +69,7 @@ def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
             r = torch.from_numpy(oracle.round_trip(rows, 3, fp8_codes=True)).double()
             q = torch.from_numpy(oracle.round_trip(queries, 3, fp8_codes=True)).double()
         else:
-            tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+            tdt = torch.float16 if dtype == "fp16" else torch.bfloat16   # f32s: the coarse pass runs on the bf16 shadow
             r = torch.from_numpy(rows).to(tdt).double()
             q = torch.from_numpy(queries).to(tdt).double()
         ref = (q / q.norm(dim=1, keepdim=True)) @ (r / r.norm(dim=1, keepdim=True)).T
@@ -83,12 +83,13 @@ def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
 @pytest.mark.parametrize("dtype,metric", [("bf16", "cosine"), ("fp16", "cosine"), ("bf16", "dot"),
                                           ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot"),
                                           ("fp8", "cosine"), ("bf16", "cosine_seq"), ("f32", "cosine_seq"),
-                                          ("fp8", "cosine_seq")])
+                                          ("fp8", "cosine_seq"), ("f32s", "cosine"), ("f32s", "dot"),
+                                          ("f32s", "cosine_seq")])
 def test_parity_small(oracle, dtype, metric):
     _run(oracle, n=1000, d=256, nq=7, k=10, dtype=dtype, metric=metric)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32", "fp8"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "fp8", "f32s"])
 @pytest.mark.parametrize("d", [8, 31, 33, 37, 100, 384, 1536])
 def test_parity_ragged_dims(oracle, dtype, d):
     """D < 32 takes the reference's scalar branch (simd_ops.rs:281-295); D % 8 != 0 the tail."""
@@ -125,6 +126,43 @@ def test_parity_medium_staged(oracle, dtype, metric):
     assert st["last_path"] == 1
     assert st["fallback_queries"] == 0
     assert st["max_observed_err"] <= st["last_eps"]
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_f32_index_with_bf16_shadow(oracle, metric):
+    """CGV_DTYPE_F32_SHADOW: results are the reference's f32 arithmetic on the UNROUNDED inputs (the same
+    as an f32 index), found through the MFMA coarse pass over a bf16 copy; the guarantee check carries
+    the copy's rounding residual. Staged launches, un-normalised rows, update_row, get_row."""
+    m = pkg()
+    rng = np.random.default_rng(31)
+    n, d, nq, k = 60_000, 384, 200, 10
+    rows = (rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = m.HipKnnIndex(d, metric=metric, dtype="f32s")
+    try:
+        ix.add(rows[:25_000])
+        ix.add(rows[25_000:])
+        idx, sc = ix.search(q, k)
+        _check(oracle, rows, q, k, "f32", metric, idx, sc, "f32 + shadow")
+        st = ix.stats()
+        assert st["last_path"] == 1 and st["last_kprime"] == 56
+        assert st["fallback_queries"] <= nq // 10                     # the bound is loose but not useless
+        assert 0 < st["max_observed_err"] <= st["last_eps"]           # bf16 rounding error, within the bound
+        assert np.array_equal(ix.get_row(4321), rows[4321])           # rows are stored unrounded
+        rows[77] = q[3] * np.float32(0.5)
+        ix.update_row(77, rows[77])
+        idx, sc = ix.search(q[:8], k)
+        _check(oracle, rows, q[:8], k, "f32", metric, idx, sc, "f32 + shadow after update_row")
+        if metric == "cosine":
+            assert idx[3, 0] == 77
+        # same answers as the plain f32 index (exact scan)
+        ix2 = m.HipKnnIndex(d, metric=metric, dtype="f32")
+        ix2.add(rows)
+        i2, s2 = ix2.search(q[:8], k)
+        ix2.close()
+        assert np.array_equal(idx, i2) and np.array_equal(sc, s2)
+    finally:
+        ix.close()
 
 
 def test_parity_sequential_cosine_metric_staged(oracle):
