@@ -276,7 +276,7 @@ class SymbolResolver:
     """Embedding phase of the index-time symbol resolver (indexer.rs:2790-2843) over the HIP kNN:
     add the known symbols once, then match whole batches of unresolved symbols."""
 
-    def __init__(self, dim, dtype="f32", device=0):
+    def __init__(self, dim, dtype="f32s", device=0):   # f32 rows + bf16 shadow: reference-identical AND batched
         self.dim = int(dim)
         h = C.c_void_p()
         cgvec._check(_lib().cgvs_resolver_create(self.dim, cgvec.DTYPES[dtype], int(device), C.byref(h)))

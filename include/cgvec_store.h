@@ -121,8 +121,8 @@ int cgvs_combine_embeddings(const float* embeddings, uint32_t n, uint32_t dim, f
  * highest similarity, if it is > threshold (0.75 in the reference). The |unresolved| x |known|
  * similarities are ONE batched device search (CGV_METRIC_COSINE_SEQ); the name filter runs on the
  * host for the best-ranked candidates only. Ties (the reference iterates a HashMap) -> lowest index.
- * dtype F32 reproduces the reference's similarities bit for bit; bf16/fp16/fp8 evaluate them on the
- * rounded embeddings. */
+ * dtype F32 / F32_SHADOW reproduce the reference's similarities bit for bit (F32_SHADOW through the
+ * batched MFMA path); bf16/fp16/fp8 evaluate them on the rounded embeddings. */
 typedef struct cgvs_resolver cgvs_resolver;
 int cgvs_resolver_create(uint32_t dim, int dtype, int device_id, cgvs_resolver** out);
 int cgvs_resolver_destroy(cgvs_resolver* r);
