@@ -178,20 +178,22 @@ def test_parity_unnormalised_rows_and_prefetch_k(oracle):
     _run(oracle, n=20_000, d=384, nq=40, k=30, dtype="bf16", metric="cosine", seed=9, unit=False)
 
 
-def test_ties_duplicates_zero_rows_zero_query(oracle):
+@pytest.mark.parametrize("dtype", ["bf16", "f32s", "fp8"])
+def test_ties_duplicates_zero_rows_zero_query(oracle, dtype):
     def mutate(rows, queries):
         rows[100:140] = rows[7]          # 40 exact duplicates of the best match for query 0
         queries[0] = rows[7]
         rows[300:310] = 0.0              # zero rows -> score 0.0 (simd_ops.rs:73-74)
         queries[1] = 0.0                 # zero query -> every score 0.0, ids 0..k-1
-    st = _run(oracle, n=5000, d=128, nq=4, k=10, dtype="bf16", metric="cosine", seed=4, mutate=mutate)
+    st = _run(oracle, n=5000, d=128, nq=4, k=10, dtype=dtype, metric="cosine", seed=4, mutate=mutate)
     assert st["fallback_queries"] >= 1   # ties at the candidate boundary are resolved by the exact scan
 
 
 def test_fewer_rows_than_k_and_single_row(oracle):
     m = pkg()
     for n in (1, 3, 9):
-        st = _run(oracle, n=n, d=64, nq=3, k=10, dtype="bf16", metric="cosine", seed=n)
+        for dtype in ("bf16", "f32s"):
+            _run(oracle, n=n, d=64, nq=3, k=10, dtype=dtype, metric="cosine", seed=n)
     ix = m.HipKnnIndex(64)
     try:
         idx, sc = ix.search(np.ones((2, 64), np.float32), 5)     # empty index
