@@ -562,3 +562,40 @@ def test_packed_exchange_kernels(oracle, k):
         ri, rs = oracle.merge_topk(idx[:, q, :], sc[:, q, :], k)
         assert np.array_equal(oi[q].cpu().numpy().view(np.uint64), ri) and np.array_equal(os_[q].cpu().numpy(), rs)
     assert torch.equal(oi, oi2) and torch.equal(os_, os2)
+
+
+def test_randomised_shapes_differential(oracle):
+    """Seeded sweep over shapes the fixed cases do not pin: n around tile / block boundaries, nq around
+    query-tile boundaries, arbitrary D, k up to 256 (beyond the MFMA path's k' cap -> exact path),
+    every dtype x metric the library accepts, duplicated and zero rows sprinkled in."""
+    m = pkg()
+    rng = np.random.default_rng(20260927)
+    ns = [1, 2, 31, 32, 33, 255, 256, 257, 511, 512, 513, 1023, 1025, 4095, 4097, 9000, 20011]
+    nqs = [1, 2, 7, 64, 255, 256, 257, 300, 513]
+    combos = [("bf16", "cosine"), ("bf16", "dot"), ("fp16", "cosine"), ("fp16", "dot"), ("fp8", "cosine"),
+              ("f32", "cosine"), ("f32", "dot"), ("f32s", "cosine"), ("f32s", "dot"), ("bf16", "cosine_seq"),
+              ("f32s", "cosine_seq")]
+    for it in range(44):
+        dtype, metric = combos[it % len(combos)]
+        n = int(rng.choice(ns))
+        nq = int(rng.choice(nqs))
+        d = int(rng.choice([1, 3, 8, 16, 31, 32, 33, 64, 65, 100, 128, 200, 384, 513]))
+        k = int(rng.choice([1, 2, 5, 10, 16, 30, 57, 64, 100, 256]))
+        if n * nq > 3_000_000:
+            nq = max(1, 3_000_000 // n)
+        rows = (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        if n > 40:
+            rows[n // 2] = rows[3]                    # a duplicate
+            rows[n // 3] = 0.0                        # a zero row
+        if nq > 2:
+            q[1] = rows[min(3, n - 1)]
+        ix = m.HipKnnIndex(d, metric=metric, dtype=dtype)
+        try:
+            cut = int(rng.integers(0, n + 1))
+            ix.add(rows[:cut])
+            ix.add(rows[cut:])
+            idx, sc = ix.search(q, k)
+            _check(oracle, rows, q, k, dtype, metric, idx, sc, f"it={it} n={n} nq={nq} d={d} k={k} {dtype} {metric}")
+        finally:
+            ix.close()
