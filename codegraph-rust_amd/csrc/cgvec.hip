@@ -353,7 +353,7 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
         break;                                                                                                   \
     }
         switch (abl) {
-            CGV_ABLK(1) CGV_ABLK(2) CGV_ABLK(4) CGV_ABLK(8) CGV_ABLK(10) CGV_ABLK(15) CGV_ABLK(16)
+            CGV_ABLK(1) CGV_ABLK(2) CGV_ABLK(4) CGV_ABLK(8) CGV_ABLK(10) CGV_ABLK(15) CGV_ABLK(16) CGV_ABLK(32)
             default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE: unknown mask");
         }
 #undef CGV_ABLK

@@ -208,7 +208,8 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
 
 // ABL: timing-only ablation mask for scripts/gpu_ablate.sh (results are WRONG for ABL != 0):
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
-// (MFMA on zeros), 16 = skip the vmcnt wait. DESIGN.md §5.1 quotes the numbers.
+// (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
+// (results stay correct for 32). DESIGN.md §9 quotes the numbers.
 template <int DT, bool DUMP, int ABL = 0>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
@@ -274,6 +275,18 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // The stream never ends: past the last stage it re-reads the last stage into the (free) ring
     // slot, so the loop body needs no "is there a next stage" branches and the counted
     // s_waitcnt vmcnt(8) below is valid in every iteration (<= 3 x 32 KiB of extra L2 reads).
+    // The copies go through buffer_load ... lds (scalar resource + scalar offset + ONE constant per-lane
+    // VGPR offset): no per-instruction 64-bit address arithmetic; measured 2.6 % faster on C2 than the
+    // global_load ... lds form (ABL & 32 selects that form for A/B timing).
+    constexpr bool BUFDMA = (ABL & 32) == 0;
+    const char* abase = a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;  // uniform
+    const char* bbase = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)bbase, 0, 0x7fffffff, 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    auto bdma = [&](__amdgpu_buffer_rsrc_t rs, uint32_t soff, char* l) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+    };
     auto issue_q = [&](int q) {
         if (ABL & 2) {
             if (q == 3) ++issued;
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         }
         char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
         const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
+        const uint32_t so = (uint32_t)koff + (uint32_t)wave * 2048u;
         if (q == 0) {
             if (lkc == 0 && issued < total) {
                 if (wave == 0)  // the tile's 256 inverse norms ride along with its first stage
@@ -291,19 +305,22 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                     glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
                 }
             }
-            glds16(acur + koff, dst);
+            if (BUFDMA) bdma(rsA, so, dst); else glds16(acur + koff, dst);
         } else if (q == 1) {
-            glds16(acur + koff + 1024, dst + 1024);
+            if (BUFDMA) bdma(rsA, so + 1024, dst + 1024); else glds16(acur + koff + 1024, dst + 1024);
         } else if (q == 2) {
-            glds16(bq + koff, dst + A_BYTES);
+            if (BUFDMA) bdma(rsB, so, dst + A_BYTES); else glds16(bq + koff, dst + A_BYTES);
         } else {
-            glds16(bq + koff + 1024, dst + A_BYTES + 1024);
+            if (BUFDMA) bdma(rsB, so + 1024, dst + A_BYTES + 1024); else glds16(bq + koff + 1024, dst + A_BYTES + 1024);
             ++issued;
             if (issued < total && ++lkc == KC) {
                 lkc = 0;
                 ++lj;
                 lt = next_tile(lt);
                 acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+                if (BUFDMA)
+                    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0,
+                                                            0x7fffffff, 0x00020000);
             }
         }
     };

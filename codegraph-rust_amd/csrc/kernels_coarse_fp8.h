@@ -75,14 +75,20 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     };
 
     // ---- DMA issue side: identical to coarse_kernel (endless stream, one instruction at a time) ----
-    const uint32_t slab = (uint32_t)wave * 2048u + (uint32_t)lane * 16u;
-    const char* bq = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES + slab;
-    const char* atile = a.rows + slab;
     uint32_t lj = 0, lkc = 0, issued = 0, lt = t_first;
-    const char* acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+    // buffer_load ... lds: scalar resource + scalar offset + one constant per-lane offset (kernels_coarse.h)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.qrows + (uint64_t)qt * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    auto bdma = [&](__amdgpu_buffer_rsrc_t rs, uint32_t soff, char* l) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+    };
     auto issue_q = [&](int q) {
         char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
         const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
+        const uint32_t so = (uint32_t)koff + (uint32_t)wave * 2048u;
         if (q == 0) {
             if (lkc == 0 && issued < total) {
                 if (wave == 0)
@@ -93,19 +99,20 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
                     glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
                 }
             }
-            glds16(acur + koff, dst);
+            bdma(rsA, so, dst);
         } else if (q == 1) {
-            glds16(acur + koff + 1024, dst + 1024);
+            bdma(rsA, so + 1024, dst + 1024);
         } else if (q == 2) {
-            glds16(bq + koff, dst + A_BYTES);
+            bdma(rsB, so, dst + A_BYTES);
         } else {
-            glds16(bq + koff + 1024, dst + A_BYTES + 1024);
+            bdma(rsB, so + 1024, dst + A_BYTES + 1024);
             ++issued;
             if (issued < total && ++lkc == KC) {
                 lkc = 0;
                 ++lj;
                 lt = next_tile(lt);
-                acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
+                rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0,
+                                                        0x7fffffff, 0x00020000);
             }
         }
     };
