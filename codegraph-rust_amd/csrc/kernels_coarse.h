@@ -10,19 +10,20 @@
 // bit-for-bit on those candidates, the same two-stage shape as
 // SemanticSearch::search_by_embedding (search.rs:113-137).
 //
-// Structure (gfx950) — see DESIGN.md §5.1 for the measurements behind each choice:
+// Structure (gfx950) — see DESIGN.md §5.1 / §9 for the measurements behind each choice:
 //   * workgroup = 256 x 256 output tile, 8 waves as 2(M) x 4(N), each wave 128 x 64 =
-//     4 x 2 blocks of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs); K streamed in
-//     64-element chunks through two 64-KiB LDS stages by global_load_lds_dwordx4;
-//   * both operands live in HBM in the BLOCKED layout B32 (common.h): a (tile, chunk)
-//     block is 32 KiB contiguous and byte-identical to its LDS image (XOR-swizzled so that
+//     4 x 2 blocks of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs);
+//   * both operands live in HBM in the BLOCKED layout B32 (common.h): a (tile, 64-byte K chunk)
+//     block is 16 KiB contiguous and byte-identical to its LDS image (XOR-swizzled so that
 //     ds_read_b128 fragment reads are bank-conflict-free), so every DMA instruction is a
-//     linear 1-KiB copy. The kernel is bound by the L2->LDS path (64 KB per chunk per CU):
-//     contiguous blocks move at ~60 GB/s/CU, 128-B row pieces at a 1536-B pitch at ~33;
-//   * hand-pinned software pipeline: fragments double-buffered in registers (the 6
-//     ds_reads of k-step kk+1 are issued right after the first MFMA of k-step kk), the
-//     per-chunk "DMA landed" wait + raw s_barrier sits before the LAST k-step so barrier
-//     skew, the next DMA issue and the first LDS latency of the next chunk hide under MFMAs;
+//     linear 1-KiB copy (contiguous blocks move at ~60 GB/s/CU, row pieces at a pitch at ~33);
+//   * K is streamed through a RING of four 32-KiB LDS stages (A chunk + B chunk = two k-steps)
+//     by buffer_load_dwordx4 ... lds, three stages ahead, ONE instruction at a time between MFMA
+//     groups, retired by a counted s_waitcnt vmcnt(8); the stream never ends (no tail branches);
+//   * hand-pinned software pipeline: fragments double-buffered in registers (the 6 ds_reads of
+//     the next k-step are issued right after the first MFMA of the current one); one raw
+//     s_barrier per stage, placed after the first MFMA of the stage's last k-step; every MFMA
+//     is unconditional (accumulators are cleared after the tile epilogue);
 //   * a workgroup is persistent over a list of corpus tiles for ONE query tile: the
 //     (tile, k-chunk) sequence is one flat pipeline across tile boundaries;
 //   * MFMA C layout (32x32): lane holds column (= query) lane&31 and 16 rows
@@ -61,7 +62,8 @@ struct Mfma<DT_FP16> {
 
 // fp8 (e4m3): one 16-byte LDS piece holds 16 elements = the lane's share of TWO K=16 MFMAs
 // (low / high 8 bytes), so "mma" issues v_mfma_f32_32x32x16_fp8_fp8 twice and the K chunk of
-// a 128-byte row is 128 elements. Any K permutation is fine as long as A and B use the same one.
+// a 64-byte row chunk is 64 elements. Any K permutation is fine as long as A and B use the same one.
+// (The production fp8 path is kernels_coarse_fp8.h; this one remains for the boot kernel and A/B timing.)
 typedef long fp8x16_t __attribute__((ext_vector_type(2)));
 template <>
 struct Mfma<DT_FP8> {

@@ -11,8 +11,8 @@
 namespace cgv {
 
 // in: [n][D] f32 (n rows to append). out: the index' row storage (f32: row-major [.][ld];
-// bf16/fp16: blocked layout B64, see common.h), written at absolute rows row0 + r, columns
-// zero padded to ld (multiple of 64).
+// bf16/fp16/fp8: blocked layout B32, see common.h), written at absolute rows row0 + r, columns
+// zero padded to ld (a whole number of 64-byte chunks).
 // fp8 rows are stored scaled by their own power of two (rexp[r], common.h); norms are taken in
 // that scaled domain, where the coarse pass works.
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
