@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--host-io-steps", type=int, default=10, help="extra host-pointer-API batches (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly serial steps)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=128)
@@ -209,6 +210,19 @@ def main():
                          "fallback_queries": int(st["fallback_queries"]), "eps": st["last_eps"],
                          "max_observed_coarse_err": st["max_observed_err"]},
         }
+
+    if rank == 0 and world == 1 and args.host_io_steps > 0:
+        # PCIe-inclusive rate of the host-pointer entry point (cgv_search_f32: queries H2D, results D2H,
+        # serial batches). Reported beside `value`, never as it.
+        qh_np = qpool[0].cpu().numpy()
+        ix.search(qh_np, k)
+        t0 = time.perf_counter()
+        for _ in range(args.host_io_steps):
+            ix.search(qh_np, k)
+        dt = time.perf_counter() - t0
+        result["host_pointer_api"] = {"queries_per_sec": round(batch * args.host_io_steps / dt, 1),
+                                      "ms_per_batch": round(1e3 * dt / args.host_io_steps, 4),
+                                      "note": "cgv_search_f32: pageable host queries in, host results out, one batch at a time"}
 
     if want_cpu:
         from oracle import oracle as o   # CPU baseline + recall checker only
