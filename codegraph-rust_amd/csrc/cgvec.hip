@@ -394,8 +394,8 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
-int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
-                  const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0) {
+SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
+                            const float* dense, uint32_t n_dense, uint64_t expected, size_t* lds_out) {
     SelectArgs sa;
     sa.cand = c->cand.as<uint2>();
     sa.cand_cnt = c->candcnt.as<uint32_t>();
@@ -423,7 +423,14 @@ int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
         const uint64_t want = next_pow2((uint32_t)std::min<uint64_t>(8 * expected + kprime, SELECT_LDS_KEYS));
         sa.lds_keys = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1024), SELECT_LDS_KEYS);
     }
-    const size_t lds = (size_t)sa.lds_keys * 8 + ((size_t)nsplit + 1) * 4;
+    *lds_out = (size_t)sa.lds_keys * 8 + ((size_t)nsplit + 1) * 4;
+    return sa;
+}
+
+int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
+                  const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0) {
+    size_t lds = 0;
+    const SelectArgs sa = make_select_args(c, nq, nqt, nsplit, kprime, dense, n_dense, expected, &lds);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -673,6 +680,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.nqt = nqt;
         a.metric = h->metric;
         uint32_t j0 = 0;
+        const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
+        uint32_t last_nsplit = 0;
+        uint64_t last_expected = 0;
         for (size_t st = 0; st < p.counts.size(); ++st) {
             const uint32_t cnt = p.counts[st];
             a.j0 = j0;
@@ -688,7 +698,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             }
             // expected emissions per query of this launch: k' * rows / rows seen before it
             const uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)p.T1 + j0) + 1;
-            if ((rc = launch_select(c, nq, nqt, a.nsplit, kprime, nullptr, 0, s, expected))) return rc;
+            if (dominant && fused_final) {  // the last selection happens inside final_kernel
+                last_nsplit = a.nsplit;
+                last_expected = expected;
+            } else if ((rc = launch_select(c, nq, nqt, a.nsplit, kprime, nullptr, 0, s, expected))) {
+                return rc;
+            }
             j0 += cnt;
         }
         RescoreArgs r;
@@ -730,27 +745,41 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             const size_t budget = h->shadow ? 45 * 1024 : 15 * 1024;  // (the f32 rows of 4k+16 candidates)
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
-            const size_t lds = rowb + (size_t)rpb * pitch;
+            size_t lds = rowb + (size_t)rpb * pitch;
             static bool attr_set = false;
             if (!attr_set) {
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_BF16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP8>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_F32>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                const int cap = 96 * 1024;
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 attr_set = true;
             }
-            if (h->dtype == CGV_DTYPE_F32)
+            if (fused_final) {
+                size_t sel_lds = 0;
+                const SelectArgs sa = make_select_args(c, nq, nqt, last_nsplit, kprime, nullptr, 0, last_expected, &sel_lds);
+                lds = std::max(lds, sel_lds);
+                if (h->dtype == CGV_DTYPE_F32)
+                    hipLaunchKernelGGL(final_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, sa, r);
+                else if (h->dtype == CGV_DTYPE_BF16)
+                    hipLaunchKernelGGL(final_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, sa, r);
+                else if (h->dtype == CGV_DTYPE_FP16)
+                    hipLaunchKernelGGL(final_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, sa, r);
+                else
+                    hipLaunchKernelGGL(final_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, sa, r);
+            } else if (h->dtype == CGV_DTYPE_F32) {
                 hipLaunchKernelGGL(rescore_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, r);
-            else if (h->dtype == CGV_DTYPE_BF16)
+            } else if (h->dtype == CGV_DTYPE_BF16) {
                 hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r);
-            else if (h->dtype == CGV_DTYPE_FP16)
+            } else if (h->dtype == CGV_DTYPE_FP16) {
                 hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r);
-            else
+            } else {
                 hipLaunchKernelGGL(rescore_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, r);
+            }
         }
         HIPCHK(hipGetLastError());
     }

@@ -533,8 +533,30 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const uint32_t ks = ld * Elem<DT>::bytes / 32;  // pairs of 16-byte pieces per row
-    for (uint32_t k = 0; k < ks; ++k) {
-        const uint32_t pc = 2 * k + hi;  // this lane's 16-byte piece of k-step k
+    // latency-bound (one wave per 64x64 block, operands straight from L2/HBM): eight k-steps of loads
+    // (32 x 16 B per lane, 128 VGPRs) are issued before their 32 MFMAs
+    constexpr int BU = 8;
+    uint32_t k = 0;
+    for (; k + BU <= ks; k += BU) {
+        frag fa0[BU], fa1[BU], fb0[BU], fb1[BU];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const uint32_t pc = 2 * (k + u) + hi;  // this lane's 16-byte piece of k-step k+u
+            fa0[u] = *(const frag*)(ap[0] + blocked_piece_off(pc, akey[0]));
+            fa1[u] = *(const frag*)(ap[1] + blocked_piece_off(pc, akey[1]));
+            fb0[u] = *(const frag*)(bp[0] + blocked_piece_off(pc, bkey[0]));
+            fb1[u] = *(const frag*)(bp[1] + blocked_piece_off(pc, bkey[1]));
+        }
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            acc[0][0] = Mfma<DT>::mma(fa0[u], fb0[u], acc[0][0]);
+            acc[0][1] = Mfma<DT>::mma(fa0[u], fb1[u], acc[0][1]);
+            acc[1][0] = Mfma<DT>::mma(fa1[u], fb0[u], acc[1][0]);
+            acc[1][1] = Mfma<DT>::mma(fa1[u], fb1[u], acc[1][1]);
+        }
+    }
+    for (; k < ks; ++k) {
+        const uint32_t pc = 2 * k + hi;
         frag a0 = *(const frag*)(ap[0] + blocked_piece_off(pc, akey[0])), a1 = *(const frag*)(ap[1] + blocked_piece_off(pc, akey[1]));
         frag b0 = *(const frag*)(bp[0] + blocked_piece_off(pc, bkey[0])), b1 = *(const frag*)(bp[1] + blocked_piece_off(pc, bkey[1]));
         acc[0][0] = Mfma<DT>::mma(a0, b0, acc[0][0]);

@@ -303,13 +303,10 @@ struct RescoreArgs {
 // Dynamic LDS: [query row: ld*esize B][batch rows: (ld*esize + 16) B each, +16 B pad against bank
 // conflicts]. rows_per_batch is chosen by the host (>= 1).
 template <int DT>
-__global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t nb, const uint64_t* ckeys /* LDS [nb] */,
+                                    float tau, bool overflow, char* smem, int tid) {
     __shared__ uint64_t ekeys[CAND_CAPS];
     __shared__ uint32_t maxerr;
-    const int tid = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    const uint32_t nb = a.nbest[q];
     const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
     char* qs = smem;
     char* rs = smem + rowb;
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
                 const uint32_t e = e0 + i * 256;
                 if (e < total) {
                     const uint32_t c = e / pieces, pc = e % pieces;
-                    const uint32_t row = key_row(a.best[(uint64_t)q * a.kprime + c0 + c]);
+                    const uint32_t row = key_row(ckeys[c0 + c]);
                     v[i] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pc);
                 }
             }
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
         __syncthreads();
         const LdsRow<DT> ql{qs};
         for (uint32_t c = (uint32_t)tid >> 3; c < nbat; c += 32) {
-            const uint64_t key = a.best[(uint64_t)q * a.kprime + c0 + c];
+            const uint64_t key = ckeys[c0 + c];
             const uint32_t row = key_row(key);
             const float coarse = key_score(key);
             const LdsRow<DT> cl{rs + (size_t)c * pitch};
@@ -371,8 +368,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
     }
     if (tid == 0) {
         atomicMax(a.stat_maxerr, maxerr);
-        bool fb = a.overflow[q] != 0;
-        const float tau = a.tau[q];
+        bool fb = overflow;
         if (tau > -INFINITY && nb > 0) {  // candidates were truncated: check the guarantee
             const uint32_t kk = a.k < nb ? a.k : nb;
             const float ek = key_score(ekeys[kk - 1]);
@@ -394,6 +390,44 @@ __global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint64_t ckeys[CAND_CAPS];
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t nb = a.nbest[q];
+    for (uint32_t i = tid; i < nb; i += 256) ckeys[i] = a.best[(uint64_t)q * a.kprime + i];
+    __syncthreads();
+    rescore_body<DT>(a, q, nb, ckeys, a.tau[q], a.overflow[q] != 0, smem, tid);
+}
+
+// Last stage, k' <= 64: the final selection (merge of best[q] with the last launch's candidate
+// sub-lists) and the exact re-score in ONE launch - the top-k' keys go from the extraction straight
+// into the re-score through LDS instead of a best[]/tau[] round trip and a second launch.
+// Dynamic LDS = max(select's key buffer + prefix, re-score's staged rows); the key buffer is dead
+// once the extraction is done.
+template <int DT>
+__global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint64_t ckeys[CAND_CAPS];
+    __shared__ uint64_t part[4 * 64];
+    __shared__ uint64_t outk[64];
+    uint64_t* keys = (uint64_t*)smem;
+    uint32_t* pre = (uint32_t*)(smem + (size_t)sa.lds_keys * 8);
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    bool trunc = false;
+    const uint32_t M = gather_keys(sa, q, keys, pre, tid, &trunc);
+    const uint32_t keep = M < sa.kprime ? M : sa.kprime;
+    extract_topk(keys, M, keep, part, outk, tid);
+    for (uint32_t i = tid; i < keep; i += 256) ckeys[i] = outk[i];
+    const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : -INFINITY;
+    const bool overflow = trunc || sa.overflow[q] != 0;
+    __syncthreads();
+    rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, tid);
 }
 
 // Per-shard results -> one packed record row per query for the single all-gather of SURVEY.md §8(e):
