@@ -569,14 +569,31 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
         const uint32_t q = qb * 64 + j * 32 + (lane & 31);
         if (q >= nq) continue;
         const float iq = (metric == METRIC_DOT) ? 1.0f : invn_q[q];
+        // C layout: registers 4g..4g+3 of a block are 4 CONSECUTIVE corpus rows -> one 16-byte store each
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = rb * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < n_boot) {
-                    const float v = acc[i][j][r];
-                    dense[(uint64_t)q * n_boot + row] = (metric == METRIC_DOT) ? v : v * invn_c[row] * iq;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint32_t row = rb * 64 + i * 32 + 8 * g4 + 4 * (lane >> 5);
+                float* dst = dense + (uint64_t)q * n_boot + row;
+                if (row + 3 < n_boot && (n_boot & 3u) == 0) {
+                    float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2],
+                                           acc[i][j][4 * g4 + 3]);
+                    if (metric != METRIC_DOT) {
+                        const float4 ic = *(const float4*)(invn_c + row);
+                        v.x = v.x * ic.x * iq;
+                        v.y = v.y * ic.y * iq;
+                        v.z = v.z * ic.z * iq;
+                        v.w = v.w * ic.w * iq;
+                    }
+                    *(float4*)dst = v;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (row + t < n_boot) {
+                            const float v = acc[i][j][4 * g4 + t];
+                            dst[t] = (metric == METRIC_DOT) ? v : v * invn_c[row + t] * iq;
+                        }
                 }
             }
     }
