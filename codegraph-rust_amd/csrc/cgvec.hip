@@ -541,7 +541,9 @@ uint32_t gcd_u32(uint32_t a, uint32_t b) {
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
-    const uint32_t boot = p.ntiles <= 2048 ? BOOT_TILES_SMALL : BOOT_TILES;
+    // (also when many candidates are kept per query - the f32 + shadow index, k' = 4k+16: emissions scale
+    // with k', C2 shape 548 k -> 591 k q/s)
+    const uint32_t boot = (p.ntiles <= 2048 || kprime > 32) ? BOOT_TILES_SMALL : BOOT_TILES;
     p.T1 = std::min<uint32_t>(std::max<uint32_t>((kprime + BM - 1) / BM, boot), p.ntiles);
     p.R = p.ntiles - p.T1;
     p.P = 1;
