@@ -599,3 +599,10 @@ def test_randomised_shapes_differential(oracle):
             _check(oracle, rows, q, k, dtype, metric, idx, sc, f"it={it} n={n} nq={nq} d={d} k={k} {dtype} {metric}")
         finally:
             ix.close()
+
+
+def test_many_queries_more_query_tiles_than_corpus_splits(oracle):
+    """nq = 2100 -> 9 query tiles (a query-tile count C2-C5 do not use; nsplit_max = 28), k = 30
+    (k' = 40), dot metric on un-normalised rows."""
+    st = _run(oracle, n=12_000, d=96, nq=2100, k=30, dtype="bf16", metric="dot", seed=77, unit=False)
+    assert st["last_path"] == 1 and st["fallback_queries"] <= 5
