@@ -59,6 +59,29 @@ __global__ void quantize_kernel(const float* __restrict__ in, uint64_t total, ui
     }
 }
 
+// quantize_unit_range_u4 (optimization.rs:338-343): round((clamp(x,-1,1)+1)/2 * 15) -> 0..15
+__host__ __device__ inline uint8_t quant_u4(float v) {
+    float c = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+    const float nrm = (c + 1.0f) / 2.0f;
+    int q = (nrm != nrm) ? 0 : (int)roundf(nrm * 15.0f);  // Rust: NaN as i32 == 0
+    q = q < 0 ? 0 : (q > 15 ? 15 : q);
+    return (uint8_t)q;
+}
+
+// 4-bit arm of quantize_batch (optimization.rs:248-262): two values per byte, low nibble first,
+// an odd last column pairs with 0
+__global__ void quantize4_kernel(const float* __restrict__ in, uint64_t n, uint32_t dim, uint8_t* __restrict__ out) {
+    const uint32_t half = (dim + 1) / 2;
+    const uint64_t total = n * half;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / half;
+        const uint32_t j = (uint32_t)(i % half) * 2;
+        const uint8_t q0 = quant_u4(in[r * dim + j]);
+        const uint8_t q1 = (j + 1 < dim) ? quant_u4(in[r * dim + j + 1]) : 0;
+        out[i] = (uint8_t)((q0 & 0x0F) | ((q1 & 0x0F) << 4));
+    }
+}
+
 __device__ inline int sdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 
 // scores[row] = dot / (nq * sqrt(nv)), NaN when nv == 0 (row skipped by the reference, :131-133).
@@ -407,6 +430,29 @@ int cgv_quantize_u8_f32(int device_id, const float* rows_host, uint64_t n, uint3
     (void)hipFree(din);
     if (dout) (void)hipFree(dout);
     if (e != hipSuccess) return fail(CGV_ERR_HIP, std::string("cgv_quantize_u8_f32: ") + hipGetErrorString(e));
+    return CGV_OK;
+}
+
+int cgv_quantize_u4_f32(int device_id, const float* rows_host, uint64_t n, uint32_t dim, uint8_t* out_host) {
+    if (n == 0 || dim == 0) return CGV_OK;
+    if (!rows_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    if (cgv_device_count() == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+    I8CHK(hipSetDevice(device_id));
+    const uint64_t total = n * dim, obytes = n * ((dim + 1) / 2);
+    float* din = nullptr;
+    uint8_t* dout = nullptr;
+    I8CHK(hipMalloc((void**)&din, total * 4));
+    hipError_t e = hipMalloc((void**)&dout, obytes);
+    if (e == hipSuccess) e = hipMemcpy(din, rows_host, total * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(quantize4_kernel, dim3((unsigned)std::min<uint64_t>(4096, (obytes + 255) / 256)), dim3(256), 0, 0,
+                           (const float*)din, n, dim, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, obytes, hipMemcpyDeviceToHost);
+    (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(CGV_ERR_HIP, std::string("cgv_quantize_u4_f32: ") + hipGetErrorString(e));
     return CGV_OK;
 }
 

@@ -187,6 +187,32 @@ int cgvs_resolver_match(cgvs_resolver* r, uint32_t nq, const char* const* target
     return CGV_OK;
 }
 
+// EmbeddingReRanker::rerank after the embeddings exist (crates/codegraph-vector/src/reranker.rs:113-157):
+// cosine_similarity (:94-109, the sequential formula) of the query against every candidate, then a
+// stable sort by score descending (ties keep the candidate order). Similarities on the device
+// (f32 rows, exact scan); the <= ~100-element sort on the host.
+int cgvs_rerank_embeddings(int device_id, const float* query, const float* candidates, uint32_t n, uint32_t dim,
+                           uint32_t* out_order, float* out_score) {
+    if (n == 0) return CGV_OK;
+    if (!query || !candidates || !out_order || !out_score || dim == 0) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    cgv_index* ix = nullptr;
+    int rc = cgv_create(dim, CGV_METRIC_COSINE_SEQ, CGV_DTYPE_F32, device_id, &ix);
+    if (rc) return rc;
+    std::vector<float> sc(n);
+    rc = cgv_add_f32(ix, candidates, n);
+    if (rc == CGV_OK) rc = cgv_batch_similarity_f32(ix, query, CGV_OP_COSINE_SEQ, 0, sc.data());
+    cgv_destroy(ix);
+    if (rc) return rc;
+    std::vector<uint32_t> ord(n);
+    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return sc[x] > sc[y]; });  // :148
+    for (uint32_t i = 0; i < n; ++i) {
+        out_order[i] = ord[i];
+        out_score[i] = sc[ord[i]];
+    }
+    return CGV_OK;
+}
+
 float cgvs_trigram_jaccard(const char* a, const char* b) {
     return jaccard(char_trigrams(lower_ascii(a)), char_trigrams(lower_ascii(b)));
 }

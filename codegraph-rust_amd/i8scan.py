@@ -24,8 +24,9 @@ def lib():
         L.cgv_i8_search_optimized.argtypes = [vp, vp, u32, u64, vp, C.POINTER(u64)]
         L.cgv_i8_scores_f32.argtypes = [vp, vp, u32, vp]
         L.cgv_quantize_u8_f32.argtypes = [i32, vp, u64, u32, vp]
+        L.cgv_quantize_u4_f32.argtypes = [i32, vp, u64, u32, vp]
         for n in ("cgv_i8_create", "cgv_i8_destroy", "cgv_i8_add_u8", "cgv_i8_add_f32", "cgv_i8_get_row_u8",
-                  "cgv_i8_search_optimized", "cgv_i8_scores_f32", "cgv_quantize_u8_f32"):
+                  "cgv_i8_search_optimized", "cgv_i8_scores_f32", "cgv_quantize_u8_f32", "cgv_quantize_u4_f32"):
             getattr(L, n).restype = i32
         _decl = True
     return L
@@ -38,6 +39,17 @@ def quantize_u8(rows, device=0):
         r = r[None, :]
     out = np.empty(r.shape, dtype=np.uint8)
     _check(lib().cgv_quantize_u8_f32(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1],
+                                     out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def quantize_u4(rows, device=0):
+    """ModelOptimizer::quantize_batch, 4-bit arm (optimization.rs:248-262) -> uint8 [n, ceil(dim/2)]."""
+    r = np.ascontiguousarray(rows, dtype=np.float32)
+    if r.ndim == 1:
+        r = r[None, :]
+    out = np.empty((r.shape[0], (r.shape[1] + 1) // 2), dtype=np.uint8)
+    _check(lib().cgv_quantize_u4_f32(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1],
                                      out.ctypes.data_as(C.c_void_p)))
     return out
 

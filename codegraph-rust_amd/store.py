@@ -65,6 +65,7 @@ def _lib():
         L.cgvs_trigram_jaccard.argtypes = [C.c_char_p, C.c_char_p]
         L.cgvs_trigram_jaccard.restype = C.c_float
         L.cgvs_symbol_name_eligible.argtypes = [C.c_char_p, C.c_char_p]
+        L.cgvs_rerank_embeddings.argtypes = [C.c_int, vp, vp, u32, u32, vp, vp]
         _bound = True
     return L
 
@@ -315,3 +316,19 @@ class SymbolResolver:
                                                 float(threshold), idx.ctypes.data_as(C.c_void_p),
                                                 sc.ctypes.data_as(C.c_void_p)))
         return idx, sc
+
+
+def rerank_embeddings(query, candidates, device=0):
+    """EmbeddingReRanker::rerank (reranker.rs:113-157) on ready embeddings -> (order uint32[n], scores f32[n])."""
+    q = np.ascontiguousarray(query, dtype=np.float32).ravel()
+    c = np.ascontiguousarray(candidates, dtype=np.float32)
+    n = c.shape[0] if c.ndim == 2 else 0
+    order = np.empty(n, dtype=np.uint32)
+    sc = np.empty(n, dtype=np.float32)
+    if n:
+        if c.shape[1] != q.size:
+            raise cgvec.CgvError(cgvec.CGV_ERR_DIM_MISMATCH, f"candidate dim {c.shape[1]} != {q.size}")
+        cgvec._check(_lib().cgvs_rerank_embeddings(int(device), q.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                                                   n, q.size, order.ctypes.data_as(C.c_void_p),
+                                                   sc.ctypes.data_as(C.c_void_p)))
+    return order, sc

@@ -57,6 +57,11 @@ int cgv_i8_scores_f32(cgv_i8_index* h, const float* query_host, uint32_t query_l
 /* ModelOptimizer::quantize_batch, 8-bit arm, as a free function on the device (no handle kept). */
 int cgv_quantize_u8_f32(int device_id, const float* rows_host, uint64_t n, uint32_t dim, uint8_t* out_host);
 
+/* ModelOptimizer::quantize_batch, 4-bit arm (optimization.rs:248-262, quantize_unit_range_u4 :338-343):
+ * out_host is [n][ceil(dim/2)] bytes, two codes per byte, low nibble first. (search_optimized itself
+ * only scans 8-bit data: for other widths it returns 0..limit, optimization.rs:76-82.) */
+int cgv_quantize_u4_f32(int device_id, const float* rows_host, uint64_t n, uint32_t dim, uint8_t* out_host);
+
 #ifdef __cplusplus
 }
 #endif

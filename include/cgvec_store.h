@@ -135,6 +135,12 @@ int cgvs_resolver_match(cgvs_resolver* r, uint32_t nq, const char* const* target
 float cgvs_trigram_jaccard(const char* a, const char* b);            /* indexer.rs:2901-2932 on lower-cased names */
 int cgvs_symbol_name_eligible(const char* target, const char* name); /* indexer.rs:2804-2821 */
 
+/* EmbeddingReRanker::rerank once the embeddings exist (crates/codegraph-vector/src/reranker.rs:113-157 with
+ * cosine_similarity :94-109): out_order = candidate indices by similarity to the query, descending, ties in
+ * candidate order (stable sort, :148); out_score = the similarities in that order. */
+int cgvs_rerank_embeddings(int device_id, const float* query, const float* candidates, uint32_t n, uint32_t dim,
+                           uint32_t* out_order, float* out_score);
+
 /* Free functions of the mirrored surface. */
 const char* cgvs_embedding_column_for_dimension(uint32_t dim);            /* surrealdb_storage.rs:1932-1952 */
 int cgvs_normalize_node_id(const char* raw, char* out, size_t out_len);   /* surreal_store.rs:123-128 */

@@ -434,6 +434,23 @@ void cgo_quantize_u8(const float* v, size_t len, uint8_t* out) {
     }
 }
 
+// optimization.rs:248-262 + :338-343: 4-bit arm of quantize_batch
+void cgo_quantize_u4(const float* v, uint64_t n, uint64_t dim, uint8_t* out) {
+    const uint64_t half = (dim + 1) / 2;
+    for (uint64_t r = 0; r < n; ++r)
+        for (uint64_t j = 0; j < dim; j += 2) {
+            uint8_t q[2] = {0, 0};
+            for (int t = 0; t < 2 && j + t < dim; ++t) {
+                float x = v[r * dim + j + t];
+                float c = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+                float nrm = (c + 1.0f) / 2.0f;
+                int qi = (nrm != nrm) ? 0 : (int)roundf(nrm * 15.0f);
+                q[t] = (uint8_t)(qi < 0 ? 0 : (qi > 15 ? 15 : qi));
+            }
+            out[r * half + j / 2] = (uint8_t)((q[0] & 0x0F) | ((q[1] & 0x0F) << 4));
+        }
+}
+
 uint64_t cgo_search_optimized_u8(const float* query, const uint8_t* data, uint64_t n, uint64_t dim,
                                  uint64_t limit_in, uint64_t* out_idx) {
     uint64_t limit = limit_in < 1 ? 1 : limit_in;

@@ -224,6 +224,17 @@ def quantize_u8(v):
     return out.reshape(v.shape)  # optimization.rs:212-283
 
 
+def quantize_u4(v):
+    v, pv = _f(v)
+    n, dim = v.shape
+    out = np.empty((n, (dim + 1) // 2), dtype=np.uint8)
+    L = lib()
+    L.cgo_quantize_u4.restype = None
+    L.cgo_quantize_u4.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8)]
+    L.cgo_quantize_u4(pv, n, dim, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out  # optimization.rs:248-262
+
+
 def search_optimized_u8(query, data_u8, limit):
     q, pq = _f(query)
     d = np.ascontiguousarray(data_u8, dtype=np.uint8)

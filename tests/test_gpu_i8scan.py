@@ -44,6 +44,16 @@ def test_quantize_batch_matches(oracle):
     assert np.array_equal(m.quantize_u8(x), oracle.quantize_u8(x))
 
 
+def test_quantize_batch_4bit_arm(oracle):
+    m = pkg()
+    rng = np.random.default_rng(6)
+    for d in (8, 33):                                    # odd dimension: the last code pairs with 0
+        x = (rng.standard_normal((129, d)) * 0.8).astype(np.float32)
+        x[0, :4] = [-1.0, 1.0, 0.0, 1.0 / 15.0]
+        x[1, 0] = np.nan
+        assert np.array_equal(m.quantize_u4(x), oracle.quantize_u4(x))
+
+
 def test_ties_zero_rows_and_degenerate_queries(oracle):
     """The buffer policy is order dependent: among equal minima the most recently inserted entry is
     evicted first (optimization.rs:135-145). Duplicated rows + zero rows (skipped, :131-133)."""

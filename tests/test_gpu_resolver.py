@@ -82,3 +82,21 @@ def test_resolver_escalates_past_ineligible_candidates(oracle):
             assert idx2[0] == -1 == oracle.symbol_match_phase2("qqqq", base, names, embs, 0.75)[0]
         finally:
             r.close()
+
+
+def test_rerank_embeddings_matches_reference_order(oracle):
+    """reranker.rs:113-157: sequential cosine of the query vs <= ~100 candidate embeddings, stable sort desc."""
+    pkg()
+    st = importlib.import_module("codegraph-rust_amd.store")
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal(384).astype(np.float32)
+    c = rng.standard_normal((100, 384)).astype(np.float32)
+    c[40] = c[7]                       # tie: candidate order is kept
+    c[55] = 0.0                        # zero norm -> 0.0 (reranker.rs:104-106)
+    order, sc = st.rerank_embeddings(q, c)
+    ref = np.array([oracle.search_cosine(q, r) for r in c], np.float32)
+    ro = np.argsort(-ref, kind="stable")
+    assert np.array_equal(order, ro.astype(np.uint32)) and np.array_equal(sc, ref[ro])
+    assert list(order).index(7) + 1 == list(order).index(40)
+    o0, s0 = st.rerank_embeddings(q, np.zeros((0, 384), np.float32))
+    assert o0.size == 0 and s0.size == 0
