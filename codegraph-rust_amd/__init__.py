@@ -10,3 +10,4 @@ from .cgvec import CgvError, HipKnnIndex, PendingSearch, build_library, device_c
 from .sharded import ShardedKnn, shard_range  # noqa: F401
 from . import store  # noqa: F401
 from .i8scan import Int8ScanIndex, quantize_u4, quantize_u8  # noqa: F401
+from .quant import ProductQuantizer, ScalarQuantizer  # noqa: F401

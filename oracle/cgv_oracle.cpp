@@ -711,4 +711,135 @@ int64_t cgo_symbol_match_phase2(const char* target, const float* target_emb, uin
     return best;
 }
 
+// ---------------------------------------------------------------------------
+// ScalarQuantizer / ProductQuantizer: crates/codegraph-vector/src/persistent.rs:116-477,
+// literal single-thread restatements (training order, tie rules and f32 rounding as written).
+// ---------------------------------------------------------------------------
+static inline float rs_min(float a, float b) { return (b != b) ? a : ((a != a) ? b : (b < a ? b : a)); }  // f32::min
+static inline float rs_max(float a, float b) { return (b != b) ? a : ((a != a) ? b : (b > a ? b : a)); }
+
+void cgo_sq_train(const float* v, uint64_t n, uint64_t dim, uint32_t nbits, int uniform, float* scales, float* biases) {
+    for (uint64_t d = 0; d < dim; ++d) {
+        scales[d] = 1.0f;
+        biases[d] = 0.0f;
+    }
+    const float levels = (float)(1 << nbits);
+    if (uniform) {  // :366-385
+        float gmin = INFINITY, gmax = -INFINITY;
+        for (uint64_t r = 0; r < n; ++r)
+            for (uint64_t d = 0; d < dim; ++d) {
+                gmin = rs_min(gmin, v[r * dim + d]);
+                gmax = rs_max(gmax, v[r * dim + d]);
+            }
+        const float scale = levels / (gmax - gmin);
+        for (uint64_t d = 0; d < dim; ++d) {
+            scales[d] = scale;
+            biases[d] = gmin;
+        }
+    } else {  // :386-403
+        for (uint64_t d = 0; d < dim; ++d) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (uint64_t r = 0; r < n; ++r) {
+                lo = rs_min(lo, v[r * dim + d]);
+                hi = rs_max(hi, v[r * dim + d]);
+            }
+            const float range = hi - lo;
+            if (range > 0.0f) {
+                scales[d] = levels / range;
+                biases[d] = lo;
+            }
+        }
+    }
+}
+
+void cgo_sq_encode(const float* v, uint64_t n, uint64_t dim, uint32_t nbits, const float* scales, const float* biases,
+                   uint8_t* out) {  // :410-436
+    const uint32_t max_val = (1u << nbits) - 1u;
+    const uint32_t bpv = nbits == 8 ? 1 : (nbits == 16 ? 2 : 4);
+    for (uint64_t i = 0; i < n * dim; ++i) {
+        const uint64_t d = i % dim;
+        const float normalized = (v[i] - biases[d]) * scales[d];
+        float c = rs_max(normalized, 0.0f);
+        c = rs_min(c, (float)max_val);
+        const uint32_t q = (uint32_t)c;
+        for (uint32_t b = 0; b < bpv; ++b) out[i * bpv + b] = (uint8_t)(q >> (8 * b));
+    }
+}
+
+void cgo_sq_decode(const uint8_t* codes, uint64_t n, uint64_t dim, uint32_t nbits, const float* scales,
+                   const float* biases, float* out) {  // :438-476
+    const uint32_t bpv = nbits == 8 ? 1 : (nbits == 16 ? 2 : 4);
+    for (uint64_t i = 0; i < n * dim; ++i) {
+        uint32_t q = 0;
+        for (uint32_t b = 0; b < bpv; ++b) q |= (uint32_t)codes[i * bpv + b] << (8 * b);
+        out[i] = (float)q / scales[i % dim] + biases[i % dim];
+    }
+}
+
+static float o_pq_dist(const float* a, const float* b, uint64_t dsub) {  // :320-328
+    float s = 0.0f;
+    for (uint64_t i = 0; i < dsub; ++i) {
+        const float d = a[i] - b[i];
+        s = s + d * d;
+    }
+    return sqrtf(s);
+}
+
+// centroids out: [m][ksub][dsub]
+void cgo_pq_train(const float* v, uint64_t n, uint64_t dim, uint64_t m, uint32_t nbits, float* cent) {
+    const uint64_t dsub = dim / m, ksub = 1ull << nbits;
+    std::vector<uint64_t> assign(n);
+    std::vector<float> nc(dsub);
+    for (uint64_t sub = 0; sub < m; ++sub) {
+        float* c = cent + sub * ksub * dsub;
+        for (uint64_t i = 0; i < ksub; ++i)  // :255-258
+            memcpy(c + i * dsub, v + (i % n) * dim + sub * dsub, dsub * 4);
+        for (int it = 0; it < 50; ++it) {  // :261
+            bool changed = false;
+            for (uint64_t r = 0; r < n; ++r) {
+                uint64_t best = 0;
+                float bd = INFINITY;
+                for (uint64_t k = 0; k < ksub; ++k) {
+                    const float d = o_pq_dist(v + r * dim + sub * dsub, c + k * dsub, dsub);
+                    if (d < bd) {
+                        bd = d;
+                        best = k;
+                    }
+                }
+                if (best != 0) changed = true;  // assignments were reset to 0 (:264, :279-281)
+                assign[r] = best;
+            }
+            for (uint64_t k = 0; k < ksub; ++k) {  // :286-309
+                uint64_t cnt = 0;
+                for (uint64_t d = 0; d < dsub; ++d) nc[d] = 0.0f;
+                for (uint64_t r = 0; r < n; ++r)
+                    if (assign[r] == k) {
+                        for (uint64_t d = 0; d < dsub; ++d) nc[d] += v[r * dim + sub * dsub + d];
+                        ++cnt;
+                    }
+                if (cnt)
+                    for (uint64_t d = 0; d < dsub; ++d) c[k * dsub + d] = nc[d] / (float)cnt;
+            }
+            if (!changed) break;
+        }
+    }
+}
+
+void cgo_pq_encode(const float* v, uint64_t n, uint64_t dim, uint64_t m, uint32_t nbits, const float* cent, uint8_t* codes) {
+    const uint64_t dsub = dim / m, ksub = 1ull << nbits;
+    for (uint64_t r = 0; r < n; ++r)
+        for (uint64_t sub = 0; sub < m; ++sub) {  // :196-214
+            uint64_t best = 0;
+            float bd = INFINITY;
+            for (uint64_t k = 0; k < ksub; ++k) {
+                const float d = o_pq_dist(v + r * dim + sub * dsub, cent + (sub * ksub + k) * dsub, dsub);
+                if (d < bd) {
+                    bd = d;
+                    best = k;
+                }
+            }
+            codes[r * m + sub] = (uint8_t)best;
+        }
+}
+
 }  // extern "C"

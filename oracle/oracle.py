@@ -299,3 +299,71 @@ def merge_topk(idx, score, k):
 
 def max_threads():
     return int(lib().cgo_max_threads())
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def sq_train(v, nbits, uniform):
+    """persistent.rs:355-408 -> (scales, biases)"""
+    v, pv = _f(v)
+    n, dim = v.shape
+    sc, bi = np.empty(dim, np.float32), np.empty(dim, np.float32)
+    L = lib()
+    L.cgo_sq_train.restype = None
+    L.cgo_sq_train.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                               C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.cgo_sq_train(pv, n, dim, nbits, int(uniform), sc.ctypes.data_as(C.POINTER(C.c_float)),
+                   bi.ctypes.data_as(C.POINTER(C.c_float)))
+    return sc, bi
+
+
+def sq_encode(v, nbits, scales, biases):
+    v, pv = _f(v)
+    n, dim = v.shape
+    bpv = 1 if nbits == 8 else (2 if nbits == 16 else 4)
+    out = np.empty((n, dim * bpv), np.uint8)
+    L = lib()
+    L.cgo_sq_encode.restype = None
+    L.cgo_sq_encode.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_float),
+                                C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+    L.cgo_sq_encode(pv, n, dim, nbits, _f(scales)[1], _f(biases)[1], _u8p(out))
+    return out
+
+
+def sq_decode(codes, dim, nbits, scales, biases):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n = codes.shape[0]
+    out = np.empty((n, dim), np.float32)
+    L = lib()
+    L.cgo_sq_decode.restype = None
+    L.cgo_sq_decode.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_float),
+                                C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.cgo_sq_decode(_u8p(codes), n, dim, nbits, _f(scales)[1], _f(biases)[1], out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def pq_train(v, m, nbits):
+    """persistent.rs:155-187, 245-318 -> centroids [m, 2^nbits, dim/m]"""
+    v, pv = _f(v)
+    n, dim = v.shape
+    cent = np.zeros((m, 1 << nbits, dim // m), np.float32)
+    L = lib()
+    L.cgo_pq_train.restype = None
+    L.cgo_pq_train.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
+    L.cgo_pq_train(pv, n, dim, m, nbits, cent.ctypes.data_as(C.POINTER(C.c_float)))
+    return cent
+
+
+def pq_encode(v, cent):
+    v, pv = _f(v)
+    n, dim = v.shape
+    m, ksub, _ = cent.shape
+    codes = np.empty((n, m), np.uint8)
+    L = lib()
+    L.cgo_pq_encode.restype = None
+    L.cgo_pq_encode.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_float),
+                                C.POINTER(C.c_uint8)]
+    L.cgo_pq_encode(pv, n, dim, m, int(ksub).bit_length() - 1, _f(cent)[1], _u8p(codes))
+    return codes

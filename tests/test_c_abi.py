@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     m.build_library()
     L = ctypes.CDLL(m.cgvec.LIB_PATH)
     syms = _declared_symbols()
-    assert len(syms) >= 55 and "cgv_i8_search_optimized" in syms and "cgv_search_begin_f32_dev" in syms
+    assert len(syms) >= 75 and "cgv_i8_search_optimized" in syms and "cgv_search_begin_f32_dev" in syms and "cgv_pq_train_f32" in syms
     for s in syms:
         assert hasattr(L, s), f"{s} declared in cgvec.h but not exported"
 
@@ -52,6 +52,10 @@ def test_int8_scan_fails_loudly_without_gpu():
     assert "no CPU fallback" in str(ei.value)
     with pytest.raises(m.CgvError):
         m.quantize_u8([[0.5, 0.25]])
+    with pytest.raises(m.CgvError, match="no CPU fallback"):
+        m.ScalarQuantizer(8)
+    with pytest.raises(m.CgvError, match="no CPU fallback"):
+        m.ProductQuantizer(8, 2, 4)
 
 
 def test_argument_validation_needs_no_gpu():
