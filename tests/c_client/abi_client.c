@@ -1,0 +1,68 @@
+/* A plain-C client of include/cgvec.h: what a compiled host (the Rust shim of INTEGRATION.md, a C++
+ * service, ...) does with the library. No Python, no torch: dlopen-free static linking against
+ * libcgvec_hip.so. Usage: abi_client <in.bin> <out.bin> [dtype]
+ *   in.bin : u32 n, u32 dim, u32 nq, u32 k, then n*dim f32 corpus rows, then nq*dim f32 queries
+ *   out.bin: nq*k u64 ids, then nq*k f32 scores
+ * Exit code 3 = no GPU (the library has no CPU fallback). */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cgvec.h"
+
+static int die(const char* what, int rc) {
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, cgv_last_error());
+    return rc == CGV_ERR_HIP ? 3 : 2;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s in.bin out.bin [dtype]\n", argv[0]);
+        return 1;
+    }
+    const int dtype = argc > 3 ? atoi(argv[3]) : CGV_DTYPE_BF16;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 1;
+    uint32_t hdr[4];
+    if (fread(hdr, 4, 4, f) != 4) return 1;
+    const uint32_t n = hdr[0], dim = hdr[1], nq = hdr[2], k = hdr[3];
+    float* rows = (float*)malloc((size_t)n * dim * 4);
+    float* q = (float*)malloc((size_t)nq * dim * 4);
+    if (fread(rows, 4, (size_t)n * dim, f) != (size_t)n * dim) return 1;
+    if (fread(q, 4, (size_t)nq * dim, f) != (size_t)nq * dim) return 1;
+    fclose(f);
+
+    cgv_index* h = NULL;
+    int rc = cgv_create(dim, CGV_METRIC_COSINE, dtype, 0, &h);
+    if (rc) return die("cgv_create", rc);
+    /* two appends, like a store that grows */
+    if ((rc = cgv_add_f32(h, rows, n / 2))) return die("cgv_add_f32", rc);
+    if ((rc = cgv_add_f32(h, rows + (size_t)(n / 2) * dim, n - n / 2))) return die("cgv_add_f32", rc);
+    if (cgv_count(h) != n || cgv_dim(h) != dim) return 2;
+
+    uint64_t* idx = (uint64_t*)malloc((size_t)nq * k * 8);
+    float* sc = (float*)malloc((size_t)nq * k * 4);
+    if ((rc = cgv_search_f32(h, q, nq, k, idx, sc))) return die("cgv_search_f32", rc);
+
+    /* the degenerate inputs of surreal_store.rs:62-64 succeed without touching the outputs */
+    if ((rc = cgv_search_f32(h, q, 0, k, idx, sc)) || (rc = cgv_search_f32(h, q, nq, 0, idx, sc))) return die("empty", rc);
+    /* a dimension error is an error, with a message (simd_ops.rs:16-18) */
+    float* back = (float*)malloc((size_t)dim * 4);
+    if (cgv_get_row_f32(h, (uint64_t)n + 5, back) != CGV_ERR_OUT_OF_RANGE || !strlen(cgv_last_error())) return 2;
+    if ((rc = cgv_get_row_f32(h, 1, back))) return die("cgv_get_row_f32", rc);
+
+    cgv_stats st;
+    if ((rc = cgv_get_stats(h, &st))) return die("cgv_get_stats", rc);
+    printf("rows=%llu device_bytes=%llu path=%u fallback=%llu\n", (unsigned long long)st.n_rows,
+           (unsigned long long)st.device_bytes, st.last_path, (unsigned long long)st.fallback_queries);
+
+    f = fopen(argv[2], "wb");
+    if (!f) return 1;
+    fwrite(idx, 8, (size_t)nq * k, f);
+    fwrite(sc, 4, (size_t)nq * k, f);
+    fwrite(back, 4, dim, f);
+    fclose(f);
+    cgv_destroy(h);
+    return 0;
+}

@@ -1,0 +1,63 @@
+"""A plain-C program against include/cgvec.h (tests/c_client/abi_client.c): compiles with gcc, links the
+library without Python or torch in the process. On a GPU box its results must equal the oracle's;
+without a GPU it must fail loudly (exit 3, "no CPU fallback")."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from _util import ROOT, pkg
+
+SRC = os.path.join(ROOT, "tests", "c_client", "abi_client.c")
+
+
+def _build(tmp_path):
+    m = pkg()
+    m.build_library()
+    exe = str(tmp_path / "abi_client")
+    libdir = os.path.dirname(m.cgvec.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+                           "-L", libdir, "-lcgvec_hip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def _write_input(path, rows, q, k):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIII", rows.shape[0], rows.shape[1], q.shape[0], k))
+        f.write(rows.tobytes())
+        f.write(q.tobytes())
+
+
+def test_c_client_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build(tmp_path)
+    m = pkg()
+    if m.device_count() > 0:
+        pytest.skip("GPU present")
+    rng = np.random.default_rng(0)
+    _write_input(tmp_path / "in.bin", rng.standard_normal((64, 16)).astype(np.float32),
+                 rng.standard_normal((2, 16)).astype(np.float32), 5)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert p.returncode == 3 and "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,odt", [(1, 1), (0, 0), (4, 0)])
+def test_c_client_results_equal_oracle(tmp_path, oracle, dtype, odt):
+    exe = _build(tmp_path)
+    rng = np.random.default_rng(3)
+    n, d, nq, k = 20_000, 256, 33, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    _write_input(tmp_path / "in.bin", rows, q, k)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(dtype)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert f"rows={n}" in p.stdout
+    raw = open(tmp_path / "out.bin", "rb").read()
+    idx = np.frombuffer(raw[: nq * k * 8], dtype=np.uint64).reshape(nq, k)
+    sc = np.frombuffer(raw[nq * k * 8: nq * k * 12], dtype=np.float32).reshape(nq, k)
+    back = np.frombuffer(raw[nq * k * 12:], dtype=np.float32)
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+    assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    assert np.array_equal(back, oracle.round_trip(rows[1], odt))
