@@ -25,10 +25,12 @@
  *     reproduced bit-for-bit by the exact re-score kernel;
  *   - short results are padded with (UINT64_MAX, -inf).
  *
- * Threading: cgv_search_* may be called concurrently on one handle (serialised
- * internally); cgv_add_* / cgv_reserve / cgv_destroy need exclusive access — the same
- * contract as the reference's `tokio::sync::Mutex<SurrealDbStorage>` (surreal_store.rs:
- * 45-47) plus `&mut self` on store_embeddings (traits.rs:13).
+ * Threading: cgv_search_* may be called concurrently on one handle — the handle owns a small pool
+ * of search contexts (HIP stream + scratch each), so concurrent callers, or one caller using
+ * cgv_search_begin/_end, overlap on the device; cgv_add_* / cgv_update_row / cgv_reserve wait for the
+ * searches in flight and then run alone; cgv_destroy needs exclusive access — the contract of the
+ * reference's `tokio::sync::Mutex<SurrealDbStorage>` (surreal_store.rs:45-47) plus `&mut self` on
+ * store_embeddings (traits.rs:13).
  */
 #ifndef CGVEC_H
 #define CGVEC_H
