@@ -515,12 +515,15 @@ __global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
 // over nsplit (workgroup, query) lists of CAND_CAPS entries — N is chosen so that the expected
 // list length stays at EMIT_TARGET and the per-query total at MERGE_TARGET. The last launch is
 // the dominant one.
-constexpr uint32_t BOOT_TILES = 4;    // 1024 rows (large corpora)
-constexpr uint32_t BOOT_TILES_SMALL = 16;  // 4096 rows when the corpus is at most 2048 tiles (512k rows): one coarse
-                                          // launch then covers everything and a 4x tighter first threshold cuts its
-                                          // emissions 4x (C2 / 8 GPUs: 0.382 -> 0.354 ms per batch); larger corpora
-                                          // measured flat (+-1 %), so they keep the cheaper boot
-constexpr uint32_t EMIT_TARGET = 24;  // expected entries per (workgroup, query) list per launch
+constexpr uint32_t BOOT_TILES = 16;  // 4096 rows scored densely by boot_kernel (25 us); the register-only select takes <= 4096
+// Expected entries per (workgroup, query) list per launch. The threshold of a launch was learnt from
+// `seen` rows, so k' * 1024 / seen scores of every 32 x 32 block pass the epilogue's fast filter and
+// take its slow path: ~19 us per tile at 16 hits per block (seen = 1024 rows), ~8 us at 4, nothing
+// at 0.2 (measured, r01d timelines). A 4096-row boot and shorter early launches keep the hit rate
+// down where it matters: C2 682 k -> 726 k q/s, C3 shard +3 %, f32 + shadow (k' = 56, lower target)
+// 590 k -> 632 k; C4 / C5 / small shards flat.
+constexpr uint32_t EMIT_TARGET = 12;
+constexpr uint32_t EMIT_TARGET_WIDE = 6;  // k' > 32 (the hit rate scales with k')
 constexpr uint32_t MERGE_TARGET = 2048;  // expected candidates per query per launch (select holds 8192;
                                          // the count fluctuates by ~1/sqrt(k') around its mean)
 
@@ -541,9 +544,8 @@ uint32_t gcd_u32(uint32_t a, uint32_t b) {
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
-    // (also when many candidates are kept per query - the f32 + shadow index, k' = 4k+16: emissions scale
-    // with k', C2 shape 548 k -> 591 k q/s)
-    const uint32_t boot = (p.ntiles <= 2048 || kprime > 32) ? BOOT_TILES_SMALL : BOOT_TILES;
+    const uint32_t boot = BOOT_TILES;
+    const uint32_t emit_target = kprime > 32 ? EMIT_TARGET_WIDE : EMIT_TARGET;
     p.T1 = std::min<uint32_t>(std::max<uint32_t>((kprime + BM - 1) / BM, boot), p.ntiles);
     p.R = p.ntiles - p.T1;
     p.P = 1;
@@ -557,7 +559,7 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     while (left > 0) {
         const uint32_t nsplit = std::min<uint32_t>(left, nsplit_max);
         // rows this launch may cover: k' * N / seen / nsplit <= EMIT_TARGET
-        uint64_t rows = seen * std::min<uint64_t>((uint64_t)nsplit * EMIT_TARGET, MERGE_TARGET) / std::max<uint32_t>(kprime, 1);
+        uint64_t rows = seen * std::min<uint64_t>((uint64_t)nsplit * emit_target, MERGE_TARGET) / std::max<uint32_t>(kprime, 1);
         uint32_t tiles = (uint32_t)std::min<uint64_t>(left, std::max<uint64_t>(rows / BM, nsplit));
         if (tiles * 3 >= left * 2) tiles = left;  // do not leave a small tail for another launch
         p.counts.push_back(tiles);
