@@ -144,7 +144,7 @@ def main():
 
     # `depth` batches in flight (the index' context pool: each batch on its own HIP stream), every
     # one of the K steps begun AND completed inside the timed region.
-    depth = max(1, args.depth)
+    depth = max(1, min(args.depth, ix.max_in_flight))
     for i in range(args.warmup):
         searcher.search(qpool[i % npool], k)
     sync_all()

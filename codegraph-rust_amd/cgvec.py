@@ -85,6 +85,8 @@ def lib():
     L.cgv_search_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp]
     L.cgv_search_begin_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp, C.POINTER(u64)]
     L.cgv_search_end.argtypes = [vp, u64]
+    L.cgv_max_batches_in_flight.argtypes = [vp]
+    L.cgv_max_batches_in_flight.restype = u32
     L.cgv_get_row_f32.argtypes = [vp, u64, vp]
     L.cgv_batch_similarity_f32.argtypes = [vp, vp, i32, u64, vp]
     L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
@@ -247,6 +249,11 @@ class HipKnnIndex:
         out = np.empty(self.dim, dtype=np.float32)
         _check(lib().cgv_get_row_f32(self._h, int(i), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    @property
+    def max_in_flight(self):
+        """How many search_begin() results one thread may hold before it must wait() on one."""
+        return int(lib().cgv_max_batches_in_flight(self._h))
 
     def search_begin(self, queries, k):
         """Enqueue one batch (CUDA tensor [nq, dim]) and return a PendingSearch; .wait() gives

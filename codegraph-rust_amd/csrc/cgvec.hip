@@ -1270,6 +1270,8 @@ int cgv_search_end(cgv_index* h, uint64_t ticket) {
     return rc;
 }
 
+uint32_t cgv_max_batches_in_flight(const cgv_index* h) { return h ? (uint32_t)N_CTX : 0u; }
+
 int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint64_t* out_idx_dev,
                        float* out_score_dev) {
     uint64_t t = 0;

@@ -160,6 +160,9 @@ int cgv_save_mmap(cgv_index* h, const char* path);
 int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k,
                              uint64_t* out_idx_dev, float* out_score_dev, uint64_t* ticket);
 int cgv_search_end(cgv_index* h, uint64_t ticket);
+/* Size of the context pool = how many begin calls one thread may have outstanding before it must call end
+ * (a further begin would wait for a context that only this thread can release). */
+uint32_t cgv_max_batches_in_flight(const cgv_index* h);
 
 /* Copy stored row `id` (local id, without index_base) back as f32 (upcast of the
  * stored value). Replaces VectorStore::get_embedding (traits.rs:15) /
