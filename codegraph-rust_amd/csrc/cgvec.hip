@@ -741,6 +741,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
         if (h->shadow) r.eps_scale *= 2.0f;  // two accumulation-order terms: MFMA-on-shadow and the reference on f32
+        // fp8: the matrix pipe's internal accumulation of 8-bit products is coarser than one f32 rounding per
+        // term (largest observed error 2.0e-5 at D = 768, i.e. 0.75 of the f32-depth bound): 4x head room
+        if (h->dtype == CGV_DTYPE_FP8E4M3) r.eps_scale *= 4.0f;
         c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
