@@ -22,8 +22,8 @@
 //     groups, retired by a counted s_waitcnt vmcnt(8); the stream never ends (no tail branches);
 //   * hand-pinned software pipeline: fragments double-buffered in registers (the 6 ds_reads of
 //     the next k-step are issued right after the first MFMA of the current one); one raw
-//     s_barrier per stage, placed after the first MFMA of the stage's last k-step; every MFMA
-//     is unconditional (accumulators are cleared after the tile epilogue);
+//     s_barrier per stage, placed after the first MFMA of the stage's last k-step; the loop is
+//     tile-structured: the first k-step of a tile runs zero-C MFMAs in its own straight-line block;
 //   * a workgroup is persistent over a list of corpus tiles for ONE query tile: the
 //     (tile, k-chunk) sequence is one flat pipeline across tile boundaries;
 //   * MFMA C layout (32x32): lane holds column (= query) lane&31 and 16 rows
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
     frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
     if (ABL & 8) {
         for (int i = 0; i < MB; ++i) fa0[i] = fa1[i] = (frag)0;
@@ -376,6 +379,15 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         acc[3][0] = Mfma<DT>::mma(FA[3], FB[0], acc[3][0]);     \
         acc[3][1] = Mfma<DT>::mma(FA[3], FB[1], acc[3][1]);     \
     }
+// first k-step of a tile: C operand = 0 (an inline constant in the MFMA encoding) instead of clearing
+// 128 accumulator registers per tile. These run in their own straight-line block at every tile
+// boundary (never as a branch inside the stage loop: that made the register allocator copy the
+// accumulators around phis).
+#define CGV_MMA_Z(FA, FB, GLO, GHI)                                                              \
+    {                                                                                            \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) \
+            if (mb * NB + nb >= GLO && mb * NB + nb < GHI) acc[mb][nb] = Mfma<DT>::mma(FA[mb], FB[nb], zero16);    \
+    }
 
     // ---- prologue: three stages in flight --------------------------------------------
     if (total == 0) {  // uniform: nothing to stream for this workgroup
@@ -399,8 +411,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // of (s-1,1): by then every wave has all its reads of stage s-1 back (lgkmcnt(0) in front of
     // that MFMA), so slot (s-1)&3 is free for the DMA of stage s+3, and each wave has waited for
     // its own share of stage s (counted vmcnt: the 8 younger DMA instructions are stages s+1,
-    // s+2), so stage s may be read. DMA lead: 3 stages. All MFMAs are unconditional (no
-    // accumulator phis for the register allocator to copy around).
+    // s+2), so stage s may be read. DMA lead: 3 stages. No MFMA sits inside a branch of a loop body
+    // (no accumulator phis for the register allocator to copy around).
 #define CGV_A_PHASE(SB)                      \
     {                                        \
         CGV_SB;                              \
@@ -419,65 +431,95 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_MMA_G3(fa0, fb0);                \
         CGV_SB;                              \
     }
-#define CGV_EPILOGUE()                                                                                         \
-    {                                                                                                          \
-        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
-                                                      invn_s + (pj & (NINV - 1)) * 256,                        \
-                                                      stat_s + (pj & (NINV - 1)) * 16);                        \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)    \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;                              \
+#define CGV_A_PHASE_Z(SB)                                \
+    {                                                    \
+        CGV_SB;                                          \
+        CGV_MMA_Z(fa0, fb0, 0, 1);                       \
+        CGV_SB;                                          \
+        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa1, fb1, SB, 1); \
+        CGV_SB;                                          \
+        CGV_MMA_Z(fa0, fb0, 1, 4);                       \
+        CGV_SB;                                          \
+        issue_q(2);                                      \
+        CGV_SB;                                          \
+        CGV_MMA_Z(fa0, fb0, 4, 6);                       \
+        CGV_SB;                                          \
+        issue_q(3);                                      \
+        CGV_SB;                                          \
+        CGV_MMA_Z(fa0, fb0, 6, 8);                       \
+        CGV_SB;                                          \
     }
-#define CGV_ADVANCE()            \
-    if (++ckc == KC) {           \
-        ckc = 0;                 \
-        ptile = a.T1 + ct;       \
-        pj = cj;                 \
-        ++cj;                    \
-        ct = next_tile(ct);      \
+#define CGV_B_PHASE(SB)                                                        \
+    {                                                                          \
+        CGV_SB;                                                                \
+        CGV_MMA_G0(fa1, fb1);                                                  \
+        CGV_SB;                                                                \
+        if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                          \
+        CGV_SB;                                                                \
+        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa0, fb0, SB, 0);                       \
+        CGV_SB;                                                                \
+        CGV_MMA_G1(fa1, fb1);                                                  \
+        CGV_SB;                                                                \
+        issue_q(0);                                                            \
+        CGV_SB;                                                                \
+        CGV_MMA_G2(fa1, fb1);                                                  \
+        CGV_SB;                                                                \
+        issue_q(1);                                                            \
+        CGV_SB;                                                                \
+        CGV_MMA_G3(fa1, fb1);                                                  \
+        CGV_SB;                                                                \
     }
+#define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
+    if (!(ABL & 1))                                                                                                \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
+                                                      invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
+                                                      stat_s + ((SEQ) & (NINV - 1)) * 16);
 
-    uint32_t cj = 0, ckc = 0, ct = t_first, ptile = 0, pj = 0;
+    // Tile-structured: [first stage of a tile: zero-C MFMAs] then KC-1 ordinary stages; at a tile
+    // boundary the iteration is B phase (last k-step of the previous tile), its epilogue, zero-C A phase.
+    const uint32_t ntl = jhi - jlo;
+    uint32_t ct = t_first, s = 1;
     issue_q(0);  // stage 3 -> slot 3 (never used so far)
     issue_q(1);
-    CGV_A_PHASE(smem);
-    CGV_ADVANCE();
+    CGV_A_PHASE_Z(smem);
 #pragma unroll 1
-    for (uint32_t s = 1; s < total; ++s) {
+    for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
         const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-        CGV_SB;
-        CGV_MMA_G0(fa1, fb1);
-        CGV_SB;
-        if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-        CGV_SB;
-        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa0, fb0, sb, 0);
-        CGV_SB;
-        CGV_MMA_G1(fa1, fb1);
-        CGV_SB;
-        issue_q(0);
-        CGV_SB;
-        CGV_MMA_G2(fa1, fb1);
-        CGV_SB;
-        issue_q(1);
-        CGV_SB;
-        CGV_MMA_G3(fa1, fb1);
-        CGV_SB;
-        if (ckc == 0 && !(ABL & 1)) CGV_EPILOGUE();  // (s-1,1) was the last k-step of tile ptile
+        CGV_B_PHASE(sb);
         CGV_A_PHASE(sb);
-        CGV_ADVANCE();
     }
-    // tail: (total-1, 1), then the last tile's epilogue
+#pragma unroll 1
+    for (uint32_t tl = 1; tl < ntl; ++tl) {
+        {
+            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            CGV_B_PHASE(sb);
+            CGV_EPILOGUE(a.T1 + ct, tl - 1);
+            ct = next_tile(ct);
+            CGV_A_PHASE_Z(sb);
+            ++s;
+        }
+#pragma unroll 1
+        for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
+            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            CGV_B_PHASE(sb);
+            CGV_A_PHASE(sb);
+        }
+    }
+    // tail: second k-step of the last stage, then the last tile's epilogue
     CGV_SB;
     CGV_MMA_G0(fa1, fb1);
     CGV_MMA_G1(fa1, fb1);
     CGV_MMA_G2(fa1, fb1);
     CGV_MMA_G3(fa1, fb1);
     CGV_SB;
-    CGV_EPILOGUE();
+    CGV_EPILOGUE(a.T1 + ct, ntl - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail before the LDS is released
+#undef CGV_A_PHASE_Z
+#undef CGV_B_PHASE
+#undef CGV_MMA_Z
 #undef CGV_A_PHASE
 #undef CGV_EPILOGUE
-#undef CGV_ADVANCE
 #undef CGV_SB
 #undef CGV_MMA_G0
 #undef CGV_MMA_G1
