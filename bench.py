@@ -3,31 +3,40 @@
 brute-force cosine kNN at BASELINE.json config C2 (1M x 768 bf16, batch = 1024, k = 10).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank
-   per GPU; the 1M-row corpus is row-sharded across ranks — STRONG scaling — and the
-   per-shard partial top-k are combined with one RCCL all-gather + a merge kernel.)
+  N > 1: one rank per GPU over RCCL. Started either by the launcher
+  (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) or plainly
+  (`python bench.py --gpus N`): with no WORLD_SIZE in the environment the script re-executes itself
+  under torch.distributed.run on 127.0.0.1. The 1M-row corpus is row-sharded across the ranks
+  (STRONG scaling: BASELINE's metric is quoted on ONE 1M-row corpus), every rank searches its shard
+  with the full query batch, the per-shard top-k are combined with one RCCL all-gather of packed
+  12-byte records + a merge kernel.
 
-A "step" is one batched search (1024 queries against the whole corpus) with corpus AND
-queries already resident in HBM. `--depth` (default 2) batches are kept in flight through the
-library's search-context pool (each batch on its own HIP stream); all K steps are begun and
-completed inside the timed region. Rank 0 prints ONE JSON line.
-Other workloads (--workload): c4, c3shard, c5shard, c5mini, c2shard8, small — parity / sizing
-cases of BASELINE.json, not the headline line.
+A "step" is SURVEY.md §8(d)'s unit: ONE batched search of 1024 queries against the whole corpus,
+corpus resident in HBM, queries starting in (pinned) HOST memory and the B*k results ending in
+host memory — H2D of the queries and D2H of the results are inside the step; steps are strictly
+serial (one batch at a time). `value` = batch * K / wall time of the K timed steps (max over
+ranks); `median_qps` is the same from the median step. The device-resident, two-batches-in-flight
+rate of round 1 is reported beside it as `pipelined_qps`, never as `value`.
+Other workloads (--workload): c4, c3shard, c5shard, c5mini, c2shard8, small, c2f32 — parity /
+sizing cases of BASELINE.json, not the headline line.
 
   roofline     : the dominant kernel (MFMA coarse GEMM with fused top-k') — algorithmic
                  FLOPs 2*B*rows*D of one launch / its HIP-event duration (events recorded by
                  the library on the stream the kernel runs on), vs the 2.5 PFLOP/s dense bf16
-                 MFMA peak (MI355X_MICROARCH.md).
-  cpu_baseline : the CPU oracle (a faithful port of the reference's
-                 parallel_top_k_search, simd_ops.rs:361-383: AVX2+FMA scoring of separately
-                 allocated rows + full parallel sort) timed on this box's host cores on a
-                 bounded sample of the same workload (rank 0, N = 1 only).
+                 MFMA peak (MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from the
+                 committed rocprofv3 PMC passes (profiles/).
+  cpu_baseline : the CPU oracle (a port of the reference's parallel_top_k_search,
+                 simd_ops.rs:361-383: AVX2+FMA scoring of separately allocated rows + full
+                 parallel sort) timed on this box's host cores on a bounded sample of the same
+                 workload (rank 0, N = 1 only).
 """
 import argparse
 import collections
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -81,25 +90,46 @@ def gen_chunk(c, rows, dim, device):
     return torch.nn.functional.normalize(x, dim=1)
 
 
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` without a launcher: run the same command as N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--host-io-steps", type=int, default=10, help="extra host-pointer-API batches (0 = skip)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = strictly serial steps)")
+    ap.add_argument("--pipelined-steps", type=int, default=20,
+                    help="extra device-resident batches kept `--depth` in flight (0 = skip)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight of the pipelined side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=128)
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="print this rank's RANK/WORLD_SIZE and exit before touching a GPU (CPU test of the self-spawn)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_under_launcher(args.gpus))
 
     n_total, dim, dtype, metric, batch, k = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.spawn_check:
+        print(json.dumps({"spawn_check": True, "rank": rank, "local_rank": local_rank, "world": world,
+                          "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -133,6 +163,9 @@ def main():
     npool = 4
     qpool = [torch.nn.functional.normalize(torch.randn((batch, dim), generator=gq, device=dev), dim=1)
              for _ in range(npool)]
+    qhost = [q.cpu().pin_memory() for q in qpool]           # the caller's query batches: pinned host memory
+    out_i = torch.empty((batch, k), dtype=torch.int64).pin_memory()
+    out_s = torch.empty((batch, k), dtype=torch.float32).pin_memory()
     searcher = m.ShardedKnn(ix, rank=rank, world=world) if world > 1 else ix
     ix.set_profiling(True)
 
@@ -142,30 +175,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # `depth` batches in flight (the index' context pool: each batch on its own HIP stream), every
-    # one of the K steps begun AND completed inside the timed region.
-    depth = max(1, min(args.depth, ix.max_in_flight))
-    for i in range(args.warmup):
-        searcher.search(qpool[i % npool], k)
-    sync_all()
-    coarse_ms, coarse_rows = [], 0
-    pend = collections.deque()
+    if world == 1:
+        L, C = m.cgvec.lib(), m.cgvec.C
+        oi_p, os_p = C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr())
 
-    def retire():
-        nonlocal coarse_rows
-        out = pend.popleft().wait()
+        def step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
+            m.cgvec._check(L.cgv_search_f32(ix._h, C.c_void_p(qhost[i % npool].data_ptr()), batch, k, oi_p, os_p))
+    else:
+        def step(i):   # every rank: H2D of the (replicated) batch, shard search, all-gather + merge, D2H
+            q = qhost[i % npool].to(dev, non_blocking=True)
+            gi, gs = searcher.search(q, k)
+            out_i.copy_(gi, non_blocking=True)
+            out_s.copy_(gs, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    coarse_ms, coarse_rows, step_ms = [], 0, []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        step(i)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         st = ix.stats()   # host-side read of that batch's HIP-event pair; no extra device sync
         coarse_ms.append(st["last_coarse_ms"])
         coarse_rows = st["coarse_rows"]
-        return out
-
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        pend.append(searcher.search_begin(qpool[i % npool], k))
-        if len(pend) >= depth:
-            out_idx, out_sc = retire()
-    while pend:
-        out_idx, out_sc = retire()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -174,21 +209,46 @@ def main():
         elapsed = float(t.item())
     st = ix.stats()
 
+    # side measurement: device-resident queries and results, `depth` batches in flight (round 1's headline)
+    pipelined = None
+    if args.pipelined_steps > 0:
+        depth = max(1, min(args.depth, ix.max_in_flight))
+        pend = collections.deque()
+        sync_all()
+        tp = time.perf_counter()
+        for i in range(args.pipelined_steps):
+            pend.append(searcher.search_begin(qpool[i % npool], k))
+            if len(pend) >= depth:
+                pend.popleft().wait()
+        while pend:
+            pend.popleft().wait()
+        sync_all()
+        dtp = time.perf_counter() - tp
+        if dist is not None:
+            t = torch.tensor([dtp], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtp = float(t.item())
+        pipelined = {"queries_per_sec": round(batch * args.pipelined_steps / dtp, 1),
+                     "ms_per_batch": round(1e3 * dtp / args.pipelined_steps, 4), "batches_in_flight": depth,
+                     "note": "queries and results stay in HBM (cgv_search_begin_f32_dev / cgv_search_end)"}
+
     result = None
     if rank == 0:
         qps = batch * args.steps / elapsed
+        med = float(np.median(step_ms))
         cms = float(np.mean([c for c in coarse_ms if c > 0])) if any(c > 0 for c in coarse_ms) else None
         roof = None
         if cms:
             flops = 2.0 * batch * coarse_rows * dim
             ach = flops / (cms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_main_kernel.json")) \
-                if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-            if pmc and args.workload == "c2" and world == 1:
+            pdir = os.path.join(ROOT, "profiles")
+            pmc = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{args.workload}_pmc_main_kernel.json")) \
+                if os.path.isdir(pdir) else []
+            if pmc and world == 1:
                 # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/collect_profiles.sh)
-                traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("hbm_bytes_per_launch")
+                traffic = json.load(open(os.path.join(pdir, pmc[-1]))).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/" + pmc[-1]
             abytes = float(coarse_rows) * dim * ESIZE[dtype] + batch * dim * ESIZE[dtype] + coarse_rows * 4
             gbs = abytes / (cms * 1e-3) / 1e9
@@ -204,7 +264,7 @@ def main():
             roof.update({"kernel": "coarse_kernel (main stage)", "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "avg_launch_ms": round(cms, 4),
                          "rows_per_launch": int(coarse_rows), "algorithmic_flops_per_launch": flops,
-                         "algorithmic_bytes_per_launch": abytes})
+                         "algorithmic_bytes_per_launch": abytes, "rank": 0})
         result = {
             "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -213,25 +273,16 @@ def main():
             "config": {"workload": f"{args.workload.upper()}: {n_total} x {dim} {dtype} {metric} brute-force kNN, "
                                    f"batch={batch}, k={k}", "rows": n_total, "dim": dim, "batch": batch, "k": k,
                        "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
-                       "batches_in_flight": depth},
+                       "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
+                       "exchange": f"RCCL all-gather, world={world}" if world > 1 else "none"},
+            "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
+            "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
+            "pipelined": pipelined,
             "roofline": roof,
             "pipeline": {"device_ms_last_step": round(st["last_total_ms"], 4), "kprime": st["last_kprime"],
                          "fallback_queries": int(st["fallback_queries"]), "eps": st["last_eps"],
                          "max_observed_coarse_err": st["max_observed_err"]},
         }
-
-    if rank == 0 and world == 1 and args.host_io_steps > 0:
-        # PCIe-inclusive rate of the host-pointer entry point (cgv_search_f32: queries H2D, results D2H,
-        # serial batches). Reported beside `value`, never as it.
-        qh_np = qpool[0].cpu().numpy()
-        ix.search(qh_np, k)
-        t0 = time.perf_counter()
-        for _ in range(args.host_io_steps):
-            ix.search(qh_np, k)
-        dt = time.perf_counter() - t0
-        result["host_pointer_api"] = {"queries_per_sec": round(batch * args.host_io_steps / dt, 1),
-                                      "ms_per_batch": round(1e3 * dt / args.host_io_steps, 4),
-                                      "note": "cgv_search_f32: pageable host queries in, host results out, one batch at a time"}
 
     if want_cpu:
         from oracle import oracle as o   # CPU baseline + recall checker only
@@ -262,10 +313,13 @@ def main():
                                   "kind": "port",
                                   "sample": f"{nqc} single-query searches over the same {n_total} x {dim} corpus "
                                             f"(f32 upcast of the {dtype} values, rows separately allocated), "
-                                            f"{cpu_t:.1f} s wall"}
+                                            f"{cpu_t:.1f} s wall; C++ port of parallel_top_k_search: threaded AVX2 "
+                                            f"scoring + threaded sort whose last merge levels are single-threaded "
+                                            f"(rayon's par_sort_unstable_by is not) - a slight under-estimate"}
         result["recall_at_10"] = hits / (nqc * k)
         result["ordered_match_rate"] = ordered / nqc
         result["score_bit_exact_rate"] = exact_scores / nqc
+        result["recall_sample"] = f"{nqc} of the {batch} queries of one batch"
         result["speedup_vs_cpu_baseline"] = round(result["value"] / (nqc / cpu_t), 1)
     elif rank == 0:
         result["cpu_baseline"] = None

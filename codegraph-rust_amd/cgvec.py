@@ -18,7 +18,9 @@ DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3, "f32s": 4}
 
 CGV_OK = 0
 CGV_ERR_INVALID_ARG, CGV_ERR_DIM_MISMATCH, CGV_ERR_HIP, CGV_ERR_OOM = 1, 2, 3, 4
-CGV_ERR_NONFINITE, CGV_ERR_OUT_OF_RANGE, CGV_ERR_INTERNAL, CGV_ERR_IO = 5, 6, 7, 8
+CGV_ERR_NONFINITE, CGV_ERR_OUT_OF_RANGE, CGV_ERR_INTERNAL, CGV_ERR_IO, CGV_ERR_BUSY = 5, 6, 7, 8, 9
+CGV_MAX_K, CGV_FAST_MAX_K, CGV_SHARD_CHUNK_ROWS = 2048, 228, 4096
+EXCHANGE = {0: "none", 1: "rccl", 2: "copy"}
 PAD_IDX = np.uint64(2**64 - 1)
 
 
@@ -37,6 +39,14 @@ class Stats(C.Structure):
         ("last_eps", C.c_float), ("max_observed_err", C.c_float), ("last_coarse_ms", C.c_float),
         ("last_total_ms", C.c_float), ("coarse_rows", C.c_uint64), ("last_kprime", C.c_uint32),
         ("last_path", C.c_uint32),
+    ]
+
+
+class ShardedStats(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_uint64), ("device_bytes", C.c_uint64), ("searches", C.c_uint64), ("queries", C.c_uint64),
+        ("fallback_queries", C.c_uint64), ("n_shards", C.c_uint32), ("exchange", C.c_uint32),
+        ("last_search_ms", C.c_float), ("last_exchange_ms", C.c_float),
     ]
 
 
@@ -103,6 +113,29 @@ def lib():
     L.cgv_set_profiling.argtypes = [vp, i32]
     L.cgv_set_force_exact.argtypes = [vp, i32]
     L.cgv_debug_coarse_scores_dev.argtypes = [vp, vp, u32, vp]
+    L.cgv_set_id_map.argtypes = [vp, u32, u32, u32]
+    L.cgv_truncate.argtypes = [vp, u64]
+    L.cgv_score_ids_f32.argtypes = [vp, vp, u32, i32, vp, u32, vp]
+    L.cgv_sharded_create.argtypes = [u32, i32, i32, u32, C.POINTER(i32), C.POINTER(vp)]
+    L.cgv_sharded_destroy.argtypes = [vp]
+    L.cgv_sharded_reserve.argtypes = [vp, u64]
+    L.cgv_sharded_add_f32.argtypes = [vp, vp, u64]
+    L.cgv_sharded_update_row_f32.argtypes = [vp, u64, vp]
+    L.cgv_sharded_get_row_f32.argtypes = [vp, u64, vp]
+    L.cgv_sharded_count.argtypes = [vp]
+    L.cgv_sharded_count.restype = u64
+    L.cgv_sharded_n_shards.argtypes = [vp]
+    L.cgv_sharded_n_shards.restype = u32
+    L.cgv_sharded_shard.argtypes = [vp, u32]
+    L.cgv_sharded_shard.restype = vp
+    L.cgv_sharded_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
+    L.cgv_sharded_exchange.argtypes = [vp]
+    L.cgv_sharded_set_exchange.argtypes = [vp, i32]
+    L.cgv_sharded_get_stats.argtypes = [vp, C.POINTER(ShardedStats)]
+    for name in ("cgv_set_id_map", "cgv_truncate", "cgv_score_ids_f32", "cgv_sharded_create", "cgv_sharded_destroy",
+                 "cgv_sharded_reserve", "cgv_sharded_add_f32", "cgv_sharded_update_row_f32", "cgv_sharded_get_row_f32",
+                 "cgv_sharded_search_f32", "cgv_sharded_exchange", "cgv_sharded_set_exchange", "cgv_sharded_get_stats"):
+        getattr(L, name).restype = i32
     for name in ("cgv_pack_topk_dev", "cgv_merge_packed_dev", "cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
                  "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
@@ -319,6 +352,24 @@ class HipKnnIndex:
                                               out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def score_ids(self, queries, ids, op="cosine_seq"):
+        """op(query q, stored row ids[q][j]) for [nq, m] LOCAL ids in one launch (cgv_score_ids_f32): the
+        per-hit re-score of SemanticSearch::search_by_embedding without a host round trip per hit."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        i = np.ascontiguousarray(ids, dtype=np.uint64)
+        if q.ndim != 2 or q.shape[1] != self.dim or i.ndim != 2 or i.shape[0] != q.shape[0]:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, "queries [nq, dim] and ids [nq, m] expected")
+        out = np.zeros(i.shape, dtype=np.float32)
+        _check(lib().cgv_score_ids_f32(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0], self.OPS[op],
+                                       i.ctypes.data_as(C.c_void_p), i.shape[1], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_id_map(self, chunk_rows, n_shards, shard):
+        _check(lib().cgv_set_id_map(self._h, int(chunk_rows), int(n_shards), int(shard)))
+
+    def truncate(self, n):
+        _check(lib().cgv_truncate(self._h, int(n)))
+
     def search_baseline(self, query, limit):
         """ModelOptimizer::search_baseline -> (row ids, distances)."""
         q = np.ascontiguousarray(query, dtype=np.float32)
@@ -338,6 +389,95 @@ class HipKnnIndex:
         _check(lib().cgv_debug_coarse_scores_dev(self._h, C.c_void_p(q.data_ptr()), q.shape[0],
                                                  C.c_void_p(out.data_ptr())))
         return out
+
+
+class ShardedIndex:
+    """ONE handle over several devices in one process (cgv_sharded_*, csrc/sharded.hip): global row id =
+    insertion index, rows dealt block-cyclically to the shards, one exchange of the per-shard top-k
+    (RCCL all-gather when the devices are distinct, device copies when a device is listed twice)."""
+
+    def __init__(self, dim, devices, metric="cosine", dtype="bf16"):
+        self._h = C.c_void_p()
+        self.dim, self.metric, self.dtype = int(dim), metric, dtype
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _check(lib().cgv_sharded_create(self.dim, METRICS[metric], DTYPES[dtype], len(devices), devs, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().cgv_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib().cgv_sharded_count(self._h))
+
+    @property
+    def n_shards(self):
+        return int(lib().cgv_sharded_n_shards(self._h))
+
+    @property
+    def exchange(self):
+        return EXCHANGE[int(lib().cgv_sharded_exchange(self._h))]
+
+    def set_exchange(self, kind):
+        _check(lib().cgv_sharded_set_exchange(self._h, {"rccl": 1, "copy": 2}[kind]))
+
+    def reserve(self, n):
+        _check(lib().cgv_sharded_reserve(self._h, int(n)))
+
+    def add(self, rows):
+        if _is_torch(rows):
+            rows = rows.detach().float().cpu().numpy()
+        r = np.ascontiguousarray(rows, dtype=np.float32)
+        if r.ndim != 2 or r.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"expected [n,{self.dim}] rows, got {r.shape}")
+        _check(lib().cgv_sharded_add_f32(self._h, r.ctypes.data_as(C.c_void_p), r.shape[0]))
+
+    def update_row(self, i, row):
+        r = np.ascontiguousarray(row, dtype=np.float32)
+        _check(lib().cgv_sharded_update_row_f32(self._h, int(i), r.ctypes.data_as(C.c_void_p)))
+
+    def get_row(self, i):
+        out = np.empty(self.dim, dtype=np.float32)
+        _check(lib().cgv_sharded_get_row_f32(self._h, int(i), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def shard_counts(self):
+        L = lib()
+        return [int(L.cgv_count(C.c_void_p(L.cgv_sharded_shard(self._h, i)))) for i in range(self.n_shards)]
+
+    def shard_stats(self, i):
+        s = Stats()
+        _check(lib().cgv_get_stats(C.c_void_p(lib().cgv_sharded_shard(self._h, i)), C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def stats(self):
+        s = ShardedStats()
+        _check(lib().cgv_sharded_get_stats(self._h, C.byref(s)))
+        d = {f: getattr(s, f) for f, _ in ShardedStats._fields_}
+        d["exchange"] = EXCHANGE[d["exchange"]]
+        return d
+
+    def search(self, queries, k):
+        if _is_torch(queries):
+            queries = queries.detach().float().cpu().numpy()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {q.shape} != {self.dim}")
+        nq, k = q.shape[0], int(k)
+        idx = np.empty((nq, k), dtype=np.uint64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        if nq and k:
+            _check(lib().cgv_sharded_search_f32(self._h, q.ctypes.data_as(C.c_void_p), nq, k,
+                                                idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
+        return idx, sc
 
 
 def normalize_rows(rows, device=0):

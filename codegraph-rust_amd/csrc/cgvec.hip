@@ -29,6 +29,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cgvec.h"
@@ -94,6 +95,30 @@ constexpr int BM = 256, BN = 256;  // coarse tile (corpus rows x queries)
 
 uint32_t esize_of(int dtype) { return dtype == CGV_DTYPE_F32 ? 4u : (dtype == CGV_DTYPE_FP8E4M3 ? 1u : 2u); }
 
+// Bound on |coarse score - exact (reference-arithmetic) score| in units of |q||c| (cosine: absolute),
+// u = 2^-24. DESIGN.md §5.3 derives it; the three terms are
+//  (1) the MFMA accumulation, under the ALIGNED-ADDEND TRUNCATION MODEL of the matrix pipe: one
+//      instruction returns C + sum of its K exact products with an absolute error of at most
+//      (K + 1) * 2^-23 * max(|C|, |result|, max |product|) - every one of the K + 1 addends may lose up
+//      to one unit in the last place of the largest one (truncation, not rounding). ld/K instructions
+//      deep and every partial sum <= sum |x_i y_i| <= |q||c|:  (ld/K) * (K+1) * 2u;
+//  (2) the coarse scaling by the two inverse norms (each 1/sqrt of an ld/64-deep fma chain + a 6-level
+//      tree: relative error <= (ld/128 + 5)u) and two multiplications:  (ld/64 + 12)u;
+//  (3) the reference arithmetic itself against the real-number value: AVX2 order = ld/8-deep fma chain
+//      per lane + 3-level tree for the dot product and for both squared norms, sqrt, divide:
+//      (ld/4 + 10)u; the sequential formula (CGV_METRIC_COSINE_SEQ, search.rs:519-533): (2 ld + 4)u.
+// The model (1) is an assumption about undocumented hardware; tests/test_gpu_guarantee.py measures it
+// with adversarial same-sign / alternating-sign / one-huge-many-tiny inputs, and rescore_body's
+// trip-wire sends any query with an observed candidate error above eps/2 to the exact scan.
+float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, int metric) {
+    const double u = 5.9604644775390625e-8;
+    const double n_inst = (double)((ld_coarse + k_inst - 1) / k_inst);
+    const double mfma = n_inst * (double)(k_inst + 1) * 2.0;
+    const double scale = (double)ld_coarse / 64.0 + 12.0;
+    const double ref = metric == CGV_METRIC_COSINE_SEQ ? 2.0 * ld_exact + 4.0 : (double)ld_exact / 4.0 + 10.0;
+    return (float)((mfma + scale + ref) * u * 1.0001);
+}
+
 uint32_t kprime_of(uint32_t k) {
     uint32_t m = std::max<uint32_t>(6u, k / 8u);
     return ((k + m + 7u) / 8u) * 8u;
@@ -113,12 +138,14 @@ struct SearchCtx {
     uint32_t* h_flags = nullptr;  // pinned host mirror
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
         keysA, keysB, outidx, outscore, dump, qshadow, qres;
-    bool busy = false;
+    bool busy = false, split = false;
+    std::thread::id owner;
     // state of the search in flight (between begin and end)
     uint32_t gen = 0, nq = 0, k = 0;
     uint64_t* out_idx = nullptr;
     float* out_score = nullptr;
     bool mfma = false, timed_coarse = false;
+    bool rewrote = false;  // search_finish ran the exact scan and rewrote (some of) the outputs after its first sync
     uint64_t coarse_rows = 0;
     float eps = 0.0f;
     uint32_t kprime = 0;
@@ -145,7 +172,8 @@ struct cgv_index {
     uint32_t D = 0, ld = 0;
     int metric = 0, dtype = 0;
     uint32_t esize = 2;
-    uint64_t n = 0, cap = 0, index_base = 0;
+    uint64_t n = 0, cap = 0;
+    IdMap idmap = {0, 0, 1, 0, 0};  // local row -> reported id (cgv_set_index_base / cgv_set_id_map)
     char* rows = nullptr;
     float* norm = nullptr;
     float* invn = nullptr;
@@ -163,7 +191,6 @@ struct cgv_index {
     uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
     hipStream_t own_stream = nullptr, stream = nullptr;  // ingest / caller-ordering stream
     int n_cu = 256;
-    bool corpus_nonfinite = false;
     float max_norm_c = 0.0f;
     DevBuf addstage;
     SearchCtx ctx[N_CTX];
@@ -299,22 +326,54 @@ int ingest_enqueue(cgv_index* h, const float* rows_dev, uint64_t cnt, uint64_t r
     return CGV_OK;
 }
 
+// State an add must be able to return to when a later chunk of it fails (NaN/Inf rows, OOM):
+// the caller sees a failed add, so no row of it may stay in the index.
+struct IngestSnapshot {
+    uint64_t n;
+    float max_norm, res_rel, res_abs;
+};
+IngestSnapshot snapshot_of(const cgv_index* h) { return {h->n, h->max_norm_c, h->res_rel_c, h->res_abs_c}; }
+
+// Drop every row >= snap.n and restore the corpus-wide statistics the dropped rows were folded into.
+// The storage beyond snap.n is dead capacity (overwritten by the next add).
+int ingest_rollback(cgv_index* h, const IngestSnapshot& snap) {
+    hipStream_t s = h->stream;
+    (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    h->n = snap.n;
+    h->max_norm_c = snap.max_norm;
+    h->res_rel_c = snap.res_rel;
+    h->res_abs_c = snap.res_abs;
+    HIPCHK(hipMemsetAsync(h->flags, 0, F_COUNT * 4, s));
+    HIPCHK(hipMemcpyAsync(h->max_norm_dev, &h->max_norm_c, 4, hipMemcpyHostToDevice, s));
+    if (h->shadow) {
+        const float r2[2] = {snap.res_rel, snap.res_abs};
+        HIPCHK(hipMemcpyAsync(h->resmax_dev, r2, 8, hipMemcpyHostToDevice, s));
+    }
+    if (h->rows && (snap.n & 31u)) {  // the partially filled 32-row block at the boundary: bounds over the surviving rows
+        const uint64_t b0 = snap.n / 32;
+        hipLaunchKernelGGL(block_norm_stats_kernel, dim3(1), dim3(256), 0, s, h->norm, snap.n, b0, b0 + 1, h->blk_min,
+                           h->blk_max);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return CGV_OK;
+}
+
 int ingest_finish(cgv_index* h, uint64_t n_new) {
     hipStream_t s = h->stream;
     HIPCHK(hipMemcpyAsync(h->h_flags, h->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
     if (h->shadow) HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT + 1, h->resmax_dev, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (h->h_flags[F_NONFINITE_C])  // nothing is published; the caller rolls back to its snapshot
+        return fail(CGV_ERR_NONFINITE,
+                    "corpus rows contain NaN/Inf (the reference panics on NaN at simd_ops.rs:379); the add was not applied");
     h->n = n_new;
     memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
     if (h->shadow) {
         memcpy(&h->res_rel_c, h->h_flags + F_COUNT + 1, 4);
         memcpy(&h->res_abs_c, h->h_flags + F_COUNT + 2, 4);
-    }
-    if (h->h_flags[F_NONFINITE_C]) {
-        h->corpus_nonfinite = true;
-        return fail(CGV_ERR_NONFINITE,
-                    "corpus rows contain NaN/Inf (the reference panics on NaN at simd_ops.rs:379)");
     }
     return CGV_OK;
 }
@@ -327,21 +386,68 @@ int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt) {
     return ingest_finish(h, h->n + cnt);
 }
 
+// Run `body` (one or more add_dev_locked / ingest calls) atomically: on failure the index is exactly
+// what it was before (row count, statistics, sticky flags).
+template <class F>
+int atomic_ingest(cgv_index* h, F body) {
+    const IngestSnapshot snap = snapshot_of(h);
+    const int rc = body();
+    if (rc != CGV_OK) {
+        const std::string msg = g_err;  // keep the first error's message
+        (void)ingest_rollback(h, snap);
+        return fail(rc, msg);
+    }
+    return CGV_OK;
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ in, uint64_t total, float* __restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = (float)in[i];  // `as f32`: round to nearest even
 }
 
+// 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
+constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it for every
+// kernel that needs more than 64 KiB of dynamic LDS once per device (cgv_create calls this with the
+// device current), so that several devices in one process (cgv_sharded_*) and concurrent first
+// searches all find it in place.
+std::mutex g_attr_mu;
+std::vector<char> g_attr_done;
+
+int ensure_kernel_attrs(int device) {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if ((size_t)device < g_attr_done.size() && g_attr_done[device]) return CGV_OK;
+#define CGV_ATTR(K, BYTES) HIPCHK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+    CGV_ATTR((coarse_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_kernel<DT_BF16, true>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_kernel<DT_FP16, true>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_kernel<DT_FP8, false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_kernel<DT_FP8, true>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
+    CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
+    const int cap = 96 * 1024;
+    CGV_ATTR(rescore_kernel<DT_BF16>, cap);
+    CGV_ATTR(rescore_kernel<DT_FP16>, cap);
+    CGV_ATTR(rescore_kernel<DT_FP8>, cap);
+    CGV_ATTR(rescore_kernel<DT_F32>, cap);
+    CGV_ATTR(final_kernel<DT_BF16>, cap);
+    CGV_ATTR(final_kernel<DT_FP16>, cap);
+    CGV_ATTR(final_kernel<DT_FP8>, cap);
+    CGV_ATTR(final_kernel<DT_F32>, cap);
+#undef CGV_ATTR
+    if (g_attr_done.size() <= (size_t)device) g_attr_done.resize((size_t)device + 1, 0);
+    g_attr_done[device] = 1;
+    return CGV_OK;
+}
+
 template <int DT, bool DUMP>
 int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
-    constexpr size_t lds = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
-    static bool attr_set = false;
+    constexpr size_t lds = COARSE_LDS_BYTES;  // attribute set per device by ensure_kernel_attrs()
     auto kern = coarse_kernel<DT, DUMP>;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     // timing-only ablations of the bf16 kernel (scripts/gpu_ablate.sh; results are wrong when set)
     static const int abl = getenv("CGV_ABLATE") ? atoi(getenv("CGV_ABLATE")) : 0;
     if (abl && DT == DT_BF16 && !DUMP) {
@@ -367,13 +473,8 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
 
 template <bool DUMP>
 int launch_coarse_fp8s(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
-    static bool attr_set = false;
+    constexpr size_t lds = COARSE_LDS_BYTES;
     auto kern = coarse_fp8s_kernel<DUMP>;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
     HIPCHK(hipGetLastError());
     return CGV_OK;
@@ -431,12 +532,6 @@ int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
                   const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0) {
     size_t lds = 0;
     const SelectArgs sa = make_select_args(c, nq, nqt, nsplit, kprime, dense, n_dense, expected, &lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(SELECT_LDS_KEYS * 8 + 65536)));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), lds, s, sa);
     HIPCHK(hipGetLastError());
     return CGV_OK;
@@ -452,7 +547,8 @@ void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint
 
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
 int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
-                 float* out_score, hipStream_t s, int op = -1) {
+                 float* out_score, hipStream_t s, int op = -1, bool local_ids = false) {
+    const IdMap idmap = local_ids ? IdMap{0, 0, 1, 0, 0} : h->idmap;
     if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : (h->metric == CGV_METRIC_COSINE_SEQ ? OP_COSINE_SEQ : OP_COSINE);
     const uint64_t n = h->n;
     const uint32_t K = next_pow2(std::max<uint32_t>(k, 2));
@@ -489,7 +585,7 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
             nch = nch2;
         }
         hipLaunchKernelGGL(emit_topk_kernel, dim3((g * k + 255) / 256), dim3(256), 0, s, (const uint64_t*)cur,
-                           K, k, ql, g, h->index_base, out_idx, out_score);
+                           K, k, ql, g, idmap, out_idx, out_score);
         HIPCHK(hipGetLastError());
     }
     return CGV_OK;
@@ -604,8 +700,6 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
         return CGV_OK;
     }
-    if (h->corpus_nonfinite)
-        return fail(CGV_ERR_NONFINITE, "index holds NaN/Inf rows (the reference panics at simd_ops.rs:379)");
 
     if (h->profiling) HIPCHK(hipEventRecord(c->ev[0], s));
     // --- queries: round to storage dtype, norms ---
@@ -723,7 +817,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.fb_flag = c->fbflag.as<uint32_t>();
         r.fb_count = c->flags + F_FB_COUNT;
         r.stat_maxerr = c->flags + F_MAXERR;
-        r.index_base = h->index_base;
+        r.idmap = h->idmap;
         r.nq = nq;
         r.n = (uint32_t)h->n;
         r.D = h->D;
@@ -731,19 +825,14 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.kprime = kprime;
         r.k = k;
         r.metric = h->metric;
-        // |coarse - exact| <= (accumulation depth of both sums + norm terms) * u * |q||c|: the MFMA
-        // path adds D/16 partial sums, the reference D/8 per lane + a 3-level tree
-        // (the sequential formula of CGV_METRIC_COSINE_SEQ sums D deep in one chain)
-        r.eps_scale = ((float)h->D * (h->metric == CGV_METRIC_COSINE_SEQ ? 1.0f : 0.5f) + 64.0f) * 5.9604645e-8f;
+        // K = 16 for every dtype: the boot stage scores its rows with v_mfma_f32_32x32x16_* (fp8 included),
+        // and (ld/16)*17 >= (ld/64)*65 covers the K = 64 block-scaled instruction of the fp8 main kernel
+        r.eps_scale = coarse_eps_scale(h->shadow ? h->lds : h->ld, h->ld, 16u, h->metric);
         r.max_norm_c = h->max_norm_c;
         r.qres = h->shadow ? c->qres.as<float>() : nullptr;
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
-        if (h->shadow) r.eps_scale *= 2.0f;  // two accumulation-order terms: MFMA-on-shadow and the reference on f32
-        // fp8: the matrix pipe's internal accumulation of 8-bit products is coarser than one f32 rounding per
-        // term (largest observed error 2.0e-5 at D = 768, i.e. 0.75 of the f32-depth bound): 4x head room
-        if (h->dtype == CGV_DTYPE_FP8E4M3) r.eps_scale *= 4.0f;
         c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
@@ -753,19 +842,6 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
             size_t lds = rowb + (size_t)rpb * pitch;
-            static bool attr_set = false;
-            if (!attr_set) {
-                const int cap = 96 * 1024;
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)rescore_kernel<DT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_FP16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                HIPCHK(hipFuncSetAttribute((const void*)final_kernel<DT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                attr_set = true;
-            }
             if (fused_final) {
                 size_t sel_lds = 0;
                 const SelectArgs sa = make_select_args(c, nq, nqt, last_nsplit, kprime, nullptr, 0, last_expected, &sel_lds);
@@ -803,11 +879,13 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     const uint32_t nq = c->nq, k = c->k;
     int rc;
     HIPCHK(hipStreamSynchronize(s));
+    c->rewrote = false;
     if (c->h_flags[F_NONFINITE_Q])
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
     uint32_t nfb = 0;
     float me = 0.0f;
     if (!c->mfma) {
+        c->rewrote = true;
         hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
         if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, c->out_idx, c->out_score, s))) return rc;
         if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
@@ -817,6 +895,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         if (h->shadow) memcpy(&c->eps, &c->h_flags[F_MAXEPS], 4);  // largest per-query bound of this batch
         nfb = c->h_flags[F_FB_COUNT];
         if (nfb > 0) {
+            c->rewrote = true;
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
                                c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
             if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nfb, k, c->out_idx, c->out_score, s))) return rc;
@@ -843,19 +922,35 @@ int search_finish(cgv_index* h, SearchCtx* c) {
 }
 
 // ---- context pool ---------------------------------------------------------------
-// A search holds one context from acquire to release; writers (add / update / reserve /
-// set_stream) wait until every context is free and keep h->mu while they work.
-SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk) {
+// A search holds one context from acquire to release; writers (add / update / reserve / load /
+// set_id_map) wait until every context is free and keep h->mu while they work. cgv_set_stream does
+// not wait: it only changes where later calls record their ordering event.
+// split = taken by cgv_search_begin_f32_dev (released by a later cgv_search_end): if every context
+// is held that way by the CALLING thread, waiting would wait for this thread itself -> nullptr
+// (the caller reports CGV_ERR_BUSY) instead of a deadlock.
+SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk, bool split = false) {
     SearchCtx* got = nullptr;
+    const std::thread::id me = std::this_thread::get_id();
+    bool self_deadlock = false;
     h->cv.wait(lk, [&] {
-        for (SearchCtx& c : h->ctx)
+        int mine = 0;
+        for (SearchCtx& c : h->ctx) {
             if (!c.busy) {
                 got = &c;
                 return true;
             }
+            if (c.split && c.owner == me) ++mine;
+        }
+        if (mine == N_CTX) {
+            self_deadlock = true;
+            return true;
+        }
         return false;
     });
+    if (self_deadlock) return nullptr;
     got->busy = true;
+    got->split = split;
+    got->owner = me;
     got->gen++;
     return got;
 }
@@ -919,6 +1014,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
     if (device_id < 0 || device_id >= ndev) return fail(CGV_ERR_INVALID_ARG, "device_id out of range");
     HIPCHK(hipSetDevice(device_id));
+    if (int arc = ensure_kernel_attrs(device_id)) return arc;
     cgv_index* h = new cgv_index();
     h->device = device_id;
     h->D = dim;
@@ -1005,7 +1101,7 @@ int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n) {
     std::unique_lock<std::mutex> lk(h->mu);
     wait_all_idle(h, lk);
     HIPCHK(hipSetDevice(h->device));
-    return add_dev_locked(h, rows_dev, n);
+    return atomic_ingest(h, [&] { return add_dev_locked(h, rows_dev, n); });
 }
 
 int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
@@ -1016,15 +1112,18 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + n);
     if (rc) return rc;
-    const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)h->D * 4));
-    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
-        const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
-        if ((rc = h->addstage.ensure((size_t)c * h->D * 4))) return rc;
-        HIPCHK(hipMemcpyAsync(h->addstage.p, rows_host + r0 * h->D, (size_t)c * h->D * 4, hipMemcpyHostToDevice,
-                              h->stream));
-        if ((rc = add_dev_locked(h, h->addstage.as<float>(), c))) return rc;
-    }
-    return CGV_OK;
+    return atomic_ingest(h, [&]() -> int {
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)h->D * 4));
+        for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
+            int r;
+            if ((r = h->addstage.ensure((size_t)c * h->D * 4))) return r;
+            HIPCHK(hipMemcpyAsync(h->addstage.p, rows_host + r0 * h->D, (size_t)c * h->D * 4, hipMemcpyHostToDevice,
+                                  h->stream));
+            if ((r = add_dev_locked(h, h->addstage.as<float>(), c))) return r;
+        }
+        return CGV_OK;
+    });
 }
 
 int cgv_add_f64(cgv_index* h, const double* rows_host, uint64_t n) {
@@ -1035,21 +1134,24 @@ int cgv_add_f64(cgv_index* h, const double* rows_host, uint64_t n) {
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + n);
     if (rc) return rc;
-    const uint64_t chunk_rows = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)h->D * 8));
-    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
-        const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
-        const uint64_t total = c * h->D;
-        // staging: [c*D doubles][c*D floats]
-        if ((rc = h->addstage.ensure((size_t)total * 12))) return rc;
-        double* d64 = h->addstage.as<double>();
-        float* d32 = (float*)(h->addstage.as<char>() + (size_t)total * 8);
-        HIPCHK(hipMemcpyAsync(d64, rows_host + r0 * h->D, (size_t)total * 8, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)std::min<uint64_t>(4096, (total + 255) / 256)), dim3(256), 0,
-                           h->stream, (const double*)d64, total, d32);
-        HIPCHK(hipGetLastError());
-        if ((rc = add_dev_locked(h, d32, c))) return rc;
-    }
-    return CGV_OK;
+    return atomic_ingest(h, [&]() -> int {
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)h->D * 8));
+        for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            const uint64_t c = std::min<uint64_t>(chunk_rows, n - r0);
+            const uint64_t total = c * h->D;
+            int r;
+            // staging: [c*D doubles][c*D floats]
+            if ((r = h->addstage.ensure((size_t)total * 12))) return r;
+            double* d64 = h->addstage.as<double>();
+            float* d32 = (float*)(h->addstage.as<char>() + (size_t)total * 8);
+            HIPCHK(hipMemcpyAsync(d64, rows_host + r0 * h->D, (size_t)total * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)std::min<uint64_t>(4096, (total + 255) / 256)), dim3(256),
+                               0, h->stream, (const double*)d64, total, d32);
+            HIPCHK(hipGetLastError());
+            if ((r = add_dev_locked(h, d32, c))) return r;
+        }
+        return CGV_OK;
+    });
 }
 
 // ---- corpus files in the reference's mmap format (memory.rs:242-374) -------------------------
@@ -1122,6 +1224,7 @@ int cgv_load_mmap(cgv_index* h, const char* path, uint64_t* out_rows) {
         return fail(CGV_ERR_OOM, std::string("cgv_load_mmap staging: ") + hipGetErrorString(e));
     }
     const uint64_t base = h->n;
+    const IngestSnapshot snap = snapshot_of(h);
     uint64_t ci = 0;
     for (uint64_t r0 = 0; r0 < count && rc == CGV_OK; r0 += chunk_rows, ++ci) {
         const int b = (int)(ci & 1);
@@ -1136,10 +1239,12 @@ int cgv_load_mmap(cgv_index* h, const char* path, uint64_t* out_rows) {
         rc = ingest_enqueue(h, dev[b], c, base + r0);
         if (rc == CGV_OK && hipEventRecord(done[b], h->stream) != hipSuccess) rc = fail(CGV_ERR_HIP, "cgv_load_mmap: event");
     }
-    if (rc == CGV_OK)
-        rc = ingest_finish(h, base + count);
-    else
-        (void)hipStreamSynchronize(h->stream);
+    if (rc == CGV_OK) rc = ingest_finish(h, base + count);
+    if (rc != CGV_OK) {  // the file is applied whole or not at all
+        const std::string msg = g_err;
+        (void)ingest_rollback(h, snap);
+        (void)fail(rc, msg);
+    }
     cleanup();
     if (rc == CGV_OK && out_rows) *out_rows = count;
     return rc;
@@ -1206,6 +1311,9 @@ int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     std::unique_lock<std::mutex> lk(h->mu);
     wait_all_idle(h, lk);
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
+    for (uint32_t i = 0; i < h->D; ++i)  // checked BEFORE the stored row is overwritten: a rejected update changes nothing
+        if (!(fabsf(row_host[i]) <= 3.402823466e38f))
+            return fail(CGV_ERR_NONFINITE, "row contains NaN/Inf (the reference panics on NaN at simd_ops.rs:379); not applied");
     HIPCHK(hipSetDevice(h->device));
     int rc;
     if ((rc = h->addstage.ensure((size_t)h->D * 4))) return rc;
@@ -1221,7 +1329,19 @@ uint32_t cgv_dim(const cgv_index* h) { return h ? h->D : 0; }
 
 int cgv_set_index_base(cgv_index* h, uint64_t base) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    h->index_base = base;
+    h->idmap.base = base;
+    return CGV_OK;
+}
+
+int cgv_set_id_map(cgv_index* h, uint32_t chunk_rows, uint32_t n_shards, uint32_t shard) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (n_shards == 0 || shard >= n_shards || (n_shards > 1 && chunk_rows == 0))
+        return fail(CGV_ERR_INVALID_ARG, "cgv_set_id_map: need chunk_rows > 0 and shard < n_shards");
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    h->idmap.chunk = n_shards > 1 ? chunk_rows : 0;
+    h->idmap.nshards = n_shards;
+    h->idmap.shard = shard;
     return CGV_OK;
 }
 
@@ -1242,7 +1362,10 @@ int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq
     if (rc) return rc;
     std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
-    SearchCtx* c = acquire_ctx(h, lk);
+    SearchCtx* c = acquire_ctx(h, lk, /*split=*/true);
+    if (!c)
+        return fail(CGV_ERR_BUSY, "this thread already holds all " + std::to_string(N_CTX) +
+                                      " search contexts of the handle: call cgv_search_end on one of its tickets first");
     if ((rc = order_after_caller(h, c)) == CGV_OK)
         rc = search_enqueue(h, c, queries_dev, nq, k, out_idx_dev, out_score_dev);
     if (rc) {
@@ -1292,6 +1415,7 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     SearchCtx* c = acquire_ctx(h, lk);
+    if (!c) return fail(CGV_ERR_BUSY, "this thread holds every search context of the handle (cgv_search_begin without cgv_search_end)");
     hipStream_t s = c->stream;
     auto body = [&]() -> int {
         int r;
@@ -1303,10 +1427,21 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         if ((r = search_enqueue(h, c, c->qstage.as<float>(), nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>())))
             return r;
         lk.unlock();
+        // MFMA path: the results exist once the enqueued pipeline has run, so their D2H copies ride the same
+        // stream and ONE host synchronisation (inside search_finish) covers flags and results; only when the
+        // exact scan then rewrote some queries (fallbacks, f32 index) are they copied again.
+        const bool early = c->mfma;
+        auto copy_out = [&]() -> int {
+            HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(out_score_host, c->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+            return CGV_OK;
+        };
+        if (early && (r = copy_out())) return r;
         if ((r = search_finish(h, c))) return r;
-        HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(out_score_host, c->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (!early || c->rewrote) {
+            if ((r = copy_out())) return r;
+            HIPCHK(hipStreamSynchronize(s));
+        }
         return CGV_OK;
     };
     rc = body();
@@ -1387,6 +1522,64 @@ int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint
     return CGV_OK;
 }
 
+int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host, uint32_t m,
+                      float* out_host) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || m == 0) return CGV_OK;
+    if (!queries_host || !ids_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
+    if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
+        return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
+    std::unique_lock<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    SearchCtx* c = acquire_ctx(h, lk);
+    if (!c) return fail(CGV_ERR_BUSY, "this thread holds every search context of the handle");
+    hipStream_t s = c->stream;
+    const uint64_t n = h->n;
+    auto body = [&]() -> int {
+        int r;
+        const size_t qb = (size_t)nq * h->D * 4, ib = (size_t)nq * m * 8, ob = (size_t)nq * m * 4;
+        if ((r = c->qstage.ensure(qb))) return r;
+        if ((r = c->outidx.ensure(ib))) return r;
+        if ((r = c->outscore.ensure(ob))) return r;
+        if ((r = order_after_caller(h, c))) return r;
+        lk.unlock();
+        HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, qb, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->outidx.p, ids_host, ib, hipMemcpyHostToDevice, s));
+        const uint64_t pairs = (uint64_t)nq * m;
+        const dim3 grid((unsigned)((pairs + 31) / 32)), blk(256);
+        const float* qd = c->qstage.as<float>();
+        const uint64_t* idd = c->outidx.as<uint64_t>();
+        float* od = c->outscore.as<float>();
+        switch (h->dtype) {
+            case CGV_DTYPE_F32: hipLaunchKernelGGL(score_ids_kernel<DT_F32>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
+            case CGV_DTYPE_BF16: hipLaunchKernelGGL(score_ids_kernel<DT_BF16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
+            case CGV_DTYPE_FP16: hipLaunchKernelGGL(score_ids_kernel<DT_FP16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
+            default: hipLaunchKernelGGL(score_ids_kernel<DT_FP8>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_host, od, ob, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return CGV_OK;
+    };
+    const int rc = body();
+    if (lk.owns_lock()) lk.unlock();
+    if (rc) (void)hipStreamSynchronize(s);
+    release_ctx(h, c);
+    return rc;
+}
+
+int cgv_truncate(cgv_index* h, uint64_t n_rows) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    std::unique_lock<std::mutex> lk(h->mu);
+    wait_all_idle(h, lk);
+    if (n_rows >= h->n) return CGV_OK;
+    HIPCHK(hipSetDevice(h->device));
+    // the corpus-wide maxima (largest norm, shadow residuals) stay as they are: over-estimates only widen the
+    // error bound of the exactness check, they never invalidate it
+    return ingest_rollback(h, IngestSnapshot{n_rows, h->max_norm_c, h->res_rel_c, h->res_abs_c});
+}
+
 int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limit, uint64_t* out_idx_host,
                             float* out_dist_host, uint32_t* out_n) {
     if (!h || !query_host || !out_idx_host || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
@@ -1405,7 +1598,7 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
     if ((rc = c->outscore.ensure((size_t)limit * 4))) return rc;
     // ascending distance, stable (ties keep index order) == descending (-distance, index asc)
     if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), 1, limit, c->outidx.as<uint64_t>(), c->outscore.as<float>(), s,
-                           OP_NEG_COSINE_DISTANCE_SEQ)))
+                           OP_NEG_COSINE_DISTANCE_SEQ, /*local_ids=*/true)))
         return rc;
     std::vector<float> sc(limit);
     HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)limit * 8, hipMemcpyDeviceToHost, s));
@@ -1414,7 +1607,6 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
     uint32_t m = 0;
     while (m < limit && out_idx_host[m] != UINT64_MAX) ++m;
     for (uint32_t i = 0; i < m; ++i) {
-        out_idx_host[i] -= h->index_base;
         if (out_dist_host) out_dist_host[i] = -sc[i];
     }
     *out_n = m;
@@ -1485,6 +1677,9 @@ int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uin
 
 int cgv_set_stream(cgv_index* h, void* stream) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    // No wait for searches in flight: they already recorded their ordering event on the old stream;
+    // the new value only decides where LATER calls order themselves (a pipelining caller re-points
+    // the stream between cgv_search_begin calls).
     std::lock_guard<std::mutex> lk(h->mu);
     h->stream = (hipStream_t)stream;  // NULL == HIP's legacy default stream
     return CGV_OK;

@@ -27,6 +27,19 @@ __host__ __device__ inline uint64_t make_key(float s, uint32_t row) {
 __host__ __device__ inline float key_score(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
 __host__ __device__ inline uint32_t key_row(uint64_t k) { return ~(uint32_t)k; }
 
+// ---- local row -> reported id ----------------------------------------------------
+// One device index reports id = base + local row. Under a block-cyclic sharded handle
+// (cgv_sharded_*, sharded.hip) global rows are dealt to the shards in chunks of `chunk` rows:
+// global row r lives on shard (r / chunk) % nshards at local row (r / chunk / nshards) * chunk + r % chunk.
+struct IdMap {
+    uint64_t base;
+    uint32_t chunk, nshards, shard, pad_;
+};
+__host__ __device__ inline uint64_t map_id(const IdMap& m, uint32_t local) {
+    if (m.nshards <= 1u) return m.base + local;
+    return m.base + ((uint64_t)(local / m.chunk) * m.nshards + m.shard) * m.chunk + (local % m.chunk);
+}
+
 // ---- storage dtype conversion (round-to-nearest-even) ---------------------------
 __host__ __device__ inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;

@@ -30,6 +30,30 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
     }
 }
 
+// out[q][j] = op(query q, stored row ids[q][j]) for nq x m (query, row) pairs: the per-hit re-score of
+// SemanticSearch::search_by_embedding (search.rs:119-129: get_embedding + cosine_similarity per hit) as
+// ONE launch over the ids the kNN returned, instead of m host round trips per query. The query is the
+// caller's RAW f32 vector (the reference scores the unrounded query against the stored embedding);
+// the row is the stored value upcast to f32 (what get_embedding returns). ids[q][j] == UINT64_MAX or
+// beyond the index -> 0.0 (a missing embedding scores 0.0, search.rs:207-217). 8 lanes per pair.
+template <int DT>
+__global__ __launch_bounds__(256) void score_ids_kernel(const char* __restrict__ rows, const float* __restrict__ queries,
+                                                        const uint64_t* __restrict__ ids, uint32_t nq, uint32_t m,
+                                                        uint64_t n, uint32_t D, uint32_t ld, int op,
+                                                        float* __restrict__ out) {
+    const int l = threadIdx.x & 7;
+    const uint64_t pair = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (pair >= (uint64_t)nq * m) return;
+    const uint32_t q = (uint32_t)(pair / m);
+    const uint64_t id = ids[pair];
+    float s = 0.0f;
+    if (id < n) {  // uniform within the 8-lane group
+        const Row<DT_F32> qr{(const char*)(queries + (uint64_t)q * D), 0u};
+        s = exact_op_group8(op, qr, make_row<DT>(rows, id, ld), D, l);
+    }
+    if (l == 0) out[pair] = s;
+}
+
 constexpr uint32_t TOPK_CHUNK = 4096;
 
 // Level-0: chunk of f32 scores -> sorted top-K keys. Level>0: chunk of keys -> top-K keys.
@@ -65,7 +89,7 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
 // Final keys [nql][K] -> caller's out arrays at query slot qlist[qi] (or qi).
 __global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, uint32_t k,
                                  const uint32_t* __restrict__ qlist, uint32_t nql,
-                                 uint64_t index_base, uint64_t* __restrict__ out_idx,
+                                 IdMap idmap, uint64_t* __restrict__ out_idx,
                                  float* __restrict__ out_score) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nql * k) return;
@@ -75,7 +99,7 @@ __global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, 
     uint64_t oi = UINT64_MAX;
     float os = -INFINITY;
     if (key != 0ull) {
-        oi = index_base + key_row(key);
+        oi = map_id(idmap, key_row(key));
         os = key_score(key);
     }
     out_idx[(uint64_t)q * k + j] = oi;

@@ -281,10 +281,10 @@ struct RescoreArgs {
     uint32_t* fb_flag;      // [nq] 1 = needs exact full scan
     uint32_t* fb_count;     // [1]
     uint32_t* stat_maxerr;  // [1] f2ord(max |coarse-exact|)
-    uint64_t index_base;
+    IdMap idmap;
     uint32_t nq, n, D, ld, kprime, k, metric;
     uint32_t rows_per_batch;  // candidate rows staged in LDS per pass
-    float eps_scale;        // cosine: eps; dot: eps = eps_scale * |q| * max|c|
+    float eps_scale;        // cosine: eps; dot: eps = eps_scale * |q| * max|c|   (host: coarse_eps_scale())
     float max_norm_c;
     // f32 index with a bf16 shadow (coarse scores come from ROUNDED operands): rounding residuals
     const float* qres;      // [nq][2]: relative |dq|/min(|q|,|q^|) and absolute |dq| of each query; NULL otherwise
@@ -306,11 +306,27 @@ template <int DT>
 __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t nb, const uint64_t* ckeys /* LDS [nb] */,
                                     float tau, bool overflow, char* smem, int tid) {
     __shared__ uint64_t ekeys[CAND_CAPS];
-    __shared__ uint32_t maxerr;
+    __shared__ uint32_t maxerr, tripped;
     const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
     char* qs = smem;
     char* rs = smem + rowb;
-    if (tid == 0) maxerr = 0;
+    if (tid == 0) {
+        maxerr = 0;
+        tripped = 0;
+    }
+    // eps: bound on |coarse - exact| for THIS query, in score units
+    float eps = a.eps_scale;
+    if (a.metric == METRIC_DOT) eps = a.eps_scale * a.norm_q[q] * a.max_norm_c;
+    if (a.qres) {
+        // |cos(q^,c^) - cos(q,c)| <= |u^-u| + |v^-v| <= res_rel(q) + res_rel(c)   (unit vectors u, v);
+        // |q^.c^ - q.c| <= |dq||c^| + |q||dc|. 1 % head room for the f32 rounding of the residual sums.
+        const float rq_rel = a.qres[2 * q], rq_abs = a.qres[2 * q + 1];
+        if (a.metric == METRIC_DOT)
+            eps += 1.01f * (rq_abs * a.max_norm_c + (a.norm_q[q] + rq_abs) * a.res_abs_c);
+        else
+            eps += 1.01f * (rq_rel + a.res_rel_c);
+    }
+    const float trip = 0.5f * eps;
     const uint32_t P = next_pow2(nb < 2 ? 2 : nb);
     for (uint32_t i = nb + tid; i < P; i += 256) ekeys[i] = 0ull;
     {   // query row -> LDS (linear element order)
@@ -351,6 +367,10 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
                 ekeys[c0 + c] = make_key(ex, row);
                 const float err = fabsf(ex - coarse);
                 if (err == err) atomicMax(&maxerr, __float_as_uint(err));
+                // trip-wire: the bound is derived under an explicit model of the matrix pipe's internal
+                // accumulation; an observed error beyond HALF of it on any candidate means the model
+                // cannot be trusted for this query -> exact full scan (never a silent wrong answer)
+                if (!(err <= trip)) tripped = 1u;
             }
         }
     }
@@ -360,7 +380,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         uint64_t oi = UINT64_MAX;
         float os = -INFINITY;
         if (j < nb) {
-            oi = a.index_base + key_row(ekeys[j]);
+            oi = map_id(a.idmap, key_row(ekeys[j]));
             os = key_score(ekeys[j]);
         }
         a.out_idx[(uint64_t)q * a.k + j] = oi;
@@ -372,20 +392,10 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         if (tau > -INFINITY && nb > 0) {  // candidates were truncated: check the guarantee
             const uint32_t kk = a.k < nb ? a.k : nb;
             const float ek = key_score(ekeys[kk - 1]);
-            float eps = a.eps_scale;
-            if (a.metric == METRIC_DOT) eps = a.eps_scale * a.norm_q[q] * a.max_norm_c;
-            if (a.qres) {
-                // |cos(q^,c^) - cos(q,c)| <= |u^-u| + |v^-v| <= res_rel(q) + res_rel(c)   (unit vectors u, v);
-                // |q^.c^ - q.c| <= |dq||c^| + |q||dc|. 1 % head room for the f32 rounding of the residual sums.
-                const float rq_rel = a.qres[2 * q], rq_abs = a.qres[2 * q + 1];
-                if (a.metric == METRIC_DOT)
-                    eps += 1.01f * (rq_abs * a.max_norm_c + (a.norm_q[q] + rq_abs) * a.res_abs_c);
-                else
-                    eps += 1.01f * (rq_rel + a.res_rel_c);
-            }
             if (a.stat_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
             if (!(ek > tau + eps)) fb = true;
             if (nb < a.k) fb = true;
+            if (tripped) fb = true;
         }
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);

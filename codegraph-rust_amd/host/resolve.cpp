@@ -164,14 +164,14 @@ int cgvs_resolver_match(cgvs_resolver* r, uint32_t nq, const char* const* target
         bool ex = false;
         walk(&idx[(size_t)q * K1], &sc[(size_t)q * K1], K1, &ex);
         if (!ex) continue;
-        const uint32_t K2 = (uint32_t)std::min<uint64_t>(CGV_MAX_K, n);
+        const uint32_t K2 = (uint32_t)std::min<uint64_t>(256, n);
         idx2.resize(K2);
         sc2.resize(K2);
         if ((rc = cgv_search_f32(r->index, target_embeddings + (size_t)q * r->dim, 1, K2, idx2.data(), sc2.data())))
             return rc;
         walk(idx2.data(), sc2.data(), K2, &ex);
         if (!ex) continue;
-        // more than CGV_MAX_K ineligible symbols above the threshold: exact scores of every symbol
+        // more than 256 ineligible symbols above the threshold: exact scores of every symbol
         all.resize(n);
         if ((rc = cgv_batch_similarity_f32(r->index, target_embeddings + (size_t)q * r->dim, CGV_OP_COSINE_SEQ, 0,
                                            all.data())))

@@ -1,9 +1,9 @@
 // store.cpp — host-side mirror (C++) of the reference's vector-store surface over the HIP
 // kNN library. The reference is Rust; with no Rust toolchain in the build image the host
 // code above the C ABI is C++ (see include/cgvec_store.h for the file:line of every item
-// mirrored). Only the caller-side logic lives here (id mapping, prefetch rule, the per-hit
-// re-score of search.rs:119-137, min-max normalisation, filters, OR/AND merging); the kNN
-// itself always runs on the GPU through cgv_search_f32 — there is no CPU search path.
+// mirrored). Only the caller-side logic lives here (id mapping, prefetch rule, min-max
+// normalisation, filters, OR/AND merging); the kNN and the per-hit re-score of search.rs:119-137
+// run on the GPU (cgv_search_f32, cgv_score_ids_f32) — there is no CPU search path.
 // Compiled with -ffp-contract=off: the scalar formulas must round like the Rust code does.
 #include <math.h>
 #include <stdio.h>
@@ -201,6 +201,23 @@ struct SurrealVectorBackend {
         return CGV_OK;
     }
     virtual int get_node_embedding(const NodeId& id, std::vector<float>& out, bool& found) = 0;
+    // calculate_similarity_score (search.rs:207-217) for nq queries x their hit lists in one call:
+    // scores[q][j] = cosine_similarity(query q, embedding of ids[q][j]) (0.0 when the node has none).
+    // Default = the reference's own shape, one get_node_embedding per hit (what a remote backend does);
+    // the GPU backend overrides it with ONE device launch over all (query, hit) pairs.
+    virtual int score_nodes_batch(const float* queries, size_t nq, size_t dim, const std::vector<std::vector<NodeId>>& ids,
+                                  std::vector<std::vector<float>>& scores) {
+        scores.assign(nq, {});
+        for (size_t q = 0; q < nq; ++q)
+            for (const NodeId& id : ids[q]) {
+                std::vector<float> e;
+                bool found = false;
+                int rc = get_node_embedding(id, e, found);
+                if (rc) return rc;
+                scores[q].push_back(found ? cosine_similarity(queries + q * dim, dim, e.data(), e.size()) : 0.0f);
+            }
+        return CGV_OK;
+    }
 };
 
 // The GPU backend: one device index per embedding column.
@@ -233,16 +250,21 @@ class HipKnnBackend : public SurrealVectorBackend {
             flat.reserve(kv.second.size() * c.dim);
             std::vector<NodeId> ids;
             for (const Node* n : kv.second) {
-                if (c.row_of.count(n->id)) continue;  // duplicate id inside this batch: first wins, then update
+                auto dup = c.row_of.find(n->id);
+                if (dup != c.row_of.end()) {  // the id repeats inside this batch: UPSERT = last writer wins
+                    const size_t slot = (size_t)(dup->second - c.ids.size());
+                    std::copy(n->embedding, n->embedding + c.dim, flat.begin() + slot * c.dim);
+                    continue;
+                }
                 c.row_of[n->id] = c.ids.size() + ids.size();
                 ids.push_back(n->id);
                 flat.insert(flat.end(), n->embedding, n->embedding + c.dim);
             }
-            const uint64_t before = cgv_count(c.h);
+            // cgv_add_f32 is all-or-nothing (a rejected batch leaves the device index untouched), so on
+            // failure only this batch's id entries are dropped and rows / ids stay aligned
             int rc = cgv_add_f32(c.h, flat.data(), ids.size());
             if (rc) {
                 for (auto& id : ids) c.row_of.erase(id);
-                (void)before;
                 return rc;
             }
             c.ids.insert(c.ids.end(), ids.begin(), ids.end());
@@ -265,7 +287,13 @@ class HipKnnBackend : public SurrealVectorBackend {
         if (it == cols_.end() || limit == 0 || nq == 0) return CGV_OK;  // empty column: no neighbours
         Column& c = it->second;
         if (dim != c.dim) return fail(CGV_ERR_DIM_MISMATCH, "query dimension " + std::to_string(dim) + " != column " + column_name);
-        const size_t k = std::min<size_t>(limit, CGV_MAX_K);
+        // a search cannot return more neighbours than the column holds; beyond CGV_MAX_K the request is an
+        // error, never a silent truncation (k <= CGV_FAST_MAX_K: MFMA path; larger: exact scan on the device)
+        const size_t k = std::min<size_t>(limit, (size_t)cgv_count(c.h));
+        if (k == 0) return CGV_OK;
+        if (k > CGV_MAX_K)
+            return fail(CGV_ERR_INVALID_ARG, "vector_knn: limit " + std::to_string(limit) + " exceeds CGV_MAX_K (" +
+                                                 std::to_string(CGV_MAX_K) + ") neighbours per query");
         std::vector<uint64_t> idx(nq * k);
         std::vector<float> sc(nq * k);
         int rc = cgv_search_f32(c.h, queries, (uint32_t)nq, (uint32_t)k, idx.data(), sc.data());
@@ -278,6 +306,32 @@ class HipKnnBackend : public SurrealVectorBackend {
                 // (surrealdb_storage.rs:297-301 ORDER BY score ASC)
                 out[q].push_back({"nodes:" + format_uuid(c.ids[(size_t)r]), 1.0f - sc[q * k + j]});
             }
+        return CGV_OK;
+    }
+    // ONE device launch for every (query, hit) pair: the sequential cosine of search.rs:519-533 evaluated by
+    // cgv_score_ids_f32 (CGV_OP_COSINE_SEQ) on the stored rows - no get_node_embedding round trip per hit.
+    int score_nodes_batch(const float* queries, size_t nq, size_t dim, const std::vector<std::vector<NodeId>>& ids,
+                          std::vector<std::vector<float>>& scores) override {
+        scores.assign(nq, {});
+        size_t m = 0;
+        for (auto& l : ids) m = std::max(m, l.size());
+        if (nq == 0 || m == 0) return CGV_OK;
+        // an embedding of another dimension scores 0.0 (length mismatch, search.rs:520-522), as does a node without one
+        auto it = cols_.find(column_for_dimension(dim));
+        Column* c = (it != cols_.end() && it->second.dim == dim) ? &it->second : nullptr;
+        std::vector<uint64_t> rows(nq * m, UINT64_MAX);
+        if (c)
+            for (size_t q = 0; q < nq; ++q)
+                for (size_t j = 0; j < ids[q].size(); ++j) {
+                    auto r = c->row_of.find(ids[q][j]);
+                    if (r != c->row_of.end()) rows[q * m + j] = r->second;
+                }
+        std::vector<float> out(nq * m, 0.0f);
+        if (c) {
+            int rc = cgv_score_ids_f32(c->h, queries, (uint32_t)nq, CGV_OP_COSINE_SEQ, rows.data(), (uint32_t)m, out.data());
+            if (rc) return rc;
+        }
+        for (size_t q = 0; q < nq; ++q) scores[q].assign(out.begin() + q * m, out.begin() + q * m + ids[q].size());
         return CGV_OK;
     }
     int get_node_embedding(const NodeId& id, std::vector<float>& out, bool& found) override {
@@ -400,26 +454,19 @@ struct cgvs_store {
         }
         return CGV_OK;
     }
-    // search.rs:207-217 calculate_similarity_score
-    int similarity_score(const float* q, size_t dim, const NodeId& id, float& score) {
-        std::vector<float> e;
-        bool found = false;
-        int rc = backend->get_node_embedding(id, e, found);
-        if (rc) return rc;
-        score = found ? cosine_similarity(q, dim, e.data(), e.size()) : 0.0f;
-        return CGV_OK;
-    }
-    int rescore(const float* q, size_t dim, const std::vector<NodeId>& ids, size_t limit, std::vector<SearchResult>& out) {
+    // search.rs:119-137: score every hit, stable sort desc, truncate, min-max normalise
+    void finish_rescore(const std::vector<NodeId>& ids, const std::vector<float>& sc, size_t limit, std::vector<SearchResult>& out) {
         out.clear();
-        for (auto& id : ids) {
-            float s;
-            int rc = similarity_score(q, dim, id, s);
-            if (rc) return rc;
-            out.push_back({id, s});
-        }
+        for (size_t j = 0; j < ids.size(); ++j) out.push_back({ids[j], sc[j]});
         stable_sort_desc(out);
         if (out.size() > limit) out.resize(limit);
         normalize_scores(out);
+    }
+    int rescore(const float* q, size_t dim, const std::vector<NodeId>& ids, size_t limit, std::vector<SearchResult>& out) {
+        std::vector<std::vector<float>> sc;
+        int rc = backend->score_nodes_batch(q, 1, dim, {ids}, sc);
+        if (rc) return rc;
+        finish_rescore(ids, sc[0], limit, out);
         return CGV_OK;
     }
     // SemanticSearch::search_by_embedding, search.rs:91-144 (QueryHash cache not reproduced)
@@ -437,11 +484,12 @@ struct cgvs_store {
         std::vector<std::vector<std::pair<std::string, float>>> nb;
         int rc = backend->vector_knn_batch(column_for_dimension(dim), qs, nq, dim, (size_t)prefetch_k(limit), ef_search, nb);
         if (rc) return rc;
-        for (size_t i = 0; i < nq; ++i) {
-            std::vector<NodeId> ids;
-            if ((rc = ids_from(nb[i], ids))) return rc;
-            if ((rc = rescore(qs + i * dim, dim, ids, limit, out[i]))) return rc;
-        }
+        std::vector<std::vector<NodeId>> ids(nq);
+        for (size_t i = 0; i < nq; ++i)
+            if ((rc = ids_from(nb[i], ids[i]))) return rc;
+        std::vector<std::vector<float>> sc;
+        if ((rc = backend->score_nodes_batch(qs, nq, dim, ids, sc))) return rc;  // all hits of all queries: one call
+        for (size_t i = 0; i < nq; ++i) finish_rescore(ids[i], sc[i], limit, out[i]);
         return CGV_OK;
     }
     // search.rs:420-463 node_matches_filters

@@ -70,8 +70,13 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_ERR_OUT_OF_RANGE 6 /* VectorError::IndexOutOfBounds, error.rs:14-15 */
 #define CGV_ERR_INTERNAL 7
 #define CGV_ERR_IO 8           /* corpus file errors; messages follow memory.rs:242-374 */
+#define CGV_ERR_BUSY 9         /* the calling thread already holds every search context (begin without end) */
 
-#define CGV_MAX_K 256u
+/* Largest k of a search. k <= CGV_FAST_MAX_K runs the MFMA coarse pass + exact re-score; larger k (the
+ * over-fetch of SemanticSearch: prefetch_k(max(4*limit, limit+25)), search.rs:113,293) takes the exact
+ * full scan on the device - same results, HBM-bound instead of MFMA-bound. */
+#define CGV_MAX_K 2048u
+#define CGV_FAST_MAX_K 228u
 
 /* Library/ABI version (major<<16 | minor). */
 uint32_t cgv_version(void);
@@ -115,6 +120,16 @@ uint32_t cgv_dim(const cgv_index* h);
 /* Added to every row id this index reports (global id = index_base + local row);
  * used when the corpus is row-sharded across devices. */
 int cgv_set_index_base(cgv_index* h, uint64_t base);
+
+/* Block-cyclic id map (used by cgv_sharded_*): this index is shard `shard` of `n_shards`, global rows are
+ * dealt to the shards in chunks of `chunk_rows`; a local row r is reported as
+ * index_base + ((r / chunk_rows) * n_shards + shard) * chunk_rows + r % chunk_rows. n_shards == 1 = identity. */
+int cgv_set_id_map(cgv_index* h, uint32_t chunk_rows, uint32_t n_shards, uint32_t shard);
+
+/* Drop the rows >= n_rows (roll back the tail of the index; the capacity is kept). Used by callers that
+ * apply one logical insert to several indices (cgv_sharded_add_f32) and must undo it everywhere when one
+ * of them rejects its part (NaN/Inf rows, out of memory). */
+int cgv_truncate(cgv_index* h, uint64_t n_rows);
 
 /* Batched kNN: nq queries (flat f32 [nq][dim], HOST), top-k each.
  * out_idx / out_score: HOST arrays of nq*k entries, row-major per query.
@@ -183,6 +198,15 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host);
  * limit_rows = limit, GpuAcceleration::compute_distances / compute_distances_cpu
  * (gpu.rs:248-322: distances of the FIRST `limit` rows, not a top-k). */
 int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host);
+
+/* Scores of given (query, stored row) pairs in ONE device launch: out[q][j] = op(query q, row ids[q][j]) for
+ * nq queries (HOST f32 [nq][dim], used UNROUNDED as the reference does) and m LOCAL row ids per query
+ * (HOST u64 [nq][m]; UINT64_MAX or an id beyond the index scores 0.0, like a missing embedding in
+ * calculate_similarity_score, search.rs:207-217). Replaces the per-hit `get_embedding` + `cosine_similarity`
+ * loop of SemanticSearch::search_by_embedding (search.rs:119-129, op = CGV_OP_COSINE_SEQ) - prefetch_k host
+ * round trips per query become one call per batch. */
+int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host,
+                      uint32_t m, float* out_host);
 
 /* ModelOptimizer::search_baseline (optimization.rs:376-402): ascending cosine_distance, stable
  * (ties keep row order), take(limit). out_dist_host may be NULL. Row ids are local (no index_base). */
@@ -254,6 +278,54 @@ int cgv_set_force_exact(cgv_index* h, int enabled);
  * out_dev[nq][n] (f32, DEVICE). Used by tests to check the GEMM tile mapping. */
 int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t nq,
                                 float* out_dev);
+
+/* ---- one index over several devices (cgv_create(.., n_devices, device_ids*); §8(e)) ----
+ * The backend object the reference's seam injects (`Arc<dyn SurrealVectorBackend>`, surreal_store.rs:11-22,
+ * 32-34; `Box<dyn VectorStore + Send>`, graph_vector.rs:241-253) is ONE object, so it must own all shards:
+ * a cgv_sharded is one handle over n_devices device indices in one process, one worker thread per device.
+ *   rows    : global row id = insertion index, dealt to the shards block-cyclically in chunks of
+ *             CGV_SHARD_CHUNK_ROWS (incremental upserts keep the shards balanced; cgv_set_id_map);
+ *   search  : the query batch goes to every device, each shard runs the single-device pipeline, the
+ *             per-shard top-k travel as packed 12-byte records in ONE exchange - an RCCL all-gather over
+ *             xGMI when the devices are distinct (librccl is loaded on first use), peer / same-device
+ *             copies into the root's buffer otherwise (CGV_EXCHANGE_*; the same device may be listed more
+ *             than once, which is how a 1-GPU box exercises the whole path) - and the root merges
+ *             n_devices * k records per query with (score desc, id asc). Exact: the global top-k is a
+ *             subset of the union of the per-shard top-k.
+ * Thread-safety: calls on one cgv_sharded are serialised by the handle. */
+typedef struct cgv_sharded cgv_sharded;
+#define CGV_SHARD_CHUNK_ROWS 4096u
+#define CGV_EXCHANGE_NONE 0 /* one shard */
+#define CGV_EXCHANGE_RCCL 1 /* ncclAllGather of the packed records (RCCL over xGMI) */
+#define CGV_EXCHANGE_COPY 2 /* hipMemcpyPeerAsync / device-to-device copies into the root's gather buffer */
+
+int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, const int* device_ids,
+                       cgv_sharded** out);
+int cgv_sharded_destroy(cgv_sharded* s);
+/* Pre-size every shard for total_rows rows in all (optional). */
+int cgv_sharded_reserve(cgv_sharded* s, uint64_t total_rows);
+/* Append n rows (HOST f32 [n][dim]); applied to all shards or to none (NaN/Inf -> CGV_ERR_NONFINITE). */
+int cgv_sharded_add_f32(cgv_sharded* s, const float* rows_host, uint64_t n);
+int cgv_sharded_update_row_f32(cgv_sharded* s, uint64_t id, const float* row_host);
+int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host);
+uint64_t cgv_sharded_count(const cgv_sharded* s);
+uint32_t cgv_sharded_n_shards(const cgv_sharded* s);
+/* Borrowed handle of shard i (statistics, profiling switches); do not add to / destroy it. */
+cgv_index* cgv_sharded_shard(cgv_sharded* s, uint32_t i);
+/* cgv_search_f32 over all shards; out arrays HOST [nq][k], ids global. */
+int cgv_sharded_search_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k,
+                           uint64_t* out_idx_host, float* out_score_host);
+/* Which exchange the handle uses (CGV_EXCHANGE_*); cgv_sharded_set_exchange forces RCCL or COPY
+ * (RCCL needs distinct devices). */
+int cgv_sharded_exchange(const cgv_sharded* s);
+int cgv_sharded_set_exchange(cgv_sharded* s, int kind);
+typedef struct cgv_sharded_stats {
+    uint64_t n_rows, device_bytes, searches, queries, fallback_queries;
+    uint32_t n_shards, exchange;
+    float last_search_ms;   /* host wall time of the last cgv_sharded_search_f32 */
+    float last_exchange_ms; /* of which: pack + exchange + merge + result copy (after the slowest shard finished) */
+} cgv_sharded_stats;
+int cgv_sharded_get_stats(cgv_sharded* s, cgv_sharded_stats* out);
 
 #ifdef __cplusplus
 }

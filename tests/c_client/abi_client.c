@@ -1,6 +1,9 @@
 /* A plain-C client of include/cgvec.h: what a compiled host (the Rust shim of INTEGRATION.md, a C++
  * service, ...) does with the library. No Python, no torch: dlopen-free static linking against
- * libcgvec_hip.so. Usage: abi_client <in.bin> <out.bin> [dtype]
+ * libcgvec_hip.so. Usage: abi_client <in.bin> <out.bin> [dtype] [n_shards]
+ *   n_shards > 0: the same flow through ONE sharded handle (cgv_sharded_*) over n_shards shards placed
+ *   on devices i % device_count (a 1-GPU box lists device 0 several times), which must give the same
+ *   ids (global id = insertion index) and scores as the single index.
  *   in.bin : u32 n, u32 dim, u32 nq, u32 k, then n*dim f32 corpus rows, then nq*dim f32 queries
  *   out.bin: nq*k u64 ids, then nq*k f32 scores
  * Exit code 3 = no GPU (the library has no CPU fallback). */
@@ -32,6 +35,45 @@ int main(int argc, char** argv) {
     if (fread(rows, 4, (size_t)n * dim, f) != (size_t)n * dim) return 1;
     if (fread(q, 4, (size_t)nq * dim, f) != (size_t)nq * dim) return 1;
     fclose(f);
+
+    const int n_shards = argc > 4 ? atoi(argv[4]) : 0;
+    if (n_shards > 0) {
+        int devs[64];
+        const int ndev = cgv_device_count();
+        if (ndev == 0) {
+            fprintf(stderr, "no HIP device visible: libcgvec_hip has no CPU fallback\n");
+            return 3;
+        }
+        for (int i = 0; i < n_shards && i < 64; ++i) devs[i] = i % ndev;
+        cgv_sharded* sh = NULL;
+        int src = cgv_sharded_create(dim, CGV_METRIC_COSINE, dtype, (uint32_t)n_shards, devs, &sh);
+        if (src) return die("cgv_sharded_create", src);
+        /* three appends that do not line up with the 4096-row chunks of the block-cyclic placement */
+        const uint32_t a = n / 3, b = n / 2;
+        if ((src = cgv_sharded_add_f32(sh, rows, a))) return die("cgv_sharded_add_f32", src);
+        if ((src = cgv_sharded_add_f32(sh, rows + (size_t)a * dim, b - a))) return die("cgv_sharded_add_f32", src);
+        if ((src = cgv_sharded_add_f32(sh, rows + (size_t)b * dim, n - b))) return die("cgv_sharded_add_f32", src);
+        if (cgv_sharded_count(sh) != n || cgv_sharded_n_shards(sh) != (uint32_t)n_shards) return 2;
+        uint64_t* sidx = (uint64_t*)malloc((size_t)nq * k * 8);
+        float* ssc = (float*)malloc((size_t)nq * k * 4);
+        if ((src = cgv_sharded_search_f32(sh, q, nq, k, sidx, ssc))) return die("cgv_sharded_search_f32", src);
+        float* sback = (float*)malloc((size_t)dim * 4);
+        if (cgv_sharded_get_row_f32(sh, (uint64_t)n + 5, sback) != CGV_ERR_OUT_OF_RANGE) return 2;
+        if ((src = cgv_sharded_get_row_f32(sh, 1, sback))) return die("cgv_sharded_get_row_f32", src);
+        cgv_sharded_stats sst;
+        if ((src = cgv_sharded_get_stats(sh, &sst))) return die("cgv_sharded_get_stats", src);
+        printf("rows=%llu shards=%u exchange=%u fallback=%llu search_ms=%.3f exchange_ms=%.3f\n",
+               (unsigned long long)sst.n_rows, sst.n_shards, sst.exchange, (unsigned long long)sst.fallback_queries,
+               sst.last_search_ms, sst.last_exchange_ms);
+        f = fopen(argv[2], "wb");
+        if (!f) return 1;
+        fwrite(sidx, 8, (size_t)nq * k, f);
+        fwrite(ssc, 4, (size_t)nq * k, f);
+        fwrite(sback, 4, dim, f);
+        fclose(f);
+        cgv_sharded_destroy(sh);
+        return 0;
+    }
 
     cgv_index* h = NULL;
     int rc = cgv_create(dim, CGV_METRIC_COSINE, dtype, 0, &h);

@@ -61,3 +61,27 @@ def test_c_client_results_equal_oracle(tmp_path, oracle, dtype, odt):
     ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
     assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
     assert np.array_equal(back, oracle.round_trip(rows[1], odt))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_c_client_sharded_handle_equals_oracle(tmp_path, oracle, n_shards):
+    """ONE cgv_sharded handle over several shards (devices i % device_count: a 1-GPU box lists device 0 more than
+    once, a multi-GPU box uses distinct devices and the RCCL all-gather): ids are global insertion indices and
+    the results equal the single-index / oracle results."""
+    exe = _build(tmp_path)
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 30_000, 128, 65, 10      # 30k rows = 8 chunks of 4096: uneven over 3 shards
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    _write_input(tmp_path / "in.bin", rows, q, k)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "1", str(n_shards)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert f"rows={n} shards={n_shards}" in p.stdout
+    raw = open(tmp_path / "out.bin", "rb").read()
+    idx = np.frombuffer(raw[: nq * k * 8], dtype=np.uint64).reshape(nq, k)
+    sc = np.frombuffer(raw[nq * k * 8: nq * k * 12], dtype=np.float32).reshape(nq, k)
+    back = np.frombuffer(raw[nq * k * 12:], dtype=np.float32)
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+    assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    assert np.array_equal(back, oracle.round_trip(rows[1], 1))

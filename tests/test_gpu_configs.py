@@ -1,0 +1,166 @@
+"""Every BASELINE.json configuration at its FULL single-GPU size (VERDICT r1 'Missing' 3 / 'next' 3):
+
+  C3  10M x 768 bf16, batch 4096, 8 GPUs   -> one GPU's shard: 1.25M rows, the whole 4096-query batch
+  C4  1M x 1536 fp16 dot, batch 256, 1 GPU -> full size
+  C5  500M x 768 fp8, batch 8192, 8 GPUs   -> one GPU's shard: 62.5M rows (48 GB of codes), batch 8192
+(C1 and C2 run in test_gpu_parity.py.)
+
+The CPU oracle cannot scan these corpora inside a test budget, so each case is verified by
+  * size-independent properties: planted probes come back first, idempotence, sortedness, no fallback on random data;
+  * an ORACLE-ANCHORED check of sampled queries that is complete, not statistical: (1) the reported scores are
+    bit-equal to the oracle's arithmetic (simd_ops.rs:15-78 / :149-183) on the rows the library returns for those
+    ids; (2) the exact device scan of the same query over ALL rows (cgv_batch_similarity_f32, itself pinned to the
+    oracle in test_gpu_parity.py and spot-checked here) shows no row outside the reported set that beats the
+    k-th reported (score, id)."""
+import numpy as np
+import pytest
+
+from _util import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _anchored_check(ix, oracle, q_host, idx, sc, metric, odt, queries, rng):
+    op = {"cosine": "cosine", "dot": "dot"}[metric]
+    fn = oracle.cosine_adaptive if metric == "cosine" else oracle.dot_avx2
+    n = len(ix)
+    for qi in queries:
+        qs = oracle.round_trip(q_host[qi], odt, fp8_codes=True) if odt == 3 else oracle.round_trip(q_host[qi], odt)
+        ids = idx[qi].astype(np.int64)
+        # (1) reported score == oracle arithmetic on the stored row behind each reported id
+        for j, rid in enumerate(ids):
+            row = ix.get_row(int(rid))
+            if odt == 3:   # fp8 scores are defined on the e4m3 codes (row * 2^e): cosine is invariant under the row scale
+                row = oracle.round_trip(row, 3, fp8_codes=True)
+            assert np.float32(fn(qs, row)) == sc[qi, j], (qi, j, rid)
+        # (2) completeness against the exact device scan of every row
+        allsc = ix.batch_similarity(q_host[qi], op)
+        assert allsc.shape == (n,)
+        assert np.array_equal(allsc[ids], sc[qi])
+        kth_s, kth_id = sc[qi, -1], ids[-1]
+        better = np.nonzero((allsc > kth_s) | ((allsc == kth_s) & (np.arange(n) < kth_id)))[0]
+        assert set(better.tolist()) == set(ids[:-1].tolist()), (qi, len(better))
+        order = np.lexsort((ids, -sc[qi].astype(np.float64)))
+        assert np.array_equal(order, np.arange(len(ids)))              # (score desc, id asc)
+        # spot-check the exact device scan itself against the oracle on random rows
+        for rid in rng.integers(0, n, 6):
+            row = ix.get_row(int(rid))
+            if odt == 3:
+                row = oracle.round_trip(row, 3, fp8_codes=True)
+            assert np.float32(fn(qs, row)) == allsc[rid]
+
+
+def _fill(ix, n, d, chunk, seed, probe_chunks, per_chunk, unit=True, scale=None):
+    """Append n rows generated on the device; remember `per_chunk` evenly spaced rows of the chunks in
+    `probe_chunks` (probe vectors and the row ids they must come back as)."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    probes, want = [], []
+    ix.reserve(n)
+    for ci, lo in enumerate(range(0, n, chunk)):
+        rows = min(chunk, n - lo)
+        x = torch.randn((rows, d), generator=gen, device="cuda")
+        if unit:
+            x = torch.nn.functional.normalize(x, dim=1)
+        elif scale is not None:
+            x = x * scale
+        if ci in probe_chunks:
+            take = torch.arange(0, rows, max(1, rows // per_chunk), device="cuda")[:per_chunk]
+            probes.append(x[take].clone())
+            want.append(take + lo)
+        ix.add(x)
+    del x
+    return torch.cat(probes), torch.cat(want).cpu()
+
+
+def test_c3_shard_full_batch(oracle):
+    """C3: one GPU's 1.25M-row shard against the whole 4096-query batch (16 query tiles x 16 corpus splits)."""
+    import torch
+    m = pkg()
+    n, d, nq, k = 1_250_000, 768, 4096, 10
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        nch = n // 125_000
+        probe, want = _fill(ix, n, d, 125_000, 0xC0DE6003, (0, nch // 2, nch - 1), 1400)
+        probe, want = probe[:nq], want[:nq]
+        ix.set_index_base(3 * n)                         # the shard of rank 3: ids are global
+        idx, sc = ix.search(probe, k)
+        idx2, sc2 = ix.search(probe, k)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+        assert torch.equal(idx[:, 0].cpu(), want + 3 * n)
+        assert (sc[:, 0] > 0.999).all() and (sc[:, 1:] < 0.5).all() and (sc[:, :-1] >= sc[:, 1:]).all()
+        st = ix.stats()
+        assert st["last_path"] == 1 and st["fallback_queries"] == 0 and st["max_observed_err"] <= 0.5 * st["last_eps"]
+        ix.set_index_base(0)
+        rng = np.random.default_rng(3)
+        qh = torch.nn.functional.normalize(torch.randn((nq, d), generator=torch.Generator(device="cuda").manual_seed(33),
+                                                       device="cuda"), dim=1)
+        gi, gs = ix.search(qh, k)
+        _anchored_check(ix, oracle, qh.cpu().numpy(), gi.cpu().numpy().view(np.uint64), gs.cpu().numpy(), "cosine", 1,
+                        [0, 255, 256, 2047, 4095], rng)
+        assert ix.stats()["fallback_queries"] == 0
+    finally:
+        ix.close()
+
+
+def test_c4_full_size_fp16_dot(oracle):
+    """C4: 1M x 1536 fp16, dot product on UN-normalised rows (norms 0.5..2: the dot metric must not assume unit
+    vectors), batch 256 - the HBM-bound shape (one query tile, 256 corpus splits)."""
+    import torch
+    m = pkg()
+    n, d, nq, k = 1_000_000, 1536, 256, 10
+    ix = m.HipKnnIndex(d, metric="dot", dtype="fp16")
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(0xC0DE6004)
+        ix.reserve(n)
+        for lo in range(0, n, 125_000):
+            x = torch.nn.functional.normalize(torch.randn((125_000, d), generator=gen, device="cuda"), dim=1)
+            x = x * (0.5 + 1.5 * torch.rand((125_000, 1), generator=gen, device="cuda"))
+            ix.add(x)
+        del x
+        q = torch.nn.functional.normalize(torch.randn((nq, d), generator=gen, device="cuda"), dim=1)
+        idx, sc = ix.search(q, k)
+        idx2, sc2 = ix.search(q, k)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+        assert (sc[:, :-1] >= sc[:, 1:]).all() and (idx >= 0).all() and (idx < n).all()
+        st = ix.stats()
+        assert st["last_path"] == 1 and st["fallback_queries"] == 0 and st["max_observed_err"] <= 0.5 * st["last_eps"]
+        rng = np.random.default_rng(4)
+        _anchored_check(ix, oracle, q.cpu().numpy(), idx.cpu().numpy().view(np.uint64), sc.cpu().numpy(), "dot", 2,
+                        list(range(0, 256, 16)), rng)                  # 16 sampled queries
+    finally:
+        ix.close()
+
+
+def test_c5_full_shard_fp8_batch_8192(oracle):
+    """C5: one GPU's full shard - 62.5M x 768 fp8 (48 GB of e4m3 codes + norms / exponents) - against the whole
+    8192-query batch. Probes planted at both ends and in the middle come back first; ids exceed 2^24 (nothing on
+    the path may carry a row id in an f32); 288 GB sizing: device_bytes is reported."""
+    import torch
+    m = pkg()
+    n, d, nq, k, chunk = 62_500_000, 768, 8192, 10, 250_000
+    ix = m.HipKnnIndex(d, dtype="fp8")
+    try:
+        nch = n // chunk
+        probe, want = _fill(ix, n, d, chunk, 0xC0DE6005, (0, nch // 2, nch - 1), 2800)
+        probe, want = probe[:nq], want[:nq]
+        assert probe.shape[0] == nq and int(want.max()) > 60_000_000 > (1 << 24)
+        idx, sc = ix.search(probe, k)
+        torch.cuda.synchronize()
+        assert torch.equal(idx[:, 0].cpu(), want)
+        assert (sc[:, 0] > 0.999).all() and (sc[:, 1:] < 0.5).all() and (sc[:, :-1] >= sc[:, 1:]).all()
+        st = ix.stats()
+        assert st["n_rows"] == n and st["device_bytes"] > n * d and st["last_path"] == 1
+        assert st["fallback_queries"] == 0 and st["max_observed_err"] <= 0.5 * st["last_eps"]
+        idx2, sc2 = ix.search(probe[:1024], k)                         # a smaller batch over the same shard: same answers
+        assert torch.equal(idx2, idx[:1024]) and torch.equal(sc2, sc[:1024])
+        rng = np.random.default_rng(5)
+        qh = torch.nn.functional.normalize(torch.randn((64, d), generator=torch.Generator(device="cuda").manual_seed(55),
+                                                       device="cuda"), dim=1)
+        gi, gs = ix.search(qh, k)
+        _anchored_check(ix, oracle, qh.cpu().numpy(), gi.cpu().numpy().view(np.uint64), gs.cpu().numpy(), "cosine", 3,
+                        [0, 63], rng)
+    finally:
+        ix.close()

@@ -384,42 +384,7 @@ def test_full_size_properties_c2():
         ix.close()
 
 
-def test_large_shard_properties_c5_fp8():
-    """BASELINE config C5's storage at a shard size past 2^24 rows (20M x 768 fp8 = 15 GB; a full C5
-    shard is 62.5M rows = 48 GB, same code path): probes planted at both ends and in the middle of
-    the corpus come back first with score ~1, results are idempotent and sorted, ids exceed 2^24
-    (nothing on the path may carry a row id in an f32), no fallback on random data."""
-    import torch
-    m = pkg()
-    n, d, nq, k, chunk = 20_000_000, 768, 2048, 10, 250_000
-    gen = torch.Generator(device="cuda").manual_seed(0xC0DE6005)
-    ix = m.HipKnnIndex(d, dtype="fp8")
-    try:
-        ix.reserve(n)
-        want, probes = [], []
-        for ci, lo in enumerate(range(0, n, chunk)):
-            x = torch.nn.functional.normalize(torch.randn((chunk, d), generator=gen, device="cuda"), dim=1)
-            if ci in (0, 37, n // chunk - 1):
-                take = torch.arange(0, chunk, chunk // 600, device="cuda")[:600]
-                probes.append(x[take].clone())
-                want.append(take + lo)
-            ix.add(x)
-        del x
-        probe = torch.cat(probes)[:nq]
-        want = torch.cat(want)[:nq].cpu()
-        assert int(want.max()) > (1 << 24)
-        idx, sc = ix.search(probe, k)
-        idx2, sc2 = ix.search(probe, k)
-        torch.cuda.synchronize()
-        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
-        assert torch.equal(idx[:, 0].cpu(), want)
-        assert (sc[:, 0] > 0.999).all() and (sc[:, 1:] < 0.5).all()
-        assert (sc[:, :-1] >= sc[:, 1:]).all()
-        st = ix.stats()
-        assert st["n_rows"] == n and st["device_bytes"] > n * d
-        assert st["fallback_queries"] == 0 and st["max_observed_err"] <= st["last_eps"]
-    finally:
-        ix.close()
+# (BASELINE configs C3, C4 and C5 at their full single-GPU sizes: tests/test_gpu_configs.py)
 
 
 @pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1)])

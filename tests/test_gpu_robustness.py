@@ -1,0 +1,149 @@
+"""Behaviour at the edges of the single-device C ABI (ADVICE r1 + VERDICT r1): failed adds leave no trace,
+k beyond the MFMA path's range, the begin/end pool cannot self-deadlock, per-hit scoring in one launch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _util import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype,odt", [("bf16", 1), ("f32s", 0), ("fp8", 3)])
+def test_nonfinite_add_is_not_applied(oracle, dtype, odt):
+    """A rejected cgv_add_f32 (NaN/Inf row) must not publish rows, poison the index, or block later adds."""
+    m = pkg()
+    rng = np.random.default_rng(1)
+    n, d = 1000 + 13, 64                      # 13: the boundary 32-row block is partially filled
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 20, d)
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        bad = _unit(rng, 300, d) * 50.0        # large norms: must not leak into the max-norm statistic either
+        bad[17, 3] = np.inf
+        with pytest.raises(m.CgvError) as ei:
+            ix.add(bad)
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE and "not applied" in str(ei.value)
+        assert len(ix) == n
+        with pytest.raises(m.CgvError):
+            ix.get_row(n)                      # the rejected rows are not addressable
+        idx, sc = ix.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows, 10, dtype=odt)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        more = _unit(rng, 500, d)
+        ix.add(more)                           # ids continue at n
+        allr = np.vstack([rows, more])
+        idx, sc = ix.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, allr, 10, dtype=odt)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        with pytest.raises(m.CgvError) as ei:  # update with a NaN row: rejected BEFORE the stored row is touched
+            ix.update_row(5, np.full(d, np.nan, np.float32))
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+        assert np.array_equal(ix.get_row(5), oracle.round_trip(rows[5], odt))
+        ix.truncate(n)                          # cgv_truncate: back to the first n rows
+        assert len(ix) == n
+        idx, sc = ix.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows, 10, dtype=odt)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt,k", [("bf16", 1, 228), ("bf16", 1, 300), ("f32s", 0, 61), ("bf16", 1, 2048)])
+def test_k_beyond_the_mfma_range_takes_the_exact_scan(oracle, dtype, odt, k):
+    m = pkg()
+    rng = np.random.default_rng(2)
+    n, d, nq = 6000, 64, 7
+    rows, q = _unit(rng, n, d), _unit(rng, nq, d)
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        idx, sc = ix.search(q, k)
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        fast = k <= (228 if dtype == "bf16" else 60)
+        assert ix.stats()["last_path"] == (1 if fast else 0)
+        with pytest.raises(m.CgvError):
+            ix.search(q, 2049)
+    finally:
+        ix.close()
+
+
+def test_begin_without_end_reports_busy_instead_of_deadlocking():
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(3)
+    ix = m.HipKnnIndex(32, dtype="bf16")
+    try:
+        ix.add(_unit(rng, 5000, 32))
+        q = torch.from_numpy(_unit(rng, 16, 32)).cuda()
+        pend = [ix.search_begin(q, 5) for _ in range(ix.max_in_flight)]
+        with pytest.raises(m.CgvError) as ei:
+            ix.search_begin(q, 5)
+        assert ei.value.code == m.cgvec.CGV_ERR_BUSY
+        with pytest.raises(m.CgvError) as ei:   # the host-pointer entry needs a context too
+            ix.search(q.cpu().numpy(), 5)
+        assert ei.value.code == m.cgvec.CGV_ERR_BUSY
+        first = pend[0].wait()
+        again = ix.search_begin(q, 5).wait()    # a released context is usable again
+        assert torch.equal(first[0], again[0])
+        for p in pend[1:]:
+            p.wait()
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1), ("fp16", 2)])
+def test_score_ids_is_the_per_hit_rescore(oracle, dtype, odt):
+    """cgv_score_ids_f32(CGV_OP_COSINE_SEQ) == search.rs:519-533 on (raw query, stored row), 0.0 for missing ids."""
+    m = pkg()
+    rng = np.random.default_rng(4)
+    n, d, nq, mm = 3000, 100, 9, 37            # d = 100: the sequential formula has no lane structure to get wrong
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[50] = 0.0                              # zero norm -> 0.0
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ids = rng.integers(0, n, (nq, mm)).astype(np.uint64)
+    ids[0, 0] = 50
+    ids[1, 1] = np.uint64(2**64 - 1)           # padding
+    ids[2, 2] = n + 7                          # beyond the index
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        got = ix.score_ids(q, ids, "cosine_seq")
+        stored = oracle.round_trip(rows, odt)
+        exp = np.zeros((nq, mm), np.float32)
+        for a in range(nq):
+            for b in range(mm):
+                if ids[a, b] < n:
+                    exp[a, b] = oracle.search_cosine(q[a], stored[int(ids[a, b])])
+        assert np.array_equal(got, exp)
+        assert got[0, 0] == 0.0 and got[1, 1] == 0.0 and got[2, 2] == 0.0
+        got2 = ix.score_ids(q, ids, "cosine")   # the AVX2-order cosine on the same pairs
+        for a, b in ((3, 3), (4, 10), (8, 36)):
+            assert got2[a, b] == np.float32(oracle.cosine_adaptive(q[a], stored[int(ids[a, b])]))
+    finally:
+        ix.close()
+
+
+def test_two_devices_in_one_process_get_their_kernel_attributes():
+    """hipFuncAttributeMaxDynamicSharedMemorySize is per device: a second device's first search must work
+    (VERDICT r1 weak 2). Skips below 2 GPUs."""
+    m = pkg()
+    if m.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    rng = np.random.default_rng(5)
+    rows, q = _unit(rng, 20000, 128), _unit(rng, 64, 128)
+    outs = []
+    for dev in (0, 1):
+        ix = m.HipKnnIndex(128, dtype="bf16", device=dev)
+        ix.add(rows)
+        outs.append(ix.search(q, 10))
+        ix.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -1,0 +1,234 @@
+"""Multi-GPU behind the C ABI (VERDICT r1 g3 / 'Missing' 1, 5): ONE cgv_sharded handle over several shards
+(block-cyclic rows, one exchange of packed top-k records, merge on the root), the id map it relies on,
+and the one-process-per-GPU path (torch.distributed nccl = RCCL) across two real ranks.
+
+On a 1-GPU box the sharded handle lists device 0 several times (exchange = device copies): every piece of
+the path runs except the RCCL collective itself; boxes with >= 2 GPUs run it on distinct devices with both
+exchanges (RCCL all-gather and peer copies), and the 2-rank torch.distributed test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from _util import ROOT, pkg
+
+pytestmark = pytest.mark.gpu
+
+C = 4096   # CGV_SHARD_CHUNK_ROWS
+
+
+def _ndev():
+    try:
+        return pkg().device_count()
+    except Exception:   # library not built yet (collection on the CPU box)
+        return 0
+
+
+def _devices(m, g):
+    nd = m.device_count()
+    return [i % nd for i in range(g)]
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+
+
+def test_id_map_reports_block_cyclic_global_ids(oracle):
+    """cgv_set_id_map: local row r of shard s (of G) is reported as ((r / C) * G + s) * C + r % C."""
+    m = pkg()
+    rng = np.random.default_rng(1)
+    n, d, G, s = 3 * C + 77, 64, 3, 1
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 9, d)
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        ix.set_id_map(C, G, s)
+        idx, sc = ix.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows, 10, dtype=1)
+        exp = ((ri // C) * G + s) * C + ri % C
+        assert np.array_equal(idx, exp.astype(np.uint64)) and np.array_equal(sc, rs)
+        ix.set_force_exact(True)          # the exact scan reports through the same map
+        idx2, sc2 = ix.search(q, 10)
+        assert np.array_equal(idx2, idx) and np.array_equal(sc2, sc)
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("g,dtype", [(2, "bf16"), (3, "fp16"), (4, "f32s"), (2, "fp8")])
+def test_sharded_handle_matches_oracle(oracle, g, dtype):
+    m = pkg()
+    odt = {"bf16": 1, "fp16": 2, "f32s": 0, "fp8": 3}[dtype]
+    rng = np.random.default_rng(20 + g)
+    n, d, nq, k = 5 * C + 1234, 96, 130, 10
+    rows = _unit(rng, n, d)
+    rows[7] = rows[n - 5]                      # a tie across two shards: lower global id first
+    q = _unit(rng, nq, d)
+    sx = m.ShardedIndex(d, _devices(m, g), dtype=dtype)
+    try:
+        assert sx.n_shards == g
+        assert sx.exchange == ("rccl" if len(set(_devices(m, g))) == g else "copy")
+        # incremental inserts that do not line up with the chunks
+        cuts = [0, 1000, C + 1, 3 * C, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sx.add(rows[a:b])
+        assert len(sx) == n
+        # block-cyclic balance: the shards differ by at most one chunk
+        cnt = sx.shard_counts()
+        assert sum(cnt) == n and max(cnt) - min(cnt) <= C
+        idx, sc = sx.search(q, k)
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+        assert np.array_equal(idx, ri), f"ids differ {idx[:2]} {ri[:2]}"
+        assert np.array_equal(sc, rs)
+        # rows come back by GLOBAL id
+        for rid in (0, C - 1, C, 2 * C + 5, n - 1):
+            assert np.array_equal(sx.get_row(rid), oracle.round_trip(rows[rid], odt))
+        # in-place update on whichever shard owns the row, then the search sees it
+        sx.update_row(2 * C + 5, q[3])
+        rows2 = rows.copy()
+        rows2[2 * C + 5] = q[3]
+        idx2, sc2 = sx.search(q[:8], k)
+        ri2, rs2 = oracle.batch_top_k(q[:8], rows2, k, dtype=odt)
+        assert np.array_equal(idx2, ri2) and np.array_equal(sc2, rs2)
+        assert idx2[3, 0] == 2 * C + 5
+        st = sx.stats()
+        assert st["n_rows"] == n and st["n_shards"] == g and st["searches"] == 2 and st["last_search_ms"] > 0
+        assert st["fallback_queries"] <= 2      # the planted tie may send its queries through the exact scan
+    finally:
+        sx.close()
+
+
+def test_sharded_add_is_all_or_nothing(oracle):
+    """A NaN row in one shard's part of an insert: CGV_ERR_NONFINITE and NO shard keeps any row of it."""
+    m = pkg()
+    rng = np.random.default_rng(3)
+    d = 64
+    rows = _unit(rng, 3 * C, d)
+    sx = m.ShardedIndex(d, _devices(m, 2), dtype="bf16")
+    try:
+        sx.add(rows[:C + 100])
+        before = sx.shard_counts()
+        bad = rows[C + 100:].copy()
+        bad[C + 50, 7] = np.nan                # lands in a later chunk = on the other shard
+        with pytest.raises(m.CgvError) as ei:
+            sx.add(bad)
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+        assert len(sx) == C + 100 and sx.shard_counts() == before
+        q = _unit(rng, 5, d)
+        idx, sc = sx.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows[:C + 100], 10, dtype=1)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        sx.add(rows[C + 100:])                 # the clean rows go in afterwards, ids continue
+        idx, sc = sx.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows, 10, dtype=1)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    finally:
+        sx.close()
+
+
+def test_sharded_degenerate_inputs():
+    m = pkg()
+    sx = m.ShardedIndex(32, _devices(m, 2), dtype="bf16")
+    try:
+        q = np.ones((3, 32), np.float32)
+        idx, sc = sx.search(q, 4)              # empty index: padded results
+        assert (idx == np.uint64(2**64 - 1)).all() and np.isneginf(sc).all()
+        sx.add(np.eye(32, dtype=np.float32)[:3])   # fewer rows than k, all on shard 0
+        idx, sc = sx.search(q, 4)
+        assert sorted(idx[0, :3].tolist()) == [0, 1, 2] and idx[0, 3] == np.uint64(2**64 - 1)
+        with pytest.raises(m.CgvError):
+            sx.get_row(3)
+        with pytest.raises(m.CgvError):
+            sx.search(np.ones((1, 31), np.float32), 4)
+    finally:
+        sx.close()
+
+
+@pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 GPUs")
+@pytest.mark.parametrize("exchange", ["rccl", "copy"])
+def test_sharded_handle_on_distinct_devices(oracle, exchange):
+    """Distinct devices: the in-library RCCL all-gather (default) and the peer-copy exchange give the same answer."""
+    m = pkg()
+    g = min(m.device_count(), 8)
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 9 * C + 17, 128, 257, 10
+    rows = _unit(rng, n, d)
+    q = _unit(rng, nq, d)
+    sx = m.ShardedIndex(d, list(range(g)), dtype="bf16")
+    try:
+        assert sx.exchange == "rccl"
+        sx.set_exchange(exchange)
+        sx.add(rows)
+        for _ in range(3):
+            idx, sc = sx.search(q, k)
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        assert sx.stats()["exchange"] == exchange
+    finally:
+        sx.close()
+
+
+# ---- one process per GPU: two real ranks over RCCL --------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, n, d, nq, k, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    m = pkg()
+    rng = np.random.default_rng(99)
+    rows = _unit(rng, n, d)
+    rows[11] = rows[n - 2]     # cross-shard tie
+    q = _unit(rng, nq, d)
+    lo, hi = m.shard_range(n, rank, world)
+    ix = m.HipKnnIndex(d, dtype="bf16", device=rank)
+    ix.add(rows[lo:hi])
+    ix.set_index_base(lo)
+    sh = m.ShardedKnn(ix, rank=rank, world=world)      # device pack -> all_gather_into_tensor -> device merge
+    qd = torch.from_numpy(q).cuda()
+    idx, sc = sh.search(qd, k)
+    p1 = sh.search_begin(qd, k)
+    p2 = sh.search_begin(torch.flip(qd, dims=[0]), k)
+    i1, s1 = p1.wait()
+    i2, s2 = p2.wait()
+    assert torch.equal(i1, idx) and torch.equal(s1, sc)
+    assert torch.equal(i2, torch.flip(idx, dims=[0])) and torch.equal(s2, torch.flip(sc, dims=[0]))
+    np.save(f"{out}.{rank}.idx.npy", idx.cpu().numpy().view(np.uint64))
+    np.save(f"{out}.{rank}.sc.npy", sc.cpu().numpy())
+    ix.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 GPUs")
+def test_two_ranks_rccl_device_exchange(tmp_path, oracle):
+    """Real HipKnnIndex shards on two ranks, the device pack / RCCL all-gather / device merge of ShardedKnn:
+    every rank ends with the single-index answer (the gloo test substitutes the oracle for all of that)."""
+    import torch.multiprocessing as mp
+    n, d, nq, k = 40_000, 128, 200, 10
+    out = str(tmp_path / "r")
+    mp.spawn(_rank_main, args=(2, _free_port(), n, d, nq, k, out), nprocs=2, join=True)
+    rng = np.random.default_rng(99)
+    rows = _unit(rng, n, d)
+    rows[11] = rows[n - 2]
+    q = _unit(rng, nq, d)
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+    for r in range(2):
+        assert np.array_equal(np.load(f"{out}.{r}.idx.npy"), ri)
+        assert np.array_equal(np.load(f"{out}.{r}.sc.npy"), rs)

@@ -25,7 +25,7 @@ def _expected_search_by_embedding(oracle, q, rows_stored, ids, limit, odt):
     """search.rs:91-144 on the oracle: prefetch by O2 top-k, re-score with the search.rs formula
     against get_embedding (= the stored rows), stable sort desc, truncate, min-max."""
     pk = oracle.prefetch_k(limit)
-    idx, _ = oracle.batch_top_k(q[None, :], rows_stored, min(pk, 256), dtype=odt)
+    idx, _ = oracle.batch_top_k(q[None, :], rows_stored, min(pk, len(rows_stored)), dtype=odt)
     cand = [int(i) for i in idx[0] if i != np.uint64(2**64 - 1)]
     scored = [(c, oracle.search_cosine(q, rows_stored[c])) for c in cand]
     scored = sorted(scored, key=lambda t: -t[1])[:limit]          # python's sort is stable
@@ -201,3 +201,75 @@ def test_sharded_device_exchange_single_process(oracle, monkeypatch):
     finally:
         for ix in shards:
             ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt", [("f32", 0), ("bf16", 1)])
+def test_large_limits_are_not_truncated(oracle, dtype, odt):
+    """prefetch_k(max(4L, L+25)) exceeds 256 neighbours from limit 22 on; the backend used to clamp
+    silently. Limits 30 and 100 (over-fetch 360 / 1200, served by the exact scan on the device) with a selective
+    filter must return what the reference returns."""
+    st, ids, rows, rng = _mk(2500, 96, 21, dtype)
+    stored = oracle.round_trip(rows, odt)
+    for i, nid in enumerate(ids):
+        st.upsert_node_metadata(nid, language="Rust" if i % 7 == 0 else "Go", node_type="Function", file_path=f"src/f{i}.rs")
+    idx_of = {nid: i for i, nid in enumerate(ids)}
+    q = rng.standard_normal(96).astype(np.float32)
+    for limit in (30, 100):
+        got = st.search_by_embedding(q, limit)
+        exp = _expected_search_by_embedding(oracle, q, stored, ids, limit, 0)
+        assert len(got) == limit and [g[0] for g in got] == [e[0] for e in exp]
+        assert np.array_equal(np.array([g[1] for g in got], np.float32), np.array([e[1] for e in exp], np.float32))
+        pk = max(4 * limit, limit + 25)
+        base = _expected_search_by_embedding(oracle, q, stored, ids, pk, 0)
+        keep = [(n, s) for n, s in base if idx_of[n] % 7 == 0][:limit]
+        got = st.semantic_search(q, {"languages": ["Rust"], "node_types": None, "attribute_equals": {}, "path_prefixes": []}, limit)
+        assert [g[0] for g in got] == [k[0] for k in keep]
+        assert limit < 100 or len(got) > 256 // 7   # more than the old 256-neighbour clamp could yield
+        assert np.array_equal(np.array([g[1] for g in got], np.float32), oracle.normalize_scores([s for _, s in keep]))
+    st.close()
+
+
+def test_vector_knn_beyond_max_k_is_an_error_not_a_truncation():
+    m = pkg()
+    st, ids, rows, rng = _mk(3000, 32, 22, "bf16")
+    q = rng.standard_normal(32).astype(np.float32)
+    assert len(st.vector_knn("embedding_2048", np.zeros(2048, np.float32), 5)) == 0
+    with pytest.raises(m.CgvError, match="CGV_MAX_K"):
+        st.search_similar(q, 2500)         # 2500 <= 3000 rows but > CGV_MAX_K = 2048
+    assert len(st.search_similar(q, 2048)) == 2048
+    st.close()
+
+
+def test_duplicate_ids_in_one_upsert_batch_last_writer_wins(oracle):
+    """an id repeated inside one store_embeddings call keeps the LAST embedding (UPSERT)."""
+    m = pkg()
+    rng = np.random.default_rng(23)
+    d = 64
+    a, b, c = (rng.standard_normal(d).astype(np.float32) for _ in range(3))
+    i1, i2 = uuid.uuid4(), uuid.uuid4()
+    st = m.store.VectorStore(dtype="f32")
+    st.store_embeddings([i1, i2, i1], np.stack([a, b, c]))
+    assert np.array_equal(st.get_embedding(i1), c) and np.array_equal(st.get_embedding(i2), b)
+    assert st.search_similar(c, 2)[0] == i1 and len(st.search_similar(c, 5)) == 2
+    st.close()
+
+
+def test_rejected_upsert_leaves_store_consistent(oracle):
+    """a NaN embedding fails the upsert; the column keeps its rows, ids stay aligned, later upserts work."""
+    m = pkg()
+    st, ids, rows, rng = _mk(600, 48, 24, "bf16")
+    bad = rng.standard_normal((3, 48)).astype(np.float32)
+    bad[1, 5] = np.nan
+    new_ids = [uuid.uuid4() for _ in range(3)]
+    with pytest.raises(m.CgvError) as ei:
+        st.store_embeddings(new_ids, bad)
+    assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+    assert st.get_embedding(new_ids[0]) is None
+    q = rng.standard_normal(48).astype(np.float32)
+    ref_i, _ = oracle.batch_top_k(q[None, :], rows, 7, dtype=1)
+    assert st.search_similar(q, 7) == [ids[int(i)] for i in ref_i[0]]
+    good = rng.standard_normal((3, 48)).astype(np.float32)
+    st.store_embeddings(new_ids, good)
+    assert np.array_equal(st.get_embedding(new_ids[2]), oracle.round_trip(good[2], 1))
+    assert st.search_similar(good[2], 1) == [new_ids[2]]
+    st.close()
