@@ -36,6 +36,7 @@
 #include "common.h"
 #include "kernels_coarse.h"
 #include "kernels_coarse_fp8.h"
+#include "kernels_coarse_w4.h"
 #include "kernels_exact.h"
 #include "kernels_prep.h"
 #include "kernels_select.h"
@@ -425,6 +426,8 @@ int ensure_kernel_attrs(int device) {
     CGV_ATTR((coarse_kernel<DT_FP16, true>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_kernel<DT_FP8, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_kernel<DT_FP8, true>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_w4_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_w4_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
     CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
@@ -465,6 +468,50 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
 #undef CGV_ABLK
         HIPCHK(hipGetLastError());
         return CGV_OK;
+    }
+    // one-wave-per-SIMD variant (kernels_coarse_w4.h) for bf16 / fp16 searches with kc >= 4;
+    // CGV_COARSE=w8 keeps the 8-wave kernel for A/B timing
+    static const bool use_w4 = !(getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8"));
+    if (use_w4 && !DUMP && DT != DT_FP8 && a.kc >= 4) {
+        static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
+        if (abl4 && DT == DT_BF16) {
+#define CGV_ABLK4(N)                                                                                             \
+    case N: {                                                                                                    \
+        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
+        break;                                                                                                   \
+    }
+            switch (abl4) {
+                CGV_ABLK4(1) CGV_ABLK4(2) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(13) CGV_ABLK4(15) CGV_ABLK4(33) CGV_ABLK4(41) CGV_ABLK4(65) CGV_ABLK4(193)
+                default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
+            }
+#undef CGV_ABLK4
+            HIPCHK(hipGetLastError());
+            return CGV_OK;
+        }
+        static const int sched4 = getenv("CGV_W4_SCHED") ? atoi(getenv("CGV_W4_SCHED")) : 0;
+        if (sched4 && DT == DT_BF16) {  // timing experiments (SCHED 1..3 give the same results as 0)
+#define CGV_SCHK(N)                                                                                              \
+    case N: {                                                                                                    \
+        auto k2 = coarse_w4_kernel<DT_BF16, false, 0, N>;                                                        \
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
+        break;                                                                                                   \
+    }
+            switch (sched4) {
+                CGV_SCHK(1) CGV_SCHK(2) CGV_SCHK(3)
+                default: return fail(CGV_ERR_INVALID_ARG, "CGV_W4_SCHED: 1..3");
+            }
+#undef CGV_SCHK
+            HIPCHK(hipGetLastError());
+            return CGV_OK;
+        }
+        if constexpr (!DUMP && DT != DT_FP8) {
+            hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
+            HIPCHK(hipGetLastError());
+            return CGV_OK;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
     HIPCHK(hipGetLastError());

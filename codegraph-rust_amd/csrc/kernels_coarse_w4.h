@@ -1,0 +1,321 @@
+// kernels_coarse_w4.h — the coarse kernel as ONE WAVE PER SIMD: 4 waves per workgroup, each owning a
+// 128 x 128 output tile (4 x 4 blocks of v_mfma_f32_32x32x16) of the same 256 x 256 workgroup tile, with
+// the 256 accumulator registers in the accumulator half of the 512-entry register file.
+//
+// Why (VERDICT r1 'next' 5(iii); measurements in DESIGN.md §9): with two 128 x 64 waves per SIMD the
+// kernel issues 6 ds_read_b128 per 8 MFMAs and both waves of a SIMD compete for its matrix pipe; with one
+// 128 x 128 wave it is 8 reads per 16 MFMAs, nobody to compete with, and every MFMA gap (32 cycles) has
+// room for the ~2 other instructions the stage needs per MFMA (8 DMA pieces, 16 fragment reads, one
+// barrier, a dozen scalar ops per 32 MFMAs).
+// Everything else is the 8-wave kernel's design (kernels_coarse.h): B32 blocked operands, 4-stage LDS ring
+// filled by buffer_load ... lds three stages ahead and retired by a counted vmcnt, one barrier per stage,
+// tile-structured loop with zero-C MFMAs at the tile boundary, the fused threshold top-k' epilogue
+// (tile_epilogue), XCD-aware workgroup mapping. Differences:
+//   * a wave copies 4 KiB of the A block and 4 KiB of the B block per stage: 8 DMA instructions, the four of
+//     a block sharing one M0 / scalar offset and stepping by the instruction's immediate offset (1 KiB);
+//   * the per-tile side data (inverse norms, block bounds) is issued in the straight-line tile-boundary
+//     block for the tile that STARTS there (needs kc >= 3: the host uses this kernel for kc >= 4), so the
+//     stage loop contains no branch except its back edge.
+#pragma once
+#include "kernels_coarse.h"
+
+namespace cgv {
+
+template <int DT, bool DUMP, int ABL = 0, int SCHED = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void coarse_w4_kernel(const CoarseArgs a) {
+    constexpr int BM = 256, BN = 256, WN = 2, NT = 256;
+    constexpr int WTM = 128, WTN = 128, MB = 4, NB = 4;
+    constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
+    constexpr int NSTAGE = 4, NINV = 8;
+    typedef typename Mfma<DT>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
+    float* invn_s = (float*)(smem + NSTAGE * STAGE + BN * 4);  // [NINV][256], by tile sequence number
+    float* stat_s = invn_s + NINV * 256;                        // [NINV][16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const uint32_t W = gridDim.x;
+    uint32_t g = blockIdx.x;
+    if ((W & 7u) == 0) g = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
+    const uint32_t qt = g % a.nqt, split = g / a.nqt;
+
+    for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+
+    float tauv[NB], tq[NB], invq[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const bool valid = q < a.nq;
+        const float tau = valid ? a.tau[q] : INFINITY;
+        const float iq = (a.metric == METRIC_DOT) ? 1.0f : (valid ? a.invn_q[q] : 0.0f);
+        tauv[nb] = tau;
+        invq[nb] = iq;
+        tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
+    }
+
+    // uniform by construction; readfirstlane makes it provable (the 64-bit divisions run on the VALU)
+    const uint32_t jlo = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)split * a.cnt) / a.nsplit));
+    const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit));
+    const uint32_t KC = a.kc;
+    const uint32_t total = (jhi - jlo) * KC;  // pipeline stages of this workgroup
+    const uint32_t ntl = jhi - jlo;
+    if (total == 0) {  // uniform: nothing to stream for this workgroup
+        for (int i = tid; i < BN; i += NT) a.cand_cnt[(uint64_t)g * BN + i] = 0;
+        return;
+    }
+
+    const uint32_t t_first = __builtin_amdgcn_readfirstlane(stage_tile(a.T1, a.R, a.P, a.j0 + jlo) - a.T1);
+    auto next_tile = [&](uint32_t t) {
+        const uint32_t u = t + a.P;  // P < R <= 2^24 tiles: no overflow
+        return u >= a.R ? u - a.R : u;
+    };
+
+    // ---- DMA issue side: three stages ahead of the consume side --------------------------------------
+    uint32_t lkc = 0, issued = 0, lt = t_first;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0,
+                                                                   0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.qrows + (uint64_t)qt * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t stg[8];           // ABL & 64 only
+    if (ABL & 64)
+        for (int i = 0; i < 8; ++i) stg[i] = (u32x4_t)0;
+    uint32_t d_so = 0;        // scalar offset of the stage being issued (chunk * 16 KiB + wave * 4 KiB)
+    char* d_dst = smem;       // LDS base of this wave's share of it
+    // timing-only forms: ABL & 32: 4-byte pieces (same instruction count, a quarter of the bytes);
+    // ABL & 64: an ordinary buffer_load to VGPRs instead of the LDS-DMA, consumed one stage later by a
+    // register use (or, with ABL & 128, by a ds_write_b128 to the piece's LDS slot = register staging)
+#define CGV_DMA(RS, DST, IMM, Q)                                                                                     \
+    {                                                                                                                \
+        if (ABL & 64) {                                                                                              \
+            if (ABL & 128)                                                                                           \
+                *(u32x4_t*)((DST) + (IMM) + lane * 16) = stg[Q];                                                     \
+            else                                                                                                     \
+                asm volatile("" ::"v"(stg[Q]));                                                                      \
+            stg[Q] = __builtin_amdgcn_raw_buffer_load_b128(RS, voff + (IMM), d_so, 0);                               \
+        } else if (ABL & 32)                                                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 4, voff, d_so, IMM, 0); \
+        else                                                                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0); \
+    }
+    // piece Q of the stage: 0..3 = KiB 0..3 of this wave's share of the A block, 4..7 = of the B block
+#define CGV_ISSUE(Q)                                                                                     \
+    {                                                                                                    \
+        if (!(ABL & 2)) {                                                                                \
+            if (Q == 0) {                                                                                \
+                d_so = lkc * BLOCK_BYTES + (uint32_t)wave * 4096u;                                       \
+                d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 4096;                            \
+            }                                                                                            \
+            if (Q == 0) CGV_DMA(rsA, d_dst, 0, 0);                                                          \
+            if (Q == 1) CGV_DMA(rsA, d_dst, 1024, 1);                                                       \
+            if (Q == 2) CGV_DMA(rsA, d_dst, 2048, 2);                                                       \
+            if (Q == 3) CGV_DMA(rsA, d_dst, 3072, 3);                                                       \
+            if (Q == 4) CGV_DMA(rsB, d_dst + A_BYTES, 0, 4);                                                \
+            if (Q == 5) CGV_DMA(rsB, d_dst + A_BYTES, 1024, 5);                                             \
+            if (Q == 6) CGV_DMA(rsB, d_dst + A_BYTES, 2048, 6);                                             \
+            if (Q == 7) CGV_DMA(rsB, d_dst + A_BYTES, 3072, 7);                                             \
+        }                                                                                                \
+        if (Q == 7) {                                                                                    \
+            ++issued;                                                                                    \
+            /* the stream never ends: past the last stage it re-reads the last one into the free slot */ \
+            if (issued < total && ++lkc == KC) {                                                         \
+                lkc = 0;                                                                                 \
+                lt = next_tile(lt);                                                                      \
+                rsA = __builtin_amdgcn_make_buffer_rsrc(                                                 \
+                    (void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000); \
+            }                                                                                            \
+        }                                                                                                \
+    }
+    // side data of the tile with sequence number SEQ (absolute tile T1 + TT): 256 inverse norms by wave 0,
+    // 8 + 8 block norm bounds by 4 lanes of wave 1. Issued at the tile boundary where the tile starts.
+    auto issue_side = [&](uint32_t tt, uint32_t seq) {
+        if (ABL & 2) return;
+        if (wave == 0)
+            glds16((const char*)a.invn_c + (uint64_t)(a.T1 + tt) * 1024 + lane * 16, (char*)(invn_s + (seq & (NINV - 1)) * 256));
+        if (wave == 1 && lane < 4) {
+            const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + tt) * 8 + (lane & 1) * 4;
+            glds16((const char*)sp, (char*)(stat_s + (seq & (NINV - 1)) * 16));
+        }
+    };
+
+    // fragment read offsets (bytes): row r = base32 + (lane&31); the lane's piece of k-step kk is
+    // c = 2*kk + (lane>>5), stored at slot c ^ ((r>>2)&3)
+    uint32_t xo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) xo[kk] = (uint32_t)((((2 * kk + (lane >> 5)) ^ ((lane >> 2) & 3))) << 4);
+    const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 64;
+    const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 64;
+
+    f32x16_t acc[MB][NB];
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16;
+
+    frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
+#define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                                   \
+    if (!(ABL & 8)) {                                                                                      \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) FA[mb] = *(const frag*)((BASE) + aoff + mb * 2048 + xo[KK]); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) FB[nb] = *(const frag*)((BASE) + boff + nb * 2048 + xo[KK]); \
+    }
+#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
+#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
+#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
+#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], zero16);
+    // Program-order pins. An MFMA is a pure register operation: instruction selection is free to place it
+    // anywhere its operands allow, sched_barrier or not (the first build of this kernel had the phase's first
+    // MFMA sunk below the fragment reads, so its lgkmcnt(0) waited for the reads just issued). An empty asm
+    // that consumes a result (the MFMA writing it comes before this point) or redefines an operand (the MFMAs
+    // reading it come after this point) ties them to the chain of side-effecting instructions (LDS reads,
+    // DMA, barrier, waits: "memory"), which keeps its order.
+    // One gap = what is issued between MFMA (MBI, NBI) and the next one: with ONE wave on the SIMD nothing
+    // else covers an issue stall, so the 8 fragment reads of the next k-step go one per gap behind the first
+    // 8 MFMAs and the 4 DMA pieces one per two gaps behind the last 8 (8 reads back to back measured 0.33 ms
+    // of 1.08 on the C2 main launch: the matrix pipe drains while they issue).
+#define CGV_GAP(MBI, NBI, NEXT_OPERAND, ACTION)                        \
+    asm volatile("" : "+a"(acc[MBI][NBI])::"memory");                  \
+    ACTION;                                                            \
+    asm volatile("" : "+v"(NEXT_OPERAND)::"memory");
+#define CGV_NOP_ACTION
+    // One k-step: 16 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from
+    // LDS stage NBASE, k-step NKK; Q0.. = the DMA pieces issued here; FIRST = what follows the first MFMA
+    // (the stage's wait + barrier in a B phase).
+    // SCHED (timing experiments): where the 4 DMA pieces of a k-step go. 0: gaps 10, 12, 14, 16; 1: all in gap 16;
+    // 2: two in gap 12, two in gap 16; 3: all 8 of the stage right behind the stage barrier.
+#define CGV_DMAS(G, Q0)                                                                       \
+    {                                                                                         \
+        if (SCHED == 0) {                                                                     \
+            if (G == 10) CGV_ISSUE(Q0);                                                       \
+            if (G == 12) CGV_ISSUE(Q0 + 1);                                                   \
+            if (G == 14) CGV_ISSUE(Q0 + 2);                                                   \
+            if (G == 16) CGV_ISSUE(Q0 + 3);                                                   \
+        } else if (SCHED == 1) {                                                              \
+            if (G == 16) { CGV_ISSUE(Q0); CGV_ISSUE(Q0 + 1); CGV_ISSUE(Q0 + 2); CGV_ISSUE(Q0 + 3); } \
+        } else if (SCHED == 2) {                                                              \
+            if (G == 12) { CGV_ISSUE(Q0); CGV_ISSUE(Q0 + 1); }                                \
+            if (G == 16) { CGV_ISSUE(Q0 + 2); CGV_ISSUE(Q0 + 3); }                            \
+        }                                                                                     \
+    }
+#define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                \
+    {                                                                                         \
+        MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LDA(NA, 0, NBASE, NKK))             \
+        MMA(0, 1, FA, FB) CGV_GAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK))                   \
+        MMA(0, 2, FA, FB) CGV_GAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK))                   \
+        MMA(0, 3, FA, FB) CGV_GAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK))                   \
+        MMA(1, 0, FA, FB) CGV_GAP(1, 0, FB[1], CGV_LDB(NB_, 3, NBASE, NKK))                   \
+        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[2], CGV_LDA(NA, 1, NBASE, NKK))                    \
+        MMA(1, 2, FA, FB) CGV_GAP(1, 2, FB[3], CGV_LDA(NA, 2, NBASE, NKK))                    \
+        MMA(1, 3, FA, FB) CGV_GAP(1, 3, FA[2], CGV_LDA(NA, 3, NBASE, NKK))                    \
+        MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_NOP_ACTION)                                \
+        MMA(2, 1, FA, FB) CGV_GAP(2, 1, FB[2], CGV_DMAS(10, Q0))                              \
+        MMA(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_NOP_ACTION)                                \
+        MMA(2, 3, FA, FB) CGV_GAP(2, 3, FA[3], CGV_DMAS(12, Q0))                              \
+        MMA(3, 0, FA, FB) CGV_GAP(3, 0, FB[1], CGV_NOP_ACTION)                                \
+        MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[2], CGV_DMAS(14, Q0))                              \
+        MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_NOP_ACTION)                                \
+        MMA(3, 3, FA, FB) CGV_GAP(3, 3, NA[0], CGV_DMAS(16, Q0))                              \
+    }
+#define CGV_STAGE_SYNC                                                      \
+    if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      \
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                           \
+    if (SCHED == 3) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7) }
+    // A phase: k-step 0 of stage SB_ (fragments fa0/fb0), filling fa1/fb1 from the same stage's k-step 1;
+    // B phase: k-step 1 of the previous stage (fa1/fb1), the stage barrier, filling fa0/fb0 from stage SB_.
+#define CGV_A_PHASE(MMA, SB_) CGV_KSTEP(MMA, fa0, fb0, fa1, fb1, SB_, 1, 4, CGV_NOP_ACTION)
+#define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
+#define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
+    if (!(ABL & 1))                                                                                                \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
+                                                      invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
+                                                      stat_s + ((SEQ) & (NINV - 1)) * 16);
+
+    // ---- prologue: side data of the first tile, three stages in flight ---------------------------------
+    issue_side(t_first, 0);
+#pragma unroll 1
+    for (int i = 0; i < NSTAGE - 1; ++i) {
+        CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7)
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (and the side data before it) landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
+    __builtin_amdgcn_s_barrier();
+    CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
+    if (ABL & 8) {  // timing only: fragments read ONCE (real data: zero operands would raise the clock), never refreshed
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa1[i] = fa0[i] = *(const frag*)(smem + aoff + i * 2048 + xo[0]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fb1[i] = fb0[i] = *(const frag*)(smem + boff + i * 2048 + xo[1]);
+    }
+
+    // Iteration s: B phase = k-step 1 of stage s-1 (its barrier frees slot (s-1)&3 for the DMA of stage s+3
+    // and publishes stage s), A phase = k-step 0 of stage s. DMA lead: 3 stages = 24 instructions per wave,
+    // of which the 16 youngest may be in flight at the wait.
+    uint32_t ct = t_first, s = 1;
+    if (SCHED != 3) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) }  // first half of stage 3 -> slot 3 (never used so far)
+    else { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7) }
+    CGV_A_PHASE(CGV_MMAZ, smem);
+#pragma unroll 1
+    for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
+        const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+        CGV_B_PHASE(sb);
+        CGV_A_PHASE(CGV_MMA, sb);
+    }
+#pragma unroll 1
+    for (uint32_t tl = 1; tl < ntl; ++tl) {
+        {
+            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            CGV_B_PHASE(sb);
+            const uint32_t nt = next_tile(ct);
+            issue_side(nt, tl);  // the tile that starts here; consumed KC stages from now
+            CGV_EPILOGUE(a.T1 + ct, tl - 1);
+            ct = nt;
+            CGV_A_PHASE(CGV_MMAZ, sb);
+            ++s;
+        }
+#pragma unroll 1
+        for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
+            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            CGV_B_PHASE(sb);
+            CGV_A_PHASE(CGV_MMA, sb);
+        }
+    }
+    // tail: second k-step of the last stage, then the last tile's epilogue
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
+    __builtin_amdgcn_s_barrier();
+    CGV_EPILOGUE(a.T1 + ct, ntl - 1);
+#undef CGV_EPILOGUE
+#undef CGV_B_PHASE
+#undef CGV_A_PHASE
+#undef CGV_KSTEP
+#undef CGV_DMAS
+#undef CGV_GAP
+#undef CGV_NOP_ACTION
+#undef CGV_STAGE_SYNC
+#undef CGV_LDA
+#undef CGV_LDB
+#undef CGV_MMAZ
+#undef CGV_MMA
+#undef CGV_LOAD_FRAGS
+#undef CGV_ISSUE
+#undef CGV_DMA
+
+    __syncthreads();
+    for (int i = tid; i < BN; i += NT) {
+        const uint32_t c = cntq[i];
+        a.cand_cnt[(uint64_t)g * BN + i] = c < CAND_CAPS ? c : CAND_CAPS;
+    }
+}
+
+}  // namespace cgv

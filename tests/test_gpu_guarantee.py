@@ -64,9 +64,10 @@ def test_measured_coarse_error_stays_inside_the_model_bound(oracle, dtype, d):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8", "f32s"])
 def test_near_duplicate_cluster_straddling_kprime_falls_back_and_stays_exact(oracle, dtype):
-    """40 near-copies of one vector around each probed query (k = 10, k' = 16): the k-th and the (k'+1)-th best
-    are closer than eps (many are bit-equal after rounding), the guarantee cannot be proven, the query goes to
-    the exact scan, and ids / order (ties by id) / scores still equal the oracle's."""
+    """A cluster of near-copies of one vector, larger than k' (k = 10; k' = 16, or 56 for the f32 + shadow index),
+    around each probed query: the k-th and the (k'+1)-th best are closer than eps (many are bit-equal after
+    rounding), the guarantee cannot be proven, the query goes to the exact scan, and ids / order (ties by id) /
+    scores still equal the oracle's."""
     m = pkg()
     rng = np.random.default_rng(7)
     n, d, nq, k = 30_000, 256, 96, 10
@@ -74,10 +75,11 @@ def test_near_duplicate_cluster_straddling_kprime_falls_back_and_stays_exact(ora
     rows /= np.linalg.norm(rows, axis=1, keepdims=True)
     q = rng.standard_normal((nq, d)).astype(np.float32)
     probes = [3, 40, 77]
+    cl = 80 if dtype == "f32s" else 40
     for j, p in enumerate(probes):
         base = q[p] / np.linalg.norm(q[p])
-        where = rng.choice(n, 40, replace=False)
-        noise = (1e-4 if j else 0.0) * rng.standard_normal((40, d)).astype(np.float32)   # j = 0: exact duplicates
+        where = rng.choice(n, cl, replace=False)
+        noise = (1e-4 if j else 0.0) * rng.standard_normal((cl, d)).astype(np.float32)   # j = 0: exact duplicates
         rows[where] = base[None, :] + noise
     ix = m.HipKnnIndex(d, dtype=dtype)
     try:

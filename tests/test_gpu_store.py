@@ -233,7 +233,6 @@ def test_vector_knn_beyond_max_k_is_an_error_not_a_truncation():
     m = pkg()
     st, ids, rows, rng = _mk(3000, 32, 22, "bf16")
     q = rng.standard_normal(32).astype(np.float32)
-    assert len(st.vector_knn("embedding_2048", np.zeros(2048, np.float32), 5)) == 0
     with pytest.raises(m.CgvError, match="CGV_MAX_K"):
         st.search_similar(q, 2500)         # 2500 <= 3000 rows but > CGV_MAX_K = 2048
     assert len(st.search_similar(q, 2048)) == 2048
