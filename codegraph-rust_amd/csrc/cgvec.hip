@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -118,6 +119,17 @@ float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, i
     const double scale = (double)ld_coarse / 64.0 + 12.0;
     const double ref = metric == CGV_METRIC_COSINE_SEQ ? 2.0 * ld_exact + 4.0 : (double)ld_exact / 4.0 + 10.0;
     return (float)((mfma + scale + ref) * u * 1.0001);
+}
+
+// Query tiles per XCD (kernels_coarse.h block_to_work): the largest power of two that keeps their rows
+// (256 x ld x esize bytes each) within ~1.5 MiB of the XCD's 4 MiB L2, and divides nqt. CGV_QGROUP overrides.
+uint32_t query_group(uint32_t nqt, uint32_t ld, int dtype) {
+    static const int forced = getenv("CGV_QGROUP") ? atoi(getenv("CGV_QGROUP")) : -1;
+    if (forced >= 0) return (uint32_t)forced;
+    const size_t tile = (size_t)256 * ld * esize_of(dtype);
+    uint32_t g = 1;
+    while (g * 2 <= nqt && nqt % (g * 2) == 0 && (size_t)(g * 2) * tile <= (3u << 19)) g *= 2;
+    return g;
 }
 
 uint32_t kprime_of(uint32_t k) {
@@ -428,6 +440,7 @@ int ensure_kernel_attrs(int device) {
     CGV_ATTR((coarse_kernel<DT_FP8, true>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
+    CGV_ATTR((coarse_w4_kernel<DT_FP8, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
     CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
@@ -443,6 +456,32 @@ int ensure_kernel_attrs(int device) {
 #undef CGV_ATTR
     if (g_attr_done.size() <= (size_t)device) g_attr_done.resize((size_t)device + 1, 0);
     g_attr_done[device] = 1;
+    return CGV_OK;
+}
+
+// one wave per SIMD (kernels_coarse_w4.h); CGV_ABLATE_W4 = timing-only ablation masks of the bf16 instantiation
+template <int DT>
+int launch_coarse_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = COARSE_LDS_BYTES;
+    static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
+    if (abl4 && DT == DT_BF16) {
+#define CGV_ABLK4(N)                                                                                             \
+    case N: {                                                                                                    \
+        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
+        break;                                                                                                   \
+    }
+        switch (abl4) {
+            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(13)
+            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
+        }
+#undef CGV_ABLK4
+        HIPCHK(hipGetLastError());
+        return CGV_OK;
+    }
+    hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
     return CGV_OK;
 }
 
@@ -469,49 +508,12 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
         HIPCHK(hipGetLastError());
         return CGV_OK;
     }
-    // one-wave-per-SIMD variant (kernels_coarse_w4.h) for bf16 / fp16 searches with kc >= 4;
-    // CGV_COARSE=w8 keeps the 8-wave kernel for A/B timing
-    static const bool use_w4 = !(getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8"));
-    if (use_w4 && !DUMP && DT != DT_FP8 && a.kc >= 4) {
-        static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
-        if (abl4 && DT == DT_BF16) {
-#define CGV_ABLK4(N)                                                                                             \
-    case N: {                                                                                                    \
-        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
-        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
-        break;                                                                                                   \
-    }
-            switch (abl4) {
-                CGV_ABLK4(1) CGV_ABLK4(2) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(13) CGV_ABLK4(15) CGV_ABLK4(33) CGV_ABLK4(41) CGV_ABLK4(65) CGV_ABLK4(193)
-                default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
-            }
-#undef CGV_ABLK4
-            HIPCHK(hipGetLastError());
-            return CGV_OK;
-        }
-        static const int sched4 = getenv("CGV_W4_SCHED") ? atoi(getenv("CGV_W4_SCHED")) : 0;
-        if (sched4 && DT == DT_BF16) {  // timing experiments (SCHED 1..3 give the same results as 0)
-#define CGV_SCHK(N)                                                                                              \
-    case N: {                                                                                                    \
-        auto k2 = coarse_w4_kernel<DT_BF16, false, 0, N>;                                                        \
-        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
-        break;                                                                                                   \
-    }
-            switch (sched4) {
-                CGV_SCHK(1) CGV_SCHK(2) CGV_SCHK(3)
-                default: return fail(CGV_ERR_INVALID_ARG, "CGV_W4_SCHED: 1..3");
-            }
-#undef CGV_SCHK
-            HIPCHK(hipGetLastError());
-            return CGV_OK;
-        }
-        if constexpr (!DUMP && DT != DT_FP8) {
-            hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
-            HIPCHK(hipGetLastError());
-            return CGV_OK;
-        }
+    // CGV_COARSE=w4 selects the one-wave-per-SIMD variant (kernels_coarse_w4.h; kc >= 4) for bf16 / fp16 A/B
+    // timing: same results, measured equal to this 8-wave kernel on the main launch and slower on the hit-heavy
+    // stage-1 launch. (fp8 uses the one-wave-per-SIMD kernel by default: launch_coarse.)
+    static const bool use_w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
+    if constexpr (!DUMP && DT != DT_FP8) {
+        if (use_w4 && a.kc >= 4) return launch_coarse_w4<DT>(a, W, s);
     }
     hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
     HIPCHK(hipGetLastError());
@@ -537,6 +539,10 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
         // variant of the generic kernel (same results; kept for A/B timing)
         static const bool nonscaled = getenv("CGV_FP8_NONSCALED") && atoi(getenv("CGV_FP8_NONSCALED")) != 0;
         if (nonscaled) return dump ? launch_coarse_t<DT_FP8, true>(a, W, s) : launch_coarse_t<DT_FP8, false>(a, W, s);
+        // CGV_COARSE=w4: the one-wave-per-SIMD kernel (double-buffered K=64 fragments, zero-C tile starts; needs an
+        // even kc) for A/B timing - measured 16 % SLOWER than the 8-wave fp8 kernel on C5-mini
+        static const bool w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
+        if (!dump && w4 && a.kc >= 4 && (a.kc & 1u) == 0) return launch_coarse_w4<DT_FP8>(a, W, s);
         return dump ? launch_coarse_fp8s<true>(a, W, s) : launch_coarse_fp8s<false>(a, W, s);
     }
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
@@ -824,6 +830,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.P = p.P;
         a.nqt = nqt;
         a.metric = h->metric;
+        a.qgroup = query_group(nqt, a.ld, cdt);
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
         uint32_t last_nsplit = 0;
@@ -921,11 +928,32 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 // Wait for the batch enqueued on `c`, run the exact path for the queries whose guarantee check
 // failed (or for all of them on an f32 / forced-exact index), fold the statistics in.
 // Called WITHOUT h->mu (the context is owned by the caller); takes it for the statistics.
+// Wait for a stream: poll for up to CGV_SPIN_US microseconds (default 3000; 0 = never) before blocking. A
+// batch takes ~1.5 ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it.
+int wait_stream(hipStream_t s) {
+    static const long spin_us = getenv("CGV_SPIN_US") ? atol(getenv("CGV_SPIN_US")) : 3000;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return CGV_OK;
+            if (e != hipErrorNotReady) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
+                break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return CGV_OK;
+}
+
 int search_finish(cgv_index* h, SearchCtx* c) {
     hipStream_t s = c->stream;
     const uint32_t nq = c->nq, k = c->k;
     int rc;
-    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = wait_stream(s))) return rc;
     c->rewrote = false;
     if (c->h_flags[F_NONFINITE_Q])
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
@@ -1830,6 +1858,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.nsplit = nsplit;
     a.nqt = nqt;
     a.metric = h->metric;
+    a.qgroup = query_group(nqt, a.ld, cdt);
     if ((rc = launch_coarse(cdt, true, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;

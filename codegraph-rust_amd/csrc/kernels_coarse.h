@@ -90,7 +90,39 @@ struct CoarseArgs {
     float* dump;            // DUMP mode: dense [nq][n] coarse scores
     uint32_t n, nq, ld, kc;
     uint32_t T1, R, P, j0, cnt, nsplit, nqt, metric;
+    uint32_t qgroup;        // query tiles that share one XCD (block_to_work); 0 = all of them
 };
+
+// Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
+// used for speed only) and every XCD has its own 4 MiB L2. Two streams compete for it: the corpus split a
+// workgroup walks (shared by the workgroups of the same split, read once from HBM if they sit on one XCD)
+// and the query tile of each workgroup (256 x ld x esize bytes, re-read for every corpus tile). With 32 query
+// tiles (C5, B = 8192) the old mapping put all 32 query tiles of one split on an XCD: 32 x 192 KiB = 6 MiB of
+// query rows thrashed the L2 and every corpus tile re-fetched its query tile through the fabric (PMC, c5mini:
+// 66.7 GB per launch against 2 GB algorithmic, L2 hit rate 0.48). So an XCD now serves `qgroup` query tiles
+// (host: as many as keep the query rows under ~1.5 MiB) x W/8/qgroup corpus splits; the corpus is then streamed
+// nqt / qgroup times from HBM, which these MFMA-bound shapes can afford.
+// Returns g = split * nqt + qt, the logical id the candidate lists are addressed by.
+__device__ inline uint32_t block_to_work(const CoarseArgs& a, uint32_t& qt, uint32_t& split) {
+    const uint32_t W = gridDim.x, b = blockIdx.x;
+    uint32_t g = b;
+    if ((W & 7u) == 0) {
+        const uint32_t per = W >> 3, x = b & 7u, l = b >> 3;  // workgroups per XCD, XCD, index on it
+        const uint32_t G = a.qgroup ? a.qgroup : a.nqt;
+        const uint32_t NG = a.nqt / G;                         // query-tile groups
+        if (G * NG == a.nqt && per % G == 0 && NG <= 8 && (8 % NG) == 0) {
+            const uint32_t SP = per / G;                       // corpus splits per XCD
+            const uint32_t NB = 8 / NG;                        // XCDs per query-tile group
+            qt = (x / NB) * G + l % G;
+            split = (x % NB) * SP + l / G;
+            return split * a.nqt + qt;
+        }
+        g = x * per + l;  // contiguous logical ids per XCD
+    }
+    qt = g % a.nqt;
+    split = g / a.nqt;
+    return g;
+}
 
 // Order in which the corpus tiles beyond the boot tiles are visited: tile j of
 // the sequence is T1 + (j * P) mod R with P ~ 0.618 R coprime to R (a golden-ratio stride), so
@@ -230,12 +262,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware logical workgroup id: physical block b runs on XCD b % 8; give each XCD a
-    // contiguous range of logical ids so the nqt workgroups of one corpus split share an L2.
-    const uint32_t W = gridDim.x;
-    uint32_t g = blockIdx.x;
-    if ((W & 7u) == 0) g = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
-    const uint32_t qt = g % a.nqt, split = g / a.nqt;
+    uint32_t qt, split;
+    const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 
@@ -251,14 +279,16 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
     }
 
-    const uint32_t jlo = (uint32_t)(((uint64_t)split * a.cnt) / a.nsplit);
-    const uint32_t jhi = (uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit);
+    // uniform by construction; readfirstlane makes it provable (the 64-bit divisions run on the VALU and would
+    // otherwise leave `total` in a VGPR: every "is there a next stage" test became a vector compare)
+    const uint32_t jlo = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)split * a.cnt) / a.nsplit));
+    const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit));
     const uint32_t KC = a.kc;
     const uint32_t total = (jhi - jlo) * KC;  // pipeline stages of this workgroup
 
     // Tile sequence (stage_tile): t_{j+1} = t_j + P (mod R), kept incrementally on the issue side
     // (lt) and on the consume side (ct) - the 64-bit modulo is paid once per kernel, not per tile.
-    const uint32_t t_first = (total > 0) ? stage_tile(a.T1, a.R, a.P, a.j0 + jlo) - a.T1 : 0u;
+    const uint32_t t_first = __builtin_amdgcn_readfirstlane((total > 0) ? stage_tile(a.T1, a.R, a.P, a.j0 + jlo) - a.T1 : 0u);
     auto next_tile = [&](uint32_t t) {
         const uint32_t u = t + a.P;  // P < R <= 2^24 tiles: no overflow
         return u >= a.R ? u - a.R : u;
@@ -269,7 +299,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     const uint32_t slab = (uint32_t)wave * 2048u + (uint32_t)lane * 16u;
     const char* bq = a.qrows + (uint64_t)qt * KC * BLOCK_BYTES + slab;  // + kc * 16 KiB
     const char* atile = a.rows + slab;                                  // + (tile*KC + kc) * 16 KiB
-    uint32_t lj = 0, lkc = 0, issued = 0, lt = t_first;
+    uint32_t lkc = 0, issued = 0, lt = t_first;
     const char* acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
     // One stage = 4 DMA instructions per wave (A0 A1 B0 B1), issued one at a time so the caller
     // can spread them between MFMAs: a steady one-per-few-MFMAs stream instead of a burst that
@@ -286,44 +316,57 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)bbase, 0, 0x7fffffff, 0x00020000);
     const uint32_t voff = (uint32_t)lane * 16u;
-    auto bdma = [&](__amdgpu_buffer_rsrc_t rs, uint32_t soff, char* l) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
-    };
+    // (the 1-KiB second piece of a block shares M0 and the scalar offset with the first and steps by the
+    //  instruction's immediate offset, which applies to the global AND the LDS address)
+    uint32_t d_so = 0;
+    char* d_dst = smem;
+#define CGV_BDMA(RS, DST, IMM) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
     auto issue_q = [&](int q) {
         if (ABL & 2) {
             if (q == 3) ++issued;
             return;
         }
-        char* dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
         const uint64_t koff = (uint64_t)lkc * BLOCK_BYTES;
-        const uint32_t so = (uint32_t)koff + (uint32_t)wave * 2048u;
         if (q == 0) {
-            if (lkc == 0 && issued < total) {
-                if (wave == 0)  // the tile's 256 inverse norms ride along with its first stage
-                    glds16((const char*)a.invn_c + (uint64_t)(a.T1 + lt) * 1024 + lane * 16,
-                           (char*)(invn_s + (lj & (NINV - 1)) * 256));
-                if (wave == 1 && lane < 4) {  // and its 8 + 8 per-32-row-block norm bounds
-                    const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + lt) * 8 + (lane & 1) * 4;
-                    glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
-                }
-            }
-            if (BUFDMA) bdma(rsA, so, dst); else glds16(acur + koff, dst);
+            d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
+            d_so = (uint32_t)koff + (uint32_t)wave * 2048u;
+            if (BUFDMA) CGV_BDMA(rsA, d_dst, 0); else glds16(acur + koff, d_dst);
         } else if (q == 1) {
-            if (BUFDMA) bdma(rsA, so + 1024, dst + 1024); else glds16(acur + koff + 1024, dst + 1024);
+            if (BUFDMA) CGV_BDMA(rsA, d_dst, 1024); else glds16(acur + koff + 1024, d_dst + 1024);
         } else if (q == 2) {
-            if (BUFDMA) bdma(rsB, so, dst + A_BYTES); else glds16(bq + koff, dst + A_BYTES);
+            if (BUFDMA) CGV_BDMA(rsB, d_dst + A_BYTES, 0); else glds16(bq + koff, d_dst + A_BYTES);
         } else {
-            if (BUFDMA) bdma(rsB, so + 1024, dst + A_BYTES + 1024); else glds16(bq + koff + 1024, dst + A_BYTES + 1024);
+            if (BUFDMA) CGV_BDMA(rsB, d_dst + A_BYTES, 1024); else glds16(bq + koff + 1024, d_dst + A_BYTES + 1024);
             ++issued;
             if (issued < total && ++lkc == KC) {
                 lkc = 0;
-                ++lj;
                 lt = next_tile(lt);
                 acur = atile + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES;
                 if (BUFDMA)
                     rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0,
                                                             0x7fffffff, 0x00020000);
             }
+        }
+    };
+    // Side data of the tile with sequence number seq (absolute tile T1 + tt): its 256 inverse norms (wave 0) and
+    // 8 + 8 per-32-row-block norm bounds (4 lanes of wave 1), issued in the straight-line tile-boundary block
+    // where the tile STARTS: the stage loop has no branch besides its back edge. The tile's epilogue runs KC
+    // stages later; with KC >= 3 the counted vmcnt(8) of its last stage covers these (>= 8 younger DMA
+    // instructions behind them), shorter tiles wait explicitly (side_wait).
+    auto issue_side = [&](uint32_t tt, uint32_t seq) {
+        if (ABL & 2) return;
+        if (wave == 0)
+            glds16((const char*)a.invn_c + (uint64_t)(a.T1 + tt) * 1024 + lane * 16, (char*)(invn_s + (seq & (NINV - 1)) * 256));
+        if (wave == 1 && lane < 4) {
+            const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + tt) * 8 + (lane & 1) * 4;
+            glds16((const char*)sp, (char*)(stat_s + (seq & (NINV - 1)) * 16));
+        }
+    };
+    auto side_wait = [&]() {  // uniform: short tiles only (D <= 64 elements per 64-byte chunk x 2)
+        if (KC < 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     };
 
@@ -351,49 +394,65 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int i = 0; i < MB; ++i) fa0[i] = fa1[i] = (frag)0;
         for (int i = 0; i < NB; ++i) fb0[i] = fb1[i] = (frag)0;
     }
+#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
+#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
 #define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                         \
     {                                                                                            \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) FA[mb] =                               \
-            *(const frag*)((BASE) + aoff + mb * 32 * 64 + xo[KK]);                               \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) FB[nb] =                               \
-            *(const frag*)((BASE) + boff + nb * 32 * 64 + xo[KK]);                               \
+        CGV_LDA(FA, 0, BASE, KK) CGV_LDA(FA, 1, BASE, KK) CGV_LDA(FA, 2, BASE, KK) CGV_LDA(FA, 3, BASE, KK) \
+        CGV_LDB(FB, 0, BASE, KK) CGV_LDB(FB, 1, BASE, KK)                                        \
     }
-#define CGV_SB __builtin_amdgcn_sched_barrier(0)
-// the 8 MFMAs of one k-step in four groups (1 + 3 + 2 + 2) so that fragment loads and DMA issue
-// can be pinned between them
-#define CGV_MMA_G0(FA, FB) \
-    { acc[0][0] = Mfma<DT>::mma(FA[0], FB[0], acc[0][0]); }
-#define CGV_MMA_G1(FA, FB)                                      \
-    {                                                           \
-        acc[0][1] = Mfma<DT>::mma(FA[0], FB[1], acc[0][1]);     \
-        acc[1][0] = Mfma<DT>::mma(FA[1], FB[0], acc[1][0]);     \
-        acc[1][1] = Mfma<DT>::mma(FA[1], FB[1], acc[1][1]);     \
+#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
+    // first k-step of a tile: C operand = 0 (an inline constant in the MFMA encoding) instead of clearing 128
+    // accumulator registers per tile. These run in their own straight-line block at every tile boundary (never as
+    // a branch inside the stage loop: that made the register allocator copy the accumulators around phis).
+#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], zero16);
+    // Program-order pins. An MFMA is a pure register operation: instruction selection places it anywhere its
+    // operands allow, sched_barrier or not (one build of this kernel had the phase's first MFMA sunk below the
+    // fragment reads, so its lgkmcnt(0) waited for the reads just issued). An empty asm that consumes a result
+    // (the MFMA writing it comes before this point) or redefines an operand (the MFMAs reading it come after
+    // this point) ties them to the chain of side-effecting instructions (LDS reads, DMA, barrier, waits:
+    // "memory"), which keeps its order. One gap = what is issued between MFMA (MBI, NBI) and the next one.
+#define CGV_GAP(MBI, NBI, NEXT_OPERAND, ACTION)                        \
+    asm volatile("" : "+v"(acc[MBI][NBI])::"memory");                  \
+    ACTION;                                                            \
+    asm volatile("" : "+v"(NEXT_OPERAND)::"memory");
+#define CGV_NOP_ACTION
+    // One k-step: 8 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from LDS
+    // stage NBASE, k-step NKK; Q0, Q0+1 = the DMA pieces issued here; FIRST = what follows the first MFMA (the
+    // stage's counted wait + barrier in a B phase: by then every wave has all its reads of the previous stage
+    // back, so its slot may be overwritten by the DMA of stage s+3, and has waited for its own share of stage s).
+    // The 6 fragment reads go right behind the first MFMA (hipcc waits lgkmcnt(0), so they get 7 MFMAs to land;
+    // the partner wave of the SIMD covers their issue), a DMA piece behind MFMAs 4 and 6. (One read per gap
+    // measured the same: 1.003 vs 1.004 ms on the C2 main launch; giving the two waves of a SIMD different DMA
+    // gaps - waves 0-3 early, 4-7 late in the k-step - measured 4-8 % SLOWER: DESIGN.md §9.)
+#define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                   \
+    {                                                                                                            \
+        MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LOAD_FRAGS(NA, NB_, NBASE, NKK))                       \
+        MMA(0, 1, FA, FB) CGV_GAP(0, 1, FA[1], CGV_NOP_ACTION)                                                   \
+        MMA(1, 0, FA, FB) CGV_GAP(1, 0, FB[1], CGV_NOP_ACTION)                                                   \
+        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FA[2], issue_q(Q0))                                                      \
+        MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_NOP_ACTION)                                                   \
+        MMA(2, 1, FA, FB) CGV_GAP(2, 1, FA[3], issue_q(Q0 + 1))                                                  \
+        MMA(3, 0, FA, FB) CGV_GAP(3, 0, FB[1], CGV_NOP_ACTION)                                                   \
+        MMA(3, 1, FA, FB) CGV_GAP(3, 1, NA[0], CGV_NOP_ACTION)                                                   \
     }
-#define CGV_MMA_G2(FA, FB)                                      \
-    {                                                           \
-        acc[2][0] = Mfma<DT>::mma(FA[2], FB[0], acc[2][0]);     \
-        acc[2][1] = Mfma<DT>::mma(FA[2], FB[1], acc[2][1]);     \
-    }
-#define CGV_MMA_G3(FA, FB)                                      \
-    {                                                           \
-        acc[3][0] = Mfma<DT>::mma(FA[3], FB[0], acc[3][0]);     \
-        acc[3][1] = Mfma<DT>::mma(FA[3], FB[1], acc[3][1]);     \
-    }
-// first k-step of a tile: C operand = 0 (an inline constant in the MFMA encoding) instead of clearing
-// 128 accumulator registers per tile. These run in their own straight-line block at every tile
-// boundary (never as a branch inside the stage loop: that made the register allocator copy the
-// accumulators around phis).
-#define CGV_MMA_Z(FA, FB, GLO, GHI)                                                              \
-    {                                                                                            \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) \
-            if (mb * NB + nb >= GLO && mb * NB + nb < GHI) acc[mb][nb] = Mfma<DT>::mma(FA[mb], FB[nb], zero16);    \
-    }
+#define CGV_STAGE_SYNC                                                      \
+    if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
+    // Stage s holds k-steps (s,0) [fragments fa0/fb0] and (s,1) [fa1/fb1]. Iteration s runs the B phase =
+    // k-step (s-1,1) with the stage barrier behind its first MFMA, then the A phase = k-step (s,0). DMA lead:
+    // 3 stages (the 8 younger DMA instructions at the counted wait are stages s+1, s+2). No MFMA sits inside a
+    // branch of a loop body (no accumulator phis for the register allocator to copy around).
+#define CGV_A_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
+#define CGV_A_PHASE_Z(SB_) CGV_KSTEP(CGV_MMAZ, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
+#define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
 
     // ---- prologue: three stages in flight --------------------------------------------
     if (total == 0) {  // uniform: nothing to stream for this workgroup
         for (int i = tid; i < BN; i += NT) a.cand_cnt[(uint64_t)g * BN + i] = 0;
         return;
     }
+    issue_side(t_first, 0);
 #pragma unroll 1
     for (int i = 0; i < NSTAGE - 1; ++i) {
         issue_q(0);
@@ -401,75 +460,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         issue_q(2);
         issue_q(3);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // stage 0 landed; stages 1, 2 may be in flight
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // stage 0 (and the side data before it) landed; stages 1, 2 may be in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
     __builtin_amdgcn_s_barrier();
     CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
 
-    // Stage s holds k-steps (s,0) [fragments fa0/fb0] and (s,1) [fa1/fb1]. Iteration s runs the
-    // MFMAs of (s-1,1) then of (s,0); the single barrier of the iteration sits after the first MFMA
-    // of (s-1,1): by then every wave has all its reads of stage s-1 back (lgkmcnt(0) in front of
-    // that MFMA), so slot (s-1)&3 is free for the DMA of stage s+3, and each wave has waited for
-    // its own share of stage s (counted vmcnt: the 8 younger DMA instructions are stages s+1,
-    // s+2), so stage s may be read. DMA lead: 3 stages. No MFMA sits inside a branch of a loop body
-    // (no accumulator phis for the register allocator to copy around).
-#define CGV_A_PHASE(SB)                      \
-    {                                        \
-        CGV_SB;                              \
-        CGV_MMA_G0(fa0, fb0);                \
-        CGV_SB;                              \
-        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa1, fb1, SB, 1); \
-        CGV_SB;                              \
-        CGV_MMA_G1(fa0, fb0);                \
-        CGV_SB;                              \
-        issue_q(2);                          \
-        CGV_SB;                              \
-        CGV_MMA_G2(fa0, fb0);                \
-        CGV_SB;                              \
-        issue_q(3);                          \
-        CGV_SB;                              \
-        CGV_MMA_G3(fa0, fb0);                \
-        CGV_SB;                              \
-    }
-#define CGV_A_PHASE_Z(SB)                                \
-    {                                                    \
-        CGV_SB;                                          \
-        CGV_MMA_Z(fa0, fb0, 0, 1);                       \
-        CGV_SB;                                          \
-        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa1, fb1, SB, 1); \
-        CGV_SB;                                          \
-        CGV_MMA_Z(fa0, fb0, 1, 4);                       \
-        CGV_SB;                                          \
-        issue_q(2);                                      \
-        CGV_SB;                                          \
-        CGV_MMA_Z(fa0, fb0, 4, 6);                       \
-        CGV_SB;                                          \
-        issue_q(3);                                      \
-        CGV_SB;                                          \
-        CGV_MMA_Z(fa0, fb0, 6, 8);                       \
-        CGV_SB;                                          \
-    }
-#define CGV_B_PHASE(SB)                                                        \
-    {                                                                          \
-        CGV_SB;                                                                \
-        CGV_MMA_G0(fa1, fb1);                                                  \
-        CGV_SB;                                                                \
-        if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
-        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                          \
-        CGV_SB;                                                                \
-        if (!(ABL & 8)) CGV_LOAD_FRAGS(fa0, fb0, SB, 0);                       \
-        CGV_SB;                                                                \
-        CGV_MMA_G1(fa1, fb1);                                                  \
-        CGV_SB;                                                                \
-        issue_q(0);                                                            \
-        CGV_SB;                                                                \
-        CGV_MMA_G2(fa1, fb1);                                                  \
-        CGV_SB;                                                                \
-        issue_q(1);                                                            \
-        CGV_SB;                                                                \
-        CGV_MMA_G3(fa1, fb1);                                                  \
-        CGV_SB;                                                                \
-    }
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1))                                                                                                \
         tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
@@ -494,8 +489,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
             CGV_B_PHASE(sb);
+            const uint32_t nt = next_tile(ct);
+            side_wait();
             CGV_EPILOGUE(a.T1 + ct, tl - 1);
-            ct = next_tile(ct);
+            issue_side(nt, tl);  // the tile that starts here
+            ct = nt;
             CGV_A_PHASE_Z(sb);
             ++s;
         }
@@ -507,25 +505,27 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         }
     }
     // tail: second k-step of the last stage, then the last tile's epilogue
-    CGV_SB;
-    CGV_MMA_G0(fa1, fb1);
-    CGV_MMA_G1(fa1, fb1);
-    CGV_MMA_G2(fa1, fb1);
-    CGV_MMA_G3(fa1, fb1);
-    CGV_SB;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
+    __builtin_amdgcn_s_barrier();
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail before the LDS is released
 #undef CGV_A_PHASE_Z
 #undef CGV_B_PHASE
-#undef CGV_MMA_Z
 #undef CGV_A_PHASE
 #undef CGV_EPILOGUE
-#undef CGV_SB
-#undef CGV_MMA_G0
-#undef CGV_MMA_G1
-#undef CGV_MMA_G2
-#undef CGV_MMA_G3
+#undef CGV_STAGE_SYNC
+#undef CGV_KSTEP
+#undef CGV_NOP_ACTION
+#undef CGV_GAP
+#undef CGV_MMAZ
+#undef CGV_MMA
 #undef CGV_LOAD_FRAGS
+#undef CGV_LDA
+#undef CGV_LDB
+#undef CGV_BDMA
 
     __syncthreads();
     for (int i = tid; i < BN; i += NT) {

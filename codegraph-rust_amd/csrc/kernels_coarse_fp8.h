@@ -45,10 +45,8 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const uint32_t W = gridDim.x;
-    uint32_t g = blockIdx.x;
-    if ((W & 7u) == 0) g = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
-    const uint32_t qt = g % a.nqt, split = g / a.nqt;
+    uint32_t qt, split;
+    const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 

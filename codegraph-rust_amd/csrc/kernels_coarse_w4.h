@@ -1,33 +1,59 @@
 // kernels_coarse_w4.h — the coarse kernel as ONE WAVE PER SIMD: 4 waves per workgroup, each owning a
-// 128 x 128 output tile (4 x 4 blocks of v_mfma_f32_32x32x16) of the same 256 x 256 workgroup tile, with
-// the 256 accumulator registers in the accumulator half of the 512-entry register file.
+// 128 x 128 output tile (4 x 4 blocks of 32x32 MFMA) of the same 256 x 256 workgroup tile, the 256
+// accumulator registers in the accumulator half (AGPRs) of the 512-entry register file.
 //
-// Why (VERDICT r1 'next' 5(iii); measurements in DESIGN.md §9): with two 128 x 64 waves per SIMD the
+// Why (VERDICT r1 'next' 5(iii) / 8; measurements in DESIGN.md §9): with two 128 x 64 waves per SIMD the
 // kernel issues 6 ds_read_b128 per 8 MFMAs and both waves of a SIMD compete for its matrix pipe; with one
-// 128 x 128 wave it is 8 reads per 16 MFMAs, nobody to compete with, and every MFMA gap (32 cycles) has
-// room for the ~2 other instructions the stage needs per MFMA (8 DMA pieces, 16 fragment reads, one
-// barrier, a dozen scalar ops per 32 MFMAs).
-// Everything else is the 8-wave kernel's design (kernels_coarse.h): B32 blocked operands, 4-stage LDS ring
+// 128 x 128 wave it is 8 reads per 16 MFMAs and the arch VGPR half has room for fully double-buffered
+// fragments even for fp8 (K = 64 per instruction: 8 VGPRs per operand block), which the 8-wave fp8 kernel
+// could not afford (single-buffered A halves, accumulators cleared per tile instead of zero-C MFMAs).
+// Everything else is the 8-wave kernel's design (kernels_coarse.h): B32 blocked operands, 4-slot LDS ring
 // filled by buffer_load ... lds three stages ahead and retired by a counted vmcnt, one barrier per stage,
 // tile-structured loop with zero-C MFMAs at the tile boundary, the fused threshold top-k' epilogue
-// (tile_epilogue), XCD-aware workgroup mapping. Differences:
+// (tile_epilogue), XCD-aware workgroup mapping (block_to_work). Differences:
 //   * a wave copies 4 KiB of the A block and 4 KiB of the B block per stage: 8 DMA instructions, the four of
 //     a block sharing one M0 / scalar offset and stepping by the instruction's immediate offset (1 KiB);
-//   * the per-tile side data (inverse norms, block bounds) is issued in the straight-line tile-boundary
-//     block for the tile that STARTS there (needs kc >= 3: the host uses this kernel for kc >= 4), so the
-//     stage loop contains no branch except its back edge.
+//   * with ONE wave on the SIMD nothing covers an issue stall, so everything is placed: the fragment reads of
+//     the next k-step go one (bf16/fp16) or two (fp8) per MFMA gap behind the first 8 MFMAs, the DMA pieces
+//     behind the last 8 (8 reads back to back cost 0.33 ms of 1.08 on the C2 main launch);
+//   * the per-tile side data (inverse norms, block bounds) is issued in the straight-line tile-boundary block
+//     for the tile that STARTS there, so the stage loop has no branch besides its back edge.
+// bf16 / fp16: a 64-byte stage is two K=16 k-steps (A phase, B phase). fp8: a stage is ONE K=64 k-step, so
+// both phases of the loop body are whole stages with their own barrier (needs an even kc; the host falls back
+// to the 8-wave kernels for kc < 4 or odd fp8 kc).
+// Measured on C2: equal to the 8-wave kernel on the main launch, slower on the hit-heavy
+// stage-1 launch (its epilogue - 256 v_accvgpr_read + the max tree per tile - has no partner wave to hide
+// behind), so bf16 / fp16 searches keep the 8-wave kernel by default; fp8 uses this one.
 #pragma once
 #include "kernels_coarse.h"
+#include "kernels_coarse_fp8.h"
 
 namespace cgv {
 
-template <int DT, bool DUMP, int ABL = 0, int SCHED = 0>
+template <int DT>
+struct W4Ops {
+    typedef typename Mfma<DT>::frag frag;
+    static constexpr bool F8 = false;
+    static __device__ inline f32x16_t mma(const frag& a, const frag& b, f32x16_t c) { return Mfma<DT>::mma(a, b, c); }
+};
+template <>
+struct W4Ops<DT_FP8> {
+    typedef Fp8Frag frag;
+    static constexpr bool F8 = true;
+    static __device__ inline f32x16_t mma(const frag& a, const frag& b, f32x16_t c) { return mma_fp8_k64(a, b, c); }
+};
+
+// ABL: timing-only ablation mask (results are WRONG for ABL != 0; CGV_ABLATE_W4): 1 = skip the epilogue,
+// 2 = skip the DMA, 4 = skip the barrier, 8 = read the fragments once (real data) and never again,
+// 16 = skip the counted vmcnt wait.
+template <int DT, bool DUMP, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void coarse_w4_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 2, NT = 256;
     constexpr int WTM = 128, WTN = 128, MB = 4, NB = 4;
     constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
     constexpr int NSTAGE = 4, NINV = 8;
-    typedef typename Mfma<DT>::frag frag;
+    constexpr bool F8 = W4Ops<DT>::F8;
+    typedef typename W4Ops<DT>::frag frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
@@ -39,10 +65,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const uint32_t W = gridDim.x;
-    uint32_t g = blockIdx.x;
-    if ((W & 7u) == 0) g = (blockIdx.x & 7u) * (W >> 3) + (blockIdx.x >> 3);
-    const uint32_t qt = g % a.nqt, split = g / a.nqt;
+    uint32_t qt, split;
+    const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 
@@ -62,6 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t jlo = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)split * a.cnt) / a.nsplit));
     const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit));
     const uint32_t KC = a.kc;
+    const uint32_t UNITS = F8 ? KC / 2 : KC;  // loop bodies (two k-steps each) per tile
     const uint32_t total = (jhi - jlo) * KC;  // pipeline stages of this workgroup
     const uint32_t ntl = jhi - jlo;
     if (total == 0) {  // uniform: nothing to stream for this workgroup
@@ -76,64 +101,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- DMA issue side: three stages ahead of the consume side --------------------------------------
+    constexpr int RS_FLAGS = 0x00020000;
+    const uint32_t voff = (uint32_t)lane * 16u;
     uint32_t lkc = 0, issued = 0, lt = t_first;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0,
-                                                                   0x7fffffff, 0x00020000);
+                                                                   0x7fffffff, RS_FLAGS);
     const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.qrows + (uint64_t)qt * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000);
-    const uint32_t voff = (uint32_t)lane * 16u;
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t stg[8];           // ABL & 64 only
-    if (ABL & 64)
-        for (int i = 0; i < 8; ++i) stg[i] = (u32x4_t)0;
-    uint32_t d_so = 0;        // scalar offset of the stage being issued (chunk * 16 KiB + wave * 4 KiB)
-    char* d_dst = smem;       // LDS base of this wave's share of it
-    // timing-only forms: ABL & 32: 4-byte pieces (same instruction count, a quarter of the bytes);
-    // ABL & 64: an ordinary buffer_load to VGPRs instead of the LDS-DMA, consumed one stage later by a
-    // register use (or, with ABL & 128, by a ds_write_b128 to the piece's LDS slot = register staging)
-#define CGV_DMA(RS, DST, IMM, Q)                                                                                     \
-    {                                                                                                                \
-        if (ABL & 64) {                                                                                              \
-            if (ABL & 128)                                                                                           \
-                *(u32x4_t*)((DST) + (IMM) + lane * 16) = stg[Q];                                                     \
-            else                                                                                                     \
-                asm volatile("" ::"v"(stg[Q]));                                                                      \
-            stg[Q] = __builtin_amdgcn_raw_buffer_load_b128(RS, voff + (IMM), d_so, 0);                               \
-        } else if (ABL & 32)                                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 4, voff, d_so, IMM, 0); \
-        else                                                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0); \
-    }
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.qrows + (uint64_t)qt * KC * BLOCK_BYTES), 0, 0x7fffffff, RS_FLAGS);
+    uint32_t d_so = 0;   // scalar offset of the stage being issued (chunk * 16 KiB + wave * 4 KiB)
+    char* d_dst = smem;  // LDS base of this wave's share of it
+#define CGV_DMA(RS, DST, IMM) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
     // piece Q of the stage: 0..3 = KiB 0..3 of this wave's share of the A block, 4..7 = of the B block
 #define CGV_ISSUE(Q)                                                                                     \
     {                                                                                                    \
         if (!(ABL & 2)) {                                                                                \
-            if (Q == 0) {                                                                                \
+            if ((Q) == 0) {                                                                              \
                 d_so = lkc * BLOCK_BYTES + (uint32_t)wave * 4096u;                                       \
                 d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 4096;                            \
             }                                                                                            \
-            if (Q == 0) CGV_DMA(rsA, d_dst, 0, 0);                                                          \
-            if (Q == 1) CGV_DMA(rsA, d_dst, 1024, 1);                                                       \
-            if (Q == 2) CGV_DMA(rsA, d_dst, 2048, 2);                                                       \
-            if (Q == 3) CGV_DMA(rsA, d_dst, 3072, 3);                                                       \
-            if (Q == 4) CGV_DMA(rsB, d_dst + A_BYTES, 0, 4);                                                \
-            if (Q == 5) CGV_DMA(rsB, d_dst + A_BYTES, 1024, 5);                                             \
-            if (Q == 6) CGV_DMA(rsB, d_dst + A_BYTES, 2048, 6);                                             \
-            if (Q == 7) CGV_DMA(rsB, d_dst + A_BYTES, 3072, 7);                                             \
+            if ((Q) == 0) CGV_DMA(rsA, d_dst, 0);                                                        \
+            if ((Q) == 1) CGV_DMA(rsA, d_dst, 1024);                                                     \
+            if ((Q) == 2) CGV_DMA(rsA, d_dst, 2048);                                                     \
+            if ((Q) == 3) CGV_DMA(rsA, d_dst, 3072);                                                     \
+            if ((Q) == 4) CGV_DMA(rsB, d_dst + A_BYTES, 0);                                              \
+            if ((Q) == 5) CGV_DMA(rsB, d_dst + A_BYTES, 1024);                                           \
+            if ((Q) == 6) CGV_DMA(rsB, d_dst + A_BYTES, 2048);                                           \
+            if ((Q) == 7) CGV_DMA(rsB, d_dst + A_BYTES, 3072);                                           \
         }                                                                                                \
-        if (Q == 7) {                                                                                    \
+        if ((Q) == 7) {                                                                                  \
             ++issued;                                                                                    \
             /* the stream never ends: past the last stage it re-reads the last one into the free slot */ \
             if (issued < total && ++lkc == KC) {                                                         \
                 lkc = 0;                                                                                 \
                 lt = next_tile(lt);                                                                      \
                 rsA = __builtin_amdgcn_make_buffer_rsrc(                                                 \
-                    (void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff, 0x00020000); \
+                    (void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff, RS_FLAGS); \
             }                                                                                            \
         }                                                                                                \
     }
-    // side data of the tile with sequence number SEQ (absolute tile T1 + TT): 256 inverse norms by wave 0,
-    // 8 + 8 block norm bounds by 4 lanes of wave 1. Issued at the tile boundary where the tile starts.
+    // side data of the tile with sequence number seq (absolute tile T1 + tt): 256 inverse norms by wave 0,
+    // 8 + 8 block norm bounds by 4 lanes of wave 1. Issued at the tile boundary where the tile starts; its
+    // epilogue runs >= 3 stages later, behind a counted wait that leaves fewer DMA instructions in flight
+    // than were issued after these (bf16: 4 + 8 (KC - 1) >= 16 for KC >= 3; fp8: 8 >= 8).
     auto issue_side = [&](uint32_t tt, uint32_t seq) {
         if (ABL & 2) return;
         if (wave == 0)
@@ -144,11 +154,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    // fragment read offsets (bytes): row r = base32 + (lane&31); the lane's piece of k-step kk is
-    // c = 2*kk + (lane>>5), stored at slot c ^ ((r>>2)&3)
+    // fragment read offsets (bytes): row r = base32 + (lane&31). bf16/fp16: the lane's piece of k-step kk is
+    // c = 2*kk + (lane>>5); fp8: its 32 bytes are pieces 2h, 2h+1 (h = lane>>5). Piece c sits at slot c ^ ((r>>2)&3).
+    const uint32_t key = (uint32_t)(lane >> 2) & 3u, hh = (uint32_t)(lane >> 5);
     uint32_t xo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) xo[kk] = (uint32_t)((((2 * kk + (lane >> 5)) ^ ((lane >> 2) & 3))) << 4);
+    if (F8) {
+        xo[0] = ((2 * hh) ^ key) << 4;
+        xo[1] = ((2 * hh + 1) ^ key) << 4;
+    } else {
+        xo[0] = (hh ^ key) << 4;
+        xo[1] = ((2 + hh) ^ key) << 4;
+    }
     const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 64;
     const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 64;
 
@@ -162,51 +178,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16;
 
     frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
-#define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                                   \
-    if (!(ABL & 8)) {                                                                                      \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) FA[mb] = *(const frag*)((BASE) + aoff + mb * 2048 + xo[KK]); \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) FB[nb] = *(const frag*)((BASE) + boff + nb * 2048 + xo[KK]); \
+    // one fragment = one ds_read_b128 (bf16/fp16: piece xo[KK] of the stage) or two (fp8: both pieces)
+#define CGV_LDF(F, ADDR, KK)                                                       \
+    {                                                                              \
+        if constexpr (F8) {                                                        \
+            (F).p0 = *(const i32x4_t*)((ADDR) + xo[0]);                            \
+            (F).p1 = *(const i32x4_t*)((ADDR) + xo[1]);                            \
+        } else {                                                                   \
+            (F) = *(const frag*)((ADDR) + xo[KK]);                                 \
+        }                                                                          \
     }
-#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
-#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
-#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
-#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], zero16);
+#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) CGV_LDF(FA[I], (BASE) + aoff + (I) * 2048, KK)
+#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) CGV_LDF(FB[I], (BASE) + boff + (I) * 2048, KK)
+#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = W4Ops<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
+#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = W4Ops<DT>::mma(FA[MBI], FB[NBI], zero16);
     // Program-order pins. An MFMA is a pure register operation: instruction selection is free to place it
     // anywhere its operands allow, sched_barrier or not (the first build of this kernel had the phase's first
     // MFMA sunk below the fragment reads, so its lgkmcnt(0) waited for the reads just issued). An empty asm
     // that consumes a result (the MFMA writing it comes before this point) or redefines an operand (the MFMAs
     // reading it come after this point) ties them to the chain of side-effecting instructions (LDS reads,
-    // DMA, barrier, waits: "memory"), which keeps its order.
-    // One gap = what is issued between MFMA (MBI, NBI) and the next one: with ONE wave on the SIMD nothing
-    // else covers an issue stall, so the 8 fragment reads of the next k-step go one per gap behind the first
-    // 8 MFMAs and the 4 DMA pieces one per two gaps behind the last 8 (8 reads back to back measured 0.33 ms
-    // of 1.08 on the C2 main launch: the matrix pipe drains while they issue).
+    // DMA, barrier, waits: "memory"), which keeps its order. One gap = what is issued between MFMA (MBI, NBI)
+    // and the next one.
+#define CGV_PIN_OPERAND(X)                                  \
+    {                                                       \
+        if constexpr (F8)                                   \
+            asm volatile("" : "+v"((X).p0)::"memory");      \
+        else                                                \
+            asm volatile("" : "+v"(X)::"memory");           \
+    }
+    // all 8 fragments of the k-step named at its start: hipcc places its (single) lgkmcnt wait for them HERE,
+    // where they were issued a whole k-step ago, instead of in front of their first use in the middle of the
+    // phase, where it would also wait for the reads just issued
+#define CGV_PIN_ALL(FA, FB)                                                                                          \
+    {                                                                                                                \
+        if constexpr (F8)                                                                                            \
+            asm volatile("" : "+v"(FA[0].p0), "+v"(FA[0].p1), "+v"(FA[1].p0), "+v"(FA[1].p1), "+v"(FA[2].p0),        \
+                              "+v"(FA[2].p1), "+v"(FA[3].p0), "+v"(FA[3].p1), "+v"(FB[0].p0), "+v"(FB[0].p1),        \
+                              "+v"(FB[1].p0), "+v"(FB[1].p1), "+v"(FB[2].p0), "+v"(FB[2].p1), "+v"(FB[3].p0),        \
+                              "+v"(FB[3].p1)::"memory");                                                             \
+        else                                                                                                         \
+            asm volatile("" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]),          \
+                              "+v"(FB[2]), "+v"(FB[3])::"memory");                                                   \
+    }
 #define CGV_GAP(MBI, NBI, NEXT_OPERAND, ACTION)                        \
     asm volatile("" : "+a"(acc[MBI][NBI])::"memory");                  \
     ACTION;                                                            \
-    asm volatile("" : "+v"(NEXT_OPERAND)::"memory");
+    CGV_PIN_OPERAND(NEXT_OPERAND)
 #define CGV_NOP_ACTION
-    // One k-step: 16 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from
-    // LDS stage NBASE, k-step NKK; Q0.. = the DMA pieces issued here; FIRST = what follows the first MFMA
-    // (the stage's wait + barrier in a B phase).
-    // SCHED (timing experiments): where the 4 DMA pieces of a k-step go. 0: gaps 10, 12, 14, 16; 1: all in gap 16;
-    // 2: two in gap 12, two in gap 16; 3: all 8 of the stage right behind the stage barrier.
-#define CGV_DMAS(G, Q0)                                                                       \
-    {                                                                                         \
-        if (SCHED == 0) {                                                                     \
-            if (G == 10) CGV_ISSUE(Q0);                                                       \
-            if (G == 12) CGV_ISSUE(Q0 + 1);                                                   \
-            if (G == 14) CGV_ISSUE(Q0 + 2);                                                   \
-            if (G == 16) CGV_ISSUE(Q0 + 3);                                                   \
-        } else if (SCHED == 1) {                                                              \
-            if (G == 16) { CGV_ISSUE(Q0); CGV_ISSUE(Q0 + 1); CGV_ISSUE(Q0 + 2); CGV_ISSUE(Q0 + 3); } \
-        } else if (SCHED == 2) {                                                              \
-            if (G == 12) { CGV_ISSUE(Q0); CGV_ISSUE(Q0 + 1); }                                \
-            if (G == 16) { CGV_ISSUE(Q0 + 2); CGV_ISSUE(Q0 + 3); }                            \
-        }                                                                                     \
+    // the DMA pieces of a k-step, by gap: bf16/fp16 = 4 pieces (Q0..Q0+3) in gaps 10, 12, 14, 16; fp8 = the whole
+    // stage (8 pieces) in gaps 9..16
+#define CGV_DMAS(G, Q0)                                                       \
+    {                                                                         \
+        if constexpr (F8) {                                                   \
+            CGV_ISSUE((G)-9);                                                 \
+        } else {                                                              \
+            if ((G) == 10) CGV_ISSUE(Q0);                                     \
+            if ((G) == 12) CGV_ISSUE((Q0) + 1);                               \
+            if ((G) == 14) CGV_ISSUE((Q0) + 2);                               \
+            if ((G) == 16) CGV_ISSUE((Q0) + 3);                               \
+        }                                                                     \
     }
+    // One k-step: 16 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from
+    // LDS stage NBASE (bf16/fp16: its k-step NKK); FIRST = what follows the first MFMA (the stage's counted
+    // wait + barrier when the next k-step starts a new stage).
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                \
     {                                                                                         \
+        CGV_PIN_ALL(FA, FB)                                                                   \
         MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LDA(NA, 0, NBASE, NKK))             \
         MMA(0, 1, FA, FB) CGV_GAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK))                   \
         MMA(0, 2, FA, FB) CGV_GAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK))                   \
@@ -215,28 +252,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[2], CGV_LDA(NA, 1, NBASE, NKK))                    \
         MMA(1, 2, FA, FB) CGV_GAP(1, 2, FB[3], CGV_LDA(NA, 2, NBASE, NKK))                    \
         MMA(1, 3, FA, FB) CGV_GAP(1, 3, FA[2], CGV_LDA(NA, 3, NBASE, NKK))                    \
-        MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_NOP_ACTION)                                \
+        MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_DMAS(9, Q0))                               \
         MMA(2, 1, FA, FB) CGV_GAP(2, 1, FB[2], CGV_DMAS(10, Q0))                              \
-        MMA(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_NOP_ACTION)                                \
+        MMA(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_DMAS(11, Q0))                              \
         MMA(2, 3, FA, FB) CGV_GAP(2, 3, FA[3], CGV_DMAS(12, Q0))                              \
-        MMA(3, 0, FA, FB) CGV_GAP(3, 0, FB[1], CGV_NOP_ACTION)                                \
+        MMA(3, 0, FA, FB) CGV_GAP(3, 0, FB[1], CGV_DMAS(13, Q0))                              \
         MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[2], CGV_DMAS(14, Q0))                              \
-        MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_NOP_ACTION)                                \
+        MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_DMAS(15, Q0))                              \
         MMA(3, 3, FA, FB) CGV_GAP(3, 3, NA[0], CGV_DMAS(16, Q0))                              \
     }
-#define CGV_STAGE_SYNC                                                      \
-    if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      \
-    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                           \
-    if (SCHED == 3) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7) }
-    // A phase: k-step 0 of stage SB_ (fragments fa0/fb0), filling fa1/fb1 from the same stage's k-step 1;
-    // B phase: k-step 1 of the previous stage (fa1/fb1), the stage barrier, filling fa0/fb0 from stage SB_.
-#define CGV_A_PHASE(MMA, SB_) CGV_KSTEP(MMA, fa0, fb0, fa1, fb1, SB_, 1, 4, CGV_NOP_ACTION)
+    // counted wait: the DMA instructions of the stages behind the one being published may stay in flight
+    // (bf16/fp16: two stages = 16; fp8: one stage = 8, the phase's own 8 pieces are issued after the wait)
+#define CGV_STAGE_SYNC                                                                        \
+    if (!(ABL & 16)) {                                                                        \
+        if constexpr (F8)                                                                     \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  \
+        else                                                                                  \
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                 \
+    }                                                                                         \
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
+#define CGV_A_SYNC                       \
+    if constexpr (F8) { CGV_STAGE_SYNC; }
+    // bf16/fp16: A phase = k-step 0 of stage SA_ (fragments fa0/fb0), filling fa1/fb1 from the same stage's
+    //            k-step 1; B phase = k-step 1 of the previous stage (fa1/fb1), the stage barrier, filling
+    //            fa0/fb0 from stage SB_ (= SA_).
+    // fp8:       A phase = an even stage of the tile (fa0/fb0), barrier, filling fa1/fb1 from the NEXT stage
+    //            SA_; B phase = an odd stage (fa1/fb1), barrier, filling fa0/fb0 from the next stage SB_.
+#define CGV_A_PHASE(MMA, SA_) CGV_KSTEP(MMA, fa0, fb0, fa1, fb1, SA_, 1, 4, CGV_A_SYNC)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1))                                                                                                \
         tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
                                                       invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
                                                       stat_s + ((SEQ) & (NINV - 1)) * 16);
+    // LDS stage the B / A phase of loop body s fills its fragments from
+    auto stage_b = [&](uint32_t s) { return smem + ((F8 ? 2 * s : s) & (NSTAGE - 1)) * STAGE; };
+    auto stage_a = [&](uint32_t s) { return smem + ((F8 ? 2 * s + 1 : s) & (NSTAGE - 1)) * STAGE; };
 
     // ---- prologue: side data of the first tile, three stages in flight ---------------------------------
     issue_side(t_first, 0);
@@ -247,67 +298,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (and the side data before it) landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
     __builtin_amdgcn_s_barrier();
-    CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) CGV_LDF(fa0[i], smem + aoff + i * 2048, 0)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) CGV_LDF(fb0[i], smem + boff + i * 2048, 0)
     if (ABL & 8) {  // timing only: fragments read ONCE (real data: zero operands would raise the clock), never refreshed
 #pragma unroll
-        for (int i = 0; i < MB; ++i) fa1[i] = fa0[i] = *(const frag*)(smem + aoff + i * 2048 + xo[0]);
+        for (int i = 0; i < MB; ++i) fa1[i] = fa0[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) fb1[i] = fb0[i] = *(const frag*)(smem + boff + i * 2048 + xo[1]);
+        for (int i = 0; i < NB; ++i) fb1[i] = fb0[i];
     }
 
-    // Iteration s: B phase = k-step 1 of stage s-1 (its barrier frees slot (s-1)&3 for the DMA of stage s+3
-    // and publishes stage s), A phase = k-step 0 of stage s. DMA lead: 3 stages = 24 instructions per wave,
-    // of which the 16 youngest may be in flight at the wait.
+    // Loop body s = [B phase][A phase]; a tile is UNITS bodies and starts with an A phase (zero-C MFMAs) in the
+    // straight-line tile-boundary block. bf16/fp16: body s covers k-step 1 of stage s-1 and k-step 0 of stage s;
+    // the B phase's barrier frees slot (s-1)&3 for the DMA of stage s+3 and publishes stage s. fp8: body s covers
+    // stages 2s-1 and 2s, each phase publishing the next stage. DMA lead: 3 stages.
     uint32_t ct = t_first, s = 1;
-    if (SCHED != 3) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) }  // first half of stage 3 -> slot 3 (never used so far)
-    else { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7) }
-    CGV_A_PHASE(CGV_MMAZ, smem);
+    if (!F8) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) }  // first half of stage 3 -> slot 3 (never used so far)
+    CGV_A_PHASE(CGV_MMAZ, stage_a(0));
 #pragma unroll 1
-    for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
-        const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-        CGV_B_PHASE(sb);
-        CGV_A_PHASE(CGV_MMA, sb);
+    for (uint32_t u = 1; u < UNITS; ++u, ++s) {  // rest of the first tile
+        CGV_B_PHASE(stage_b(s));
+        CGV_A_PHASE(CGV_MMA, stage_a(s));
     }
 #pragma unroll 1
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
-            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-            CGV_B_PHASE(sb);
+            CGV_B_PHASE(stage_b(s));
             const uint32_t nt = next_tile(ct);
-            issue_side(nt, tl);  // the tile that starts here; consumed KC stages from now
+            issue_side(nt, tl);  // the tile that starts here
             CGV_EPILOGUE(a.T1 + ct, tl - 1);
             ct = nt;
-            CGV_A_PHASE(CGV_MMAZ, sb);
+            CGV_A_PHASE(CGV_MMAZ, stage_a(s));
             ++s;
         }
 #pragma unroll 1
-        for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
-            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-            CGV_B_PHASE(sb);
-            CGV_A_PHASE(CGV_MMA, sb);
+        for (uint32_t u = 1; u < UNITS; ++u, ++s) {
+            CGV_B_PHASE(stage_b(s));
+            CGV_A_PHASE(CGV_MMA, stage_a(s));
         }
     }
-    // tail: second k-step of the last stage, then the last tile's epilogue
+    // tail: the last k-step of the last tile, then its epilogue
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = W4Ops<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
     __builtin_amdgcn_s_barrier();
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);
 #undef CGV_EPILOGUE
 #undef CGV_B_PHASE
 #undef CGV_A_PHASE
+#undef CGV_A_SYNC
+#undef CGV_STAGE_SYNC
 #undef CGV_KSTEP
 #undef CGV_DMAS
-#undef CGV_GAP
 #undef CGV_NOP_ACTION
-#undef CGV_STAGE_SYNC
-#undef CGV_LDA
-#undef CGV_LDB
+#undef CGV_GAP
+#undef CGV_PIN_ALL
+#undef CGV_PIN_OPERAND
 #undef CGV_MMAZ
 #undef CGV_MMA
-#undef CGV_LOAD_FRAGS
+#undef CGV_LDB
+#undef CGV_LDA
+#undef CGV_LDF
 #undef CGV_ISSUE
 #undef CGV_DMA
 

@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+for rep in 1 2; do
+for v in "CGV_W8_STAGGER=0" "CGV_W8_STAGGER=1"; do
+  env $v timeout 200 python bench.py --steps 20 --warmup 3 --cpu-seconds ${CPUSEC:-0} --pipelined-steps 0 2>/dev/null | tail -1 | python -c "
+import json,sys; r=json.loads(sys.stdin.read()); ro=r['roofline']; print('$v coarse_ms',ro['avg_launch_ms'],ro['achieved'],'step_ms',r['ms_per_step'],'dev_ms',r['pipeline']['device_ms_last_step'],'recall',r.get('recall_at_10'))"
+done; done
