@@ -464,16 +464,16 @@ template <int DT>
 int launch_coarse_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     constexpr size_t lds = COARSE_LDS_BYTES;
     static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
-    if (abl4 && DT == DT_BF16) {
+    if (abl4 && (DT == DT_BF16 || DT == DT_FP8)) {
 #define CGV_ABLK4(N)                                                                                             \
     case N: {                                                                                                    \
-        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
+        auto k2 = coarse_w4_kernel<DT == DT_FP8 ? DT_FP8 : DT_BF16, false, N>;                                   \
         (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
         break;                                                                                                   \
     }
         switch (abl4) {
-            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(13)
+            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(17)
             default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
         }
 #undef CGV_ABLK4

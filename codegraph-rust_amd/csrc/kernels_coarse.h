@@ -150,93 +150,151 @@ __device__ inline void glds16(const char* g, char* l) {
 }
 
 
-// Fused top-k' epilogue of one corpus tile (shared by the coarse kernel variants).
-// MFMA C layout: lane owns query column lane&31 of each N-block and 16 corpus rows
-// (r&3)+8*(r>>2)+4*(lane>>5) of each M-block. The accumulators are NOT cleared here: the
-// first k-step of the next tile starts from a zero C operand (free in the MFMA encoding).
-template <int BM, int BN, int WTM, int WTN, int MB, int NB, bool DUMP>
-__device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], uint32_t tile, int wm,
-                                              int wn, int lane, uint32_t g, uint32_t qt, const float (&tq)[NB],
-                                              const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
-                                              const float* invn_s /* LDS: inverse norms of this tile's 256 rows */,
-                                              const float* stat_s /* LDS: 8 block-min + 8 block-max norms */) {
-    const uint64_t trow0 = (uint64_t)tile * BM + wm * WTM;
-    // Opaque copy of the lane id: stops LICM from hoisting the 16 x MB per-register row
-    // offsets out of the K loop (it cost ~50 VGPRs in the first build).
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
-    lane = lane_o;
+// 3-input maximum as ONE instruction. fmaxf() on MFMA outputs compiles to a canonicalising v_max_f32 x, x per
+// input plus the maxima (18 VALU per 16 scores instead of 10): the scores are never signalling NaNs, and a NaN
+// accumulator (non-finite inputs are rejected at ingest) would only miss the fast filter. The asm is invisible to
+// hipcc's hazard recogniser, so the caller pads the MFMA-result -> VALU-read distance itself (tile_epilogue).
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// maximum of the 16 scores a lane holds of one 32 x 32 block: 10 VALU
+__device__ __forceinline__ float block_max(const f32x16_t& v) {
+    const float m0 = vmax3(v[0], v[1], vmax2(v[2], v[3]));
+    const float m1 = vmax3(v[4], v[5], vmax2(v[6], v[7]));
+    const float m2 = vmax3(v[8], v[9], vmax2(v[10], v[11]));
+    const float m3 = vmax3(v[12], v[13], vmax2(v[14], v[15]));
+    return vmax3(m0, m1, vmax2(m2, m3));
+}
+
+// Slow path of one 32 x 32 block (some lane holds a score above its conservative threshold t): lanes with a score
+// above t compute the precise coarse score acc * invn_c * invn_q and append (score, row) to their (workgroup,
+// query) candidate list through an LDS counter. MFMA C layout: the lane owns query column lane&31 of the N-block
+// and 16 corpus rows (r&3)+8*(r>>2)+4*(lane>>5) of the M-block.
+template <int BM, int BN>
+__device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& v, float t, float tau, float iq,
+                                           uint32_t rl0 /* first row of the block within the tile */, uint32_t ql,
+                                           uint32_t tile, int lane, uint32_t g, uint32_t qt, uint32_t* cntq,
+                                           const float* invn_s) {
+    // row numbers are formed HERE, behind the branch, from an opaque base (32-bit: a device index holds < 2^32
+    // rows): hoisted, they were 16 64-bit additions per tile on the path every block takes
+    uint32_t rbase = rl0 + 4u * (uint32_t)(lane >> 5);
+    asm volatile("" : "+v"(rbase));
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const uint64_t brow = trow0 + mb * 32;
-        float mn = 0.0f, mx = 0.0f;
-        const bool blk_valid = brow < a.n;
-        if (blk_valid && a.metric != METRIC_DOT) {  // from LDS: no vector/scalar global load in the epilogue
-            mn = stat_s[(wm * WTM) / 32 + mb];
-            mx = stat_s[8 + (wm * WTM) / 32 + mb];
-        }
+    for (int gq = 0; gq < 4; ++gq) {
+        // the group maximum skips four compares at a time
+        if (vmax3(v[4 * gq], v[4 * gq + 1], vmax2(v[4 * gq + 2], v[4 * gq + 3])) > t) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x16_t v = acc[mb][nb];
-            if (blk_valid) {
-                const uint32_t ql = wn * WTN + nb * 32 + (lane & 31);
-                if (DUMP) {
-                    const uint32_t q = qt * BN + ql;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint64_t row = brow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < a.n && q < a.nq) {
-                            float s = (a.metric == METRIC_DOT) ? v[r] : v[r] * invn_s[row - (uint64_t)tile * BM] * invq[nb];
-                            a.dump[(uint64_t)q * a.n + row] = s;
-                        }
-                    }
-                } else {
-                    // conservative per-block threshold in raw-accumulator units
-                    float t = tq[nb];
-                    if (a.metric != METRIC_DOT && fabsf(t) < INFINITY)
-                        t = (t >= 0.0f) ? t * mn * (1.0f - 3.8147e-6f) : t * mx * (1.0f + 3.8147e-6f);
-                    // max tree written as nested 3-input maxima (v_max3_f32): 16 values in 8 ops;
-                    // the four group maxima are reused to skip whole groups in the slow path
-                    const float m0 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    const float m1 = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
-                    const float m2 = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11]));
-                    const float m3 = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
-                    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-                    if (m > t) {
-                        const float gm[4] = {m0, m1, m2, m3};
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            if (gm[gq] > t) {
-#pragma unroll
-                                for (int r4 = 0; r4 < 4; ++r4) {
-                                    const int r = gq * 4 + r4;
-                                    const float av = v[r];
-                                    if (av > t) {
-                                        const uint32_t rl =
-                                            (uint32_t)(wm * WTM + mb * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (uint32_t)(lane >> 5);
-                                        const uint64_t row = (uint64_t)tile * BM + rl;
-                                        if (row < a.n) {
-                                            // inverse norm from LDS: a vector global load here would need
-                                            // s_waitcnt vmcnt(0), i.e. wait for the next chunk's DMA
-                                            const float s =
-                                                (a.metric == METRIC_DOT) ? av : av * invn_s[rl] * invq[nb];
-                                            if (s > tauv[nb]) {
-                                                const uint32_t p = lds_inc_rtn(&cntq[ql]);
-                                                if (p < CAND_CAPS)
-                                                    a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] =
-                                                        make_uint2(__float_as_uint(s), (uint32_t)row);
-                                                else
-                                                    a.overflow[qt * BN + ql] = 1u;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = gq * 4 + r4;
+                const float av = v[r];
+                if (av > t) {
+                    const uint32_t rl = rbase + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    const uint32_t row = tile * (uint32_t)BM + rl;
+                    if (row < a.n) {
+                        // inverse norm from LDS: a vector global load here would need
+                        // s_waitcnt vmcnt(0), i.e. wait for the next chunk's DMA
+                        const float s = (a.metric == METRIC_DOT) ? av : av * invn_s[rl] * iq;
+                        if (s > tau) {
+                            const uint32_t p = lds_inc_rtn(&cntq[ql]);
+                            if (p < CAND_CAPS)
+                                a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(s), row);
+                            else
+                                a.overflow[qt * BN + ql] = 1u;
                         }
                     }
                 }
             }
         }
+    }
+}
+
+// conservative per-block threshold in raw-accumulator units: tq = tau / invn_q; a row of norm n scores
+// acc / n / |q|, so acc > tq * (smallest norm of the block) is necessary when tq >= 0, acc > tq * (largest) when
+// tq < 0 (2^-18 head room for the rounding of the products)
+__device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, float mn, float mx) {
+    if (a.metric == METRIC_DOT || !(fabsf(tq) < INFINITY)) return tq;
+    return (tq >= 0.0f) ? tq * mn * (1.0f - 3.8147e-6f) : tq * mx * (1.0f + 3.8147e-6f);
+}
+
+// Fused top-k' epilogue of one corpus tile (shared by the coarse kernel variants).
+// Fast filter, BRANCH-FREE over all blocks of the wave tile: the maximum of each block's 16 scores (10 VALU) against a
+// conservative raw-accumulator threshold, the verdicts collected in a per-lane bit mask; one branch for the whole
+// tile, then the slow path of the flagged blocks only. (Round 1 branched per block: 8 - 16 short basic blocks per
+// tile, each a dependent chain with nothing to overlap; measured 43 % of the one-wave-per-SIMD fp8 kernel.)
+// The accumulators are NOT cleared here: the first k-step of the next tile starts from a zero C operand (free in
+// the MFMA encoding).
+template <int BM, int BN, int WTM, int WTN, int MB, int NB, bool DUMP, bool ACC_AGPR = false>
+__device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], uint32_t tile, int wm,
+                                              int wn, int lane, uint32_t g, uint32_t qt, const float (&tq)[NB],
+                                              const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
+                                              const float* invn_s /* LDS: inverse norms of this tile's 256 rows */,
+                                              const float* stat_s /* LDS: 8 block-min + 8 block-max norms */) {
+    const uint32_t trow0 = tile * (uint32_t)BM + (uint32_t)(wm * WTM);
+    // Opaque copy of the lane id: stops LICM from hoisting per-register row offsets out of the K loop
+    // (it cost ~50 VGPRs in the first build).
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    lane = lane_o;
+    if (DUMP) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t rl = (uint32_t)(wm * WTM + mb * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (uint32_t)(lane >> 5);
+                    const uint32_t row = tile * (uint32_t)BM + rl;
+                    if (row < a.n && q < a.nq)
+                        a.dump[(uint64_t)q * a.n + row] =
+                            (a.metric == METRIC_DOT) ? acc[mb][nb][r] : acc[mb][nb][r] * invn_s[rl] * invq[nb];
+                }
+            }
+        return;
+    }
+    // the block norm bounds of all M-blocks in one LDS round trip
+    float mn[MB], mx[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        mn[mb] = stat_s[(wm * WTM) / 32 + mb];
+        mx[mb] = stat_s[8 + (wm * WTM) / 32 + mb];
+    }
+    // vmax3 (inline asm) reads MFMA results: an 8/16-pass MFMA's result needs up to 18 wait states before a VALU may
+    // read it, and hipcc pads nothing for asm
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    // With the accumulators in AGPRs (one wave per SIMD: ACC_AGPR) every score reaches the VALU through a
+    // v_accvgpr_read, which hipcc hoists as far up as it can: without the empty re-definitions below it reads all 256
+    // accumulators ahead of the filter AND keeps the copies alive for the slow path (512 registers + spills).
+    uint32_t hit = 0;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const bool blk_valid = trow0 + (uint32_t)(mb * 32) < a.n;  // uniform
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float t = block_threshold(a, tq[nb], mn[mb], mx[mb]);
+            hit |= (blk_valid && block_max(acc[mb][nb]) > t) ? (1u << (mb * NB + nb)) : 0u;
+            if (ACC_AGPR && (nb & 1)) asm volatile("" : "+a"(acc[mb][nb - 1]), "+a"(acc[mb][nb]));
+        }
+    }
+    if (__builtin_expect(hit != 0, 0)) {  // cold: the handlers (tens of KiB of code) stay out of the hot path
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if (hit & (1u << (mb * NB + nb))) {
+                    if (ACC_AGPR) asm volatile("" : "+a"(acc[mb][nb]));
+                    block_hits<BM, BN>(a, acc[mb][nb], block_threshold(a, tq[nb], mn[mb], mx[mb]), tauv[nb], invq[nb],
+                                       (uint32_t)(wm * WTM + mb * 32), (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane,
+                                       g, qt, cntq, invn_s);
+                }
     }
 }
 

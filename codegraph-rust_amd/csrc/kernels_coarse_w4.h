@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1))                                                                                                \
-        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP, true>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
                                                       invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
                                                       stat_s + ((SEQ) & (NINV - 1)) * 16);
     // LDS stage the B / A phase of loop body s fills its fragments from

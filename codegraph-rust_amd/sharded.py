@@ -31,6 +31,7 @@ class ShardedKnn:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self._device_merge = merge is None   # default: packed records + the HIP merge kernel
+        self._gathered = None
         if merge is None:
             from .cgvec import merge_topk
             merge = merge_topk
@@ -60,9 +61,11 @@ class ShardedKnn:
         if idx.is_cuda and self._device_merge:
             from .cgvec import merge_packed, pack_topk
             rec = pack_topk(idx, score)                       # one kernel instead of cat + 2 slice copies
-            gathered = torch.empty((self.world,) + tuple(rec.shape), dtype=torch.int32, device=rec.device)
-            dist.all_gather_into_tensor(gathered, rec, group=self.group)
-            return merge_packed(gathered, k)
+            key = (self.world,) + tuple(rec.shape)
+            if self._gathered is None or tuple(self._gathered.shape) != key or self._gathered.device != rec.device:
+                self._gathered = torch.empty(key, dtype=torch.int32, device=rec.device)   # reused across batches
+            dist.all_gather_into_tensor(self._gathered, rec, group=self.group)
+            return merge_packed(self._gathered, k)
         rec = torch.cat([idx.contiguous().view(torch.int32).reshape(nq, 2 * k),
                          score.contiguous().view(torch.int32).reshape(nq, k)], dim=1).contiguous()
         gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=rec.device)
