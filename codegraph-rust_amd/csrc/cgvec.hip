@@ -280,6 +280,7 @@ int grow(cgv_index* h, uint64_t need) {
     HIPCHK(hipMalloc((void**)&bmin, nblk * 4));
     HIPCHK(hipMalloc((void**)&bmax, nblk * 4));
     HIPCHK(hipMalloc((void**)&rexp, ncap));
+    HIPCHK(hipMemsetAsync(rexp, 0, ncap, h->stream));  // padding rows: scale 2^0 (an E8M0 byte of 255 would be NaN)
     char* srows = nullptr;
     if (h->shadow) {
         HIPCHK(hipMalloc((void**)&srows, shadow_bytes(h, ncap)));
@@ -419,7 +420,8 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, uint64_t total,
 }
 
 // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
-constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4;
+// (+ for fp8 an 8-deep ring of the tiles' 256 scale exponents)
+constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4 + 8 * 256;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it for every
 // kernel that needs more than 64 KiB of dynamic LDS once per device (cgv_create calls this with the
@@ -436,11 +438,8 @@ int ensure_kernel_attrs(int device) {
     CGV_ATTR((coarse_kernel<DT_BF16, true>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_kernel<DT_FP16, true>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_kernel<DT_FP8, false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_kernel<DT_FP8, true>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_w4_kernel<DT_FP8, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
     CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
@@ -464,10 +463,10 @@ template <int DT>
 int launch_coarse_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     constexpr size_t lds = COARSE_LDS_BYTES;
     static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
-    if (abl4 && (DT == DT_BF16 || DT == DT_FP8)) {
+    if (abl4 && DT == DT_BF16) {
 #define CGV_ABLK4(N)                                                                                             \
     case N: {                                                                                                    \
-        auto k2 = coarse_w4_kernel<DT == DT_FP8 ? DT_FP8 : DT_BF16, false, N>;                                   \
+        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
         (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
         break;                                                                                                   \
@@ -535,14 +534,7 @@ int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStre
     if (dtype == CGV_DTYPE_FP16)
         return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP8E4M3) {
-        // block-scaled K=64 MFMA kernel; CGV_FP8_NONSCALED=1 selects the v_mfma_f32_32x32x16_fp8_fp8
-        // variant of the generic kernel (same results; kept for A/B timing)
-        static const bool nonscaled = getenv("CGV_FP8_NONSCALED") && atoi(getenv("CGV_FP8_NONSCALED")) != 0;
-        if (nonscaled) return dump ? launch_coarse_t<DT_FP8, true>(a, W, s) : launch_coarse_t<DT_FP8, false>(a, W, s);
-        // CGV_COARSE=w4: the one-wave-per-SIMD kernel (double-buffered K=64 fragments, zero-C tile starts; needs an
-        // even kc) for A/B timing - measured 16 % SLOWER than the 8-wave fp8 kernel on C5-mini
-        static const bool w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
-        if (!dump && w4 && a.kc >= 4 && (a.kc & 1u) == 0) return launch_coarse_w4<DT_FP8>(a, W, s);
+        // block-scaled K=64 MFMA kernel with the rows' power-of-two scales applied by the instruction
         return dump ? launch_coarse_fp8s<true>(a, W, s) : launch_coarse_fp8s<false>(a, W, s);
     }
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
@@ -724,7 +716,8 @@ void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float
     hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s,
                        (const char*)(h->shadow ? h->srows : h->rows),
                        (const char*)(h->shadow ? c->qshadow.p : c->qrows.p), (const float*)h->invn,
-                       (const float*)c->qinvn.p, n_boot, nq, h->shadow ? h->lds : h->ld, h->metric, dense);
+                       (const float*)c->qinvn.p, n_boot, nq, h->shadow ? h->lds : h->ld, h->metric, dense,
+                       (const int8_t*)(DT == DT_FP8 ? h->rexp : nullptr), (const int8_t*)(DT == DT_FP8 ? c->qrexp.p : nullptr));
 }
 
 // Enqueue one batch on the context's stream (no host synchronisation); search_finish() completes it.
@@ -831,6 +824,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.nqt = nqt;
         a.metric = h->metric;
         a.qgroup = query_group(nqt, a.ld, cdt);
+        a.rexp_c = h->rexp;
+        a.rexp_q = c->qrexp.as<int8_t>();
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
         uint32_t last_nsplit = 0;
@@ -1859,6 +1854,8 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.nqt = nqt;
     a.metric = h->metric;
     a.qgroup = query_group(nqt, a.ld, cdt);
+    a.rexp_c = h->rexp;
+    a.rexp_q = c->qrexp.as<int8_t>();
     if ((rc = launch_coarse(cdt, true, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;

@@ -91,6 +91,8 @@ struct CoarseArgs {
     uint32_t n, nq, ld, kc;
     uint32_t T1, R, P, j0, cnt, nsplit, nqt, metric;
     uint32_t qgroup;        // query tiles that share one XCD (block_to_work); 0 = all of them
+    const int8_t* rexp_c;   // fp8 only: [n] per-row power-of-two scale exponents of the corpus ...
+    const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
                                                   const float* __restrict__ invn_c,
                                                   const float* __restrict__ invn_q, uint32_t n_boot,
                                                   uint32_t nq, uint32_t ld, int metric,
-                                                  float* __restrict__ dense) {
+                                                  float* __restrict__ dense,
+                                                  const int8_t* __restrict__ rexp_c = nullptr,
+                                                  const int8_t* __restrict__ rexp_q = nullptr) {
     typedef typename Mfma<DT>::frag frag;
     const int lane = threadIdx.x & 63;
     const uint32_t nrb = (n_boot + 63) / 64;
@@ -668,7 +672,10 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
     for (int j = 0; j < 2; ++j) {
         const uint32_t q = qb * 64 + j * 32 + (lane & 31);
         if (q >= nq) continue;
-        const float iq = (metric == METRIC_DOT) ? 1.0f : invn_q[q];
+        // fp8: this kernel multiplies the e4m3 CODES (v_mfma_f32_32x32x16_fp8_fp8 has no scale operands) while the
+        // inverse norms are those of the de-scaled rows: 1 / |codes| = invn * 2^-e, folded in here (exact)
+        float iq = (metric == METRIC_DOT) ? 1.0f : invn_q[q];
+        if (DT == DT_FP8 && rexp_q) iq = ldexpf(iq, -(int)rexp_q[q]);
         // C layout: registers 4g..4g+3 of a block are 4 CONSECUTIVE corpus rows -> one 16-byte store each
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -680,7 +687,14 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
                     float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2],
                                            acc[i][j][4 * g4 + 3]);
                     if (metric != METRIC_DOT) {
-                        const float4 ic = *(const float4*)(invn_c + row);
+                        float4 ic = *(const float4*)(invn_c + row);
+                        if (DT == DT_FP8 && rexp_c) {
+                            const int ec = *(const int*)(rexp_c + row);  // 4 signed bytes
+                            ic.x = ldexpf(ic.x, -((ec << 24) >> 24));
+                            ic.y = ldexpf(ic.y, -((ec << 16) >> 24));
+                            ic.z = ldexpf(ic.z, -((ec << 8) >> 24));
+                            ic.w = ldexpf(ic.w, -(ec >> 24));
+                        }
                         v.x = v.x * ic.x * iq;
                         v.y = v.y * ic.y * iq;
                         v.z = v.z * ic.z * iq;
@@ -692,7 +706,9 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
                     for (int t = 0; t < 4; ++t)
                         if (row + t < n_boot) {
                             const float v = acc[i][j][4 * g4 + t];
-                            dst[t] = (metric == METRIC_DOT) ? v : v * invn_c[row + t] * iq;
+                            float ic = invn_c[row + t];
+                            if (DT == DT_FP8 && rexp_c) ic = ldexpf(ic, -(int)rexp_c[row + t]);
+                            dst[t] = (metric == METRIC_DOT) ? v : v * ic * iq;
                         }
                 }
             }

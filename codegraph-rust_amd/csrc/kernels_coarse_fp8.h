@@ -27,6 +27,18 @@ __device__ inline f32x16_t mma_fp8_k64(const Fp8Frag& a, const Fp8Frag& b, f32x1
     // cbsz = blgp = 0: both operands OCP e4m3; E8M0 scale 0x7F = 2^0 for every 32-element block
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
+// The same with the operands' per-row power-of-two scales applied BY THE INSTRUCTION: a lane's 32 bytes are one
+// 32-element scale block of its row (A) / query (B), so byte SA of `sa` (SB of `sb`) is that row's E8M0 scale
+// 2^(x - 127) = 2^-e. The accumulators then hold dot products of the DE-SCALED values, every row of a block in the
+// same domain - what the norm-bound fast filter of the epilogue needs (with the scales left at 2^0, rows whose
+// exponents differ by one sit a factor 2 apart and a quarter of the lanes false-alarm in every block:
+// 1949 -> 2443 TFLOP/s on a corpus with one exponent, scripts/gpu_fp8_probe.py).
+template <int SA, int SB>
+__device__ inline f32x16_t mma_fp8_k64_scaled(const Fp8Frag& a, const Fp8Frag& b, f32x16_t c, int sa, int sb) {
+    const i32x8_t av = __builtin_shufflevector(a.p0, a.p1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8_t bv = __builtin_shufflevector(b.p0, b.p1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, SA, sa, SB, sb);
+}
 
 template <bool DUMP>
 __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
@@ -39,6 +51,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
     float* invn_s = (float*)(smem + NSTAGE * STAGE + BN * 4);
     float* stat_s = invn_s + NINV * 256;
+    int8_t* rexp_s = (int8_t*)(stat_s + NINV * 16);  // [NINV][256] per-row scale exponents, by tile sequence number
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,6 +109,9 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
                     const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + lt) * 8 + (lane & 1) * 4;
                     glds16((const char*)sp, (char*)(stat_s + (lj & (NINV - 1)) * 16));
                 }
+                if (wave == 2 && lane < 16)  // the tile's 256 scale exponents
+                    glds16((const char*)a.rexp_c + (uint64_t)(a.T1 + lt) * 256 + lane * 16,
+                           (char*)(rexp_s + (lj & (NINV - 1)) * 256));
             }
             bdma(rsA, so, dst);
         } else if (q == 1) {
@@ -135,6 +151,23 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
+    // E8M0 scale bytes (127 - e = 2^-e): sb = the lane's two query columns (byte nb), constant for the workgroup;
+    // sa = its four corpus rows of the current tile (byte mb), reloaded from the LDS ring at every tile boundary
+    int sb = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const int e = q < a.nq ? (int)a.rexp_q[q] : 0;
+        sb |= ((127 - e) & 0xff) << (8 * nb);
+    }
+    int sa = 0x7f7f7f7f;
+    auto load_sa = [&](uint32_t seq) {
+        const int8_t* p = rexp_s + (seq & (NINV - 1)) * 256 + wm * WTM + (lane & 31);
+        int v = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) v |= ((127 - (int)p[mb * 32]) & 0xff) << (8 * mb);
+        sa = v;
+    };
     Fp8Frag fa01[2], fa23[2], fbx[2], fby[2];
 #define F8_LOAD(F, BASE, OFF)                                  \
     {                                                          \
@@ -160,21 +193,21 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
 #define F8_STAGE(BC, BN_, SB, SNEXT)                                                             \
     {                                                                                            \
         F8_SB;                                                                                   \
-        acc[0][0] = mma_fp8_k64(fa01[0], BC[0], acc[0][0]);                                      \
+        acc[0][0] = mma_fp8_k64_scaled<0, 0>(fa01[0], BC[0], acc[0][0], sa, sb);                                      \
         F8_SB;                                                                                   \
         F8_LOAD_A23(SB);                                                                         \
         F8_SB;                                                                                   \
-        acc[0][1] = mma_fp8_k64(fa01[0], BC[1], acc[0][1]);                                      \
+        acc[0][1] = mma_fp8_k64_scaled<0, 1>(fa01[0], BC[1], acc[0][1], sa, sb);                                      \
         F8_SB;                                                                                   \
         issue_q(2);                                                                              \
         F8_SB;                                                                                   \
-        acc[1][0] = mma_fp8_k64(fa01[1], BC[0], acc[1][0]);                                      \
+        acc[1][0] = mma_fp8_k64_scaled<1, 0>(fa01[1], BC[0], acc[1][0], sa, sb);                                      \
         F8_SB;                                                                                   \
         issue_q(3);                                                                              \
         F8_SB;                                                                                   \
-        acc[1][1] = mma_fp8_k64(fa01[1], BC[1], acc[1][1]);                                      \
+        acc[1][1] = mma_fp8_k64_scaled<1, 1>(fa01[1], BC[1], acc[1][1], sa, sb);                                      \
         F8_SB;                                                                                   \
-        acc[2][0] = mma_fp8_k64(fa23[0], BC[0], acc[2][0]);                                      \
+        acc[2][0] = mma_fp8_k64_scaled<2, 0>(fa23[0], BC[0], acc[2][0], sa, sb);                                      \
         F8_SB;                                                                                   \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
         __builtin_amdgcn_s_barrier();                                                            \
@@ -182,15 +215,15 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
         F8_LOAD_A01(SNEXT);                                                                      \
         F8_LOAD_B(BN_, SNEXT);                                                                   \
         F8_SB;                                                                                   \
-        acc[2][1] = mma_fp8_k64(fa23[0], BC[1], acc[2][1]);                                      \
+        acc[2][1] = mma_fp8_k64_scaled<2, 1>(fa23[0], BC[1], acc[2][1], sa, sb);                                      \
         F8_SB;                                                                                   \
         issue_q(0);                                                                              \
         F8_SB;                                                                                   \
-        acc[3][0] = mma_fp8_k64(fa23[1], BC[0], acc[3][0]);                                      \
+        acc[3][0] = mma_fp8_k64_scaled<3, 0>(fa23[1], BC[0], acc[3][0], sa, sb);                                      \
         F8_SB;                                                                                   \
         issue_q(1);                                                                              \
         F8_SB;                                                                                   \
-        acc[3][1] = mma_fp8_k64(fa23[1], BC[1], acc[3][1]);                                      \
+        acc[3][1] = mma_fp8_k64_scaled<3, 1>(fa23[1], BC[1], acc[3][1], sa, sb);                                      \
         F8_SB;                                                                                   \
         if (++ckc == KC) {                                                                       \
             ckc = 0;                                                                             \
@@ -199,6 +232,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
             ++cj;                                                                                \
             ct = next_tile(ct);                                                                  \
             if (done < total) F8_EPILOGUE();                                                     \
+            load_sa(cj); /* the tile that starts with the next stage (its exponents landed with its first stage) */ \
         }                                                                                        \
         ++done;                                                                                  \
     }
@@ -214,6 +248,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    load_sa(0);
     F8_LOAD_A01(smem);
     F8_LOAD_B(fbx, smem);
     issue_q(0);

@@ -13,8 +13,8 @@ namespace cgv {
 // in: [n][D] f32 (n rows to append). out: the index' row storage (f32: row-major [.][ld];
 // bf16/fp16/fp8: blocked layout B32, see common.h), written at absolute rows row0 + r, columns
 // zero padded to ld (a whole number of 64-byte chunks).
-// fp8 rows are stored scaled by their own power of two (rexp[r], common.h); norms are taken in
-// that scaled domain, where the coarse pass works.
+// fp8 rows are stored scaled by their own power of two (rexp[r], common.h); norm / invn are those of the
+// de-scaled stored values (code * 2^-e), the domain the scaled MFMA of the coarse pass accumulates in.
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
 // coarse pass), invn[r] = 1/norm or 0. nonfinite: set to 1 if any input is NaN/Inf.
 template <int DT>
@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if (lane == 0) {
-        float nr = sqrtf(ss);
-        norm[row0 + row] = nr;
-        invn[row0 + row] = nr > 0.0f ? 1.0f / nr : 0.0f;
+        const float nr = sqrtf(ss);
+        // fp8: the coarse kernel applies the rows' scales inside the MFMA (kernels_coarse_fp8.h), so its accumulators -
+        // and therefore these norms - live in the DE-SCALED domain: norm * 2^-e, (1 / norm) * 2^e, both exact
+        norm[row0 + row] = (DT == DT_FP8) ? ldexpf(nr, -e) : nr;
+        invn[row0 + row] = nr > 0.0f ? ((DT == DT_FP8) ? ldexpf(1.0f / nr, e) : 1.0f / nr) : 0.0f;
     }
     if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
 }
