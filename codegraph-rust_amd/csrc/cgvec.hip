@@ -509,7 +509,7 @@ int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     }
     // CGV_COARSE=w4 selects the one-wave-per-SIMD variant (kernels_coarse_w4.h; kc >= 4) for bf16 / fp16 A/B
     // timing: same results, measured equal to this 8-wave kernel on the main launch and slower on the hit-heavy
-    // stage-1 launch. (fp8 uses the one-wave-per-SIMD kernel by default: launch_coarse.)
+    // stage-1 launch.
     static const bool use_w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
     if constexpr (!DUMP && DT != DT_FP8) {
         if (use_w4 && a.kc >= 4) return launch_coarse_w4<DT>(a, W, s);

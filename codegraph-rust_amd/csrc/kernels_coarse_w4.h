@@ -5,8 +5,7 @@
 // Why (VERDICT r1 'next' 5(iii) / 8; measurements in DESIGN.md §9): with two 128 x 64 waves per SIMD the
 // kernel issues 6 ds_read_b128 per 8 MFMAs and both waves of a SIMD compete for its matrix pipe; with one
 // 128 x 128 wave it is 8 reads per 16 MFMAs and the arch VGPR half has room for fully double-buffered
-// fragments even for fp8 (K = 64 per instruction: 8 VGPRs per operand block), which the 8-wave fp8 kernel
-// could not afford (single-buffered A halves, accumulators cleared per tile instead of zero-C MFMAs).
+// fragments.
 // Everything else is the 8-wave kernel's design (kernels_coarse.h): B32 blocked operands, 4-slot LDS ring
 // filled by buffer_load ... lds three stages ahead and retired by a counted vmcnt, one barrier per stage,
 // tile-structured loop with zero-C MFMAs at the tile boundary, the fused threshold top-k' epilogue
@@ -14,34 +13,21 @@
 //   * a wave copies 4 KiB of the A block and 4 KiB of the B block per stage: 8 DMA instructions, the four of
 //     a block sharing one M0 / scalar offset and stepping by the instruction's immediate offset (1 KiB);
 //   * with ONE wave on the SIMD nothing covers an issue stall, so everything is placed: the fragment reads of
-//     the next k-step go one (bf16/fp16) or two (fp8) per MFMA gap behind the first 8 MFMAs, the DMA pieces
+//     the next k-step go one per MFMA gap behind the first 8 MFMAs, the DMA pieces
 //     behind the last 8 (8 reads back to back cost 0.33 ms of 1.08 on the C2 main launch);
 //   * the per-tile side data (inverse norms, block bounds) is issued in the straight-line tile-boundary block
 //     for the tile that STARTS there, so the stage loop has no branch besides its back edge.
-// bf16 / fp16: a 64-byte stage is two K=16 k-steps (A phase, B phase). fp8: a stage is ONE K=64 k-step, so
-// both phases of the loop body are whole stages with their own barrier (needs an even kc; the host falls back
-// to the 8-wave kernels for kc < 4 or odd fp8 kc).
+// A 64-byte stage is two K=16 k-steps (A phase, B phase); the host falls back to the 8-wave kernel for kc < 4.
 // Measured on C2: equal to the 8-wave kernel on the main launch, slower on the hit-heavy
 // stage-1 launch (its epilogue - 256 v_accvgpr_read + the max tree per tile - has no partner wave to hide
-// behind), so bf16 / fp16 searches keep the 8-wave kernel by default; fp8 uses this one.
+// behind), so searches keep the 8-wave kernel by default and this one is an opt-in (CGV_COARSE=w4) A/B variant
+// for bf16 / fp16. An fp8 instantiation (a stage = one K=64 k-step) was measured too (1766 vs 2096 TFLOP/s for
+// the 8-wave fp8 kernel on C5-mini) and dropped: the fp8 kernel now needs the rows' scale exponents of a tile
+// before its FIRST MFMA (kernels_coarse_fp8.h), which this kernel's side-data schedule does not provide.
 #pragma once
 #include "kernels_coarse.h"
-#include "kernels_coarse_fp8.h"
 
 namespace cgv {
-
-template <int DT>
-struct W4Ops {
-    typedef typename Mfma<DT>::frag frag;
-    static constexpr bool F8 = false;
-    static __device__ inline f32x16_t mma(const frag& a, const frag& b, f32x16_t c) { return Mfma<DT>::mma(a, b, c); }
-};
-template <>
-struct W4Ops<DT_FP8> {
-    typedef Fp8Frag frag;
-    static constexpr bool F8 = true;
-    static __device__ inline f32x16_t mma(const frag& a, const frag& b, f32x16_t c) { return mma_fp8_k64(a, b, c); }
-};
 
 // ABL: timing-only ablation mask (results are WRONG for ABL != 0; CGV_ABLATE_W4): 1 = skip the epilogue,
 // 2 = skip the DMA, 4 = skip the barrier, 8 = read the fragments once (real data) and never again,
@@ -52,8 +38,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int WTM = 128, WTN = 128, MB = 4, NB = 4;
     constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
     constexpr int NSTAGE = 4, NINV = 8;
-    constexpr bool F8 = W4Ops<DT>::F8;
-    typedef typename W4Ops<DT>::frag frag;
+    static_assert(DT == DT_BF16 || DT == DT_FP16, "two-byte operands only");
+    typedef typename Mfma<DT>::frag frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
@@ -86,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t jlo = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)split * a.cnt) / a.nsplit));
     const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(split + 1) * a.cnt) / a.nsplit));
     const uint32_t KC = a.kc;
-    const uint32_t UNITS = F8 ? KC / 2 : KC;  // loop bodies (two k-steps each) per tile
+    const uint32_t UNITS = KC;  // loop bodies (two k-steps each) per tile
     const uint32_t total = (jhi - jlo) * KC;  // pipeline stages of this workgroup
     const uint32_t ntl = jhi - jlo;
     if (total == 0) {  // uniform: nothing to stream for this workgroup
@@ -143,7 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // side data of the tile with sequence number seq (absolute tile T1 + tt): 256 inverse norms by wave 0,
     // 8 + 8 block norm bounds by 4 lanes of wave 1. Issued at the tile boundary where the tile starts; its
     // epilogue runs >= 3 stages later, behind a counted wait that leaves fewer DMA instructions in flight
-    // than were issued after these (bf16: 4 + 8 (KC - 1) >= 16 for KC >= 3; fp8: 8 >= 8).
+    // than were issued after these (4 + 8 (KC - 1) >= 16 for KC >= 3).
     auto issue_side = [&](uint32_t tt, uint32_t seq) {
         if (ABL & 2) return;
         if (wave == 0)
@@ -154,17 +140,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    // fragment read offsets (bytes): row r = base32 + (lane&31). bf16/fp16: the lane's piece of k-step kk is
-    // c = 2*kk + (lane>>5); fp8: its 32 bytes are pieces 2h, 2h+1 (h = lane>>5). Piece c sits at slot c ^ ((r>>2)&3).
+    // fragment read offsets (bytes): row r = base32 + (lane&31); the lane's piece of k-step kk is
+    // c = 2*kk + (lane>>5). Piece c sits at slot c ^ ((r>>2)&3).
     const uint32_t key = (uint32_t)(lane >> 2) & 3u, hh = (uint32_t)(lane >> 5);
-    uint32_t xo[2];
-    if (F8) {
-        xo[0] = ((2 * hh) ^ key) << 4;
-        xo[1] = ((2 * hh + 1) ^ key) << 4;
-    } else {
-        xo[0] = (hh ^ key) << 4;
-        xo[1] = ((2 + hh) ^ key) << 4;
-    }
+    const uint32_t xo[2] = {(hh ^ key) << 4, ((2 + hh) ^ key) << 4};
     const uint32_t aoff = (uint32_t)(wm * WTM + (lane & 31)) * 64;
     const uint32_t boff = (uint32_t)A_BYTES + (uint32_t)(wn * WTN + (lane & 31)) * 64;
 
@@ -178,20 +157,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16;
 
     frag fa0[MB], fb0[NB], fa1[MB], fb1[NB];
-    // one fragment = one ds_read_b128 (bf16/fp16: piece xo[KK] of the stage) or two (fp8: both pieces)
-#define CGV_LDF(F, ADDR, KK)                                                       \
-    {                                                                              \
-        if constexpr (F8) {                                                        \
-            (F).p0 = *(const i32x4_t*)((ADDR) + xo[0]);                            \
-            (F).p1 = *(const i32x4_t*)((ADDR) + xo[1]);                            \
-        } else {                                                                   \
-            (F) = *(const frag*)((ADDR) + xo[KK]);                                 \
-        }                                                                          \
-    }
+    // one fragment = one ds_read_b128 (piece xo[KK] of the stage)
+#define CGV_LDF(F, ADDR, KK) (F) = *(const frag*)((ADDR) + xo[KK]);
 #define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) CGV_LDF(FA[I], (BASE) + aoff + (I) * 2048, KK)
 #define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) CGV_LDF(FB[I], (BASE) + boff + (I) * 2048, KK)
-#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = W4Ops<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
-#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = W4Ops<DT>::mma(FA[MBI], FB[NBI], zero16);
+#define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
+#define CGV_MMAZ(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], zero16);
     // Program-order pins. An MFMA is a pure register operation: instruction selection is free to place it
     // anywhere its operands allow, sched_barrier or not (the first build of this kernel had the phase's first
     // MFMA sunk below the fragment reads, so its lgkmcnt(0) waited for the reads just issued). An empty asm
@@ -199,47 +170,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // reading it come after this point) ties them to the chain of side-effecting instructions (LDS reads,
     // DMA, barrier, waits: "memory"), which keeps its order. One gap = what is issued between MFMA (MBI, NBI)
     // and the next one.
-#define CGV_PIN_OPERAND(X)                                  \
-    {                                                       \
-        if constexpr (F8)                                   \
-            asm volatile("" : "+v"((X).p0)::"memory");      \
-        else                                                \
-            asm volatile("" : "+v"(X)::"memory");           \
-    }
+#define CGV_PIN_OPERAND(X) asm volatile("" : "+v"(X)::"memory");
     // all 8 fragments of the k-step named at its start: hipcc places its (single) lgkmcnt wait for them HERE,
     // where they were issued a whole k-step ago, instead of in front of their first use in the middle of the
     // phase, where it would also wait for the reads just issued
-#define CGV_PIN_ALL(FA, FB)                                                                                          \
-    {                                                                                                                \
-        if constexpr (F8)                                                                                            \
-            asm volatile("" : "+v"(FA[0].p0), "+v"(FA[0].p1), "+v"(FA[1].p0), "+v"(FA[1].p1), "+v"(FA[2].p0),        \
-                              "+v"(FA[2].p1), "+v"(FA[3].p0), "+v"(FA[3].p1), "+v"(FB[0].p0), "+v"(FB[0].p1),        \
-                              "+v"(FB[1].p0), "+v"(FB[1].p1), "+v"(FB[2].p0), "+v"(FB[2].p1), "+v"(FB[3].p0),        \
-                              "+v"(FB[3].p1)::"memory");                                                             \
-        else                                                                                                         \
-            asm volatile("" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]),          \
-                              "+v"(FB[2]), "+v"(FB[3])::"memory");                                                   \
-    }
+#define CGV_PIN_ALL(FA, FB)                                                                             \
+    asm volatile("" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]),     \
+                      "+v"(FB[2]), "+v"(FB[3])::"memory");
 #define CGV_GAP(MBI, NBI, NEXT_OPERAND, ACTION)                        \
     asm volatile("" : "+a"(acc[MBI][NBI])::"memory");                  \
     ACTION;                                                            \
     CGV_PIN_OPERAND(NEXT_OPERAND)
 #define CGV_NOP_ACTION
-    // the DMA pieces of a k-step, by gap: bf16/fp16 = 4 pieces (Q0..Q0+3) in gaps 10, 12, 14, 16; fp8 = the whole
-    // stage (8 pieces) in gaps 9..16
+    // the DMA pieces of a k-step, by gap: 4 pieces (Q0..Q0+3) in gaps 10, 12, 14, 16
 #define CGV_DMAS(G, Q0)                                                       \
     {                                                                         \
-        if constexpr (F8) {                                                   \
-            CGV_ISSUE((G)-9);                                                 \
-        } else {                                                              \
-            if ((G) == 10) CGV_ISSUE(Q0);                                     \
-            if ((G) == 12) CGV_ISSUE((Q0) + 1);                               \
-            if ((G) == 14) CGV_ISSUE((Q0) + 2);                               \
-            if ((G) == 16) CGV_ISSUE((Q0) + 3);                               \
-        }                                                                     \
+        if ((G) == 10) CGV_ISSUE(Q0);                                         \
+        if ((G) == 12) CGV_ISSUE((Q0) + 1);                                   \
+        if ((G) == 14) CGV_ISSUE((Q0) + 2);                                   \
+        if ((G) == 16) CGV_ISSUE((Q0) + 3);                                   \
     }
     // One k-step: 16 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from
-    // LDS stage NBASE (bf16/fp16: its k-step NKK); FIRST = what follows the first MFMA (the stage's counted
+    // LDS stage NBASE (its k-step NKK); FIRST = what follows the first MFMA (the stage's counted
     // wait + barrier when the next k-step starts a new stage).
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                \
     {                                                                                         \
@@ -261,24 +213,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_DMAS(15, Q0))                              \
         MMA(3, 3, FA, FB) CGV_GAP(3, 3, NA[0], CGV_DMAS(16, Q0))                              \
     }
-    // counted wait: the DMA instructions of the stages behind the one being published may stay in flight
-    // (bf16/fp16: two stages = 16; fp8: one stage = 8, the phase's own 8 pieces are issued after the wait)
+    // counted wait: the DMA instructions of the two stages behind the one being published may stay in flight
 #define CGV_STAGE_SYNC                                                                        \
-    if (!(ABL & 16)) {                                                                        \
-        if constexpr (F8)                                                                     \
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  \
-        else                                                                                  \
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                 \
-    }                                                                                         \
+    if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                        \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
-#define CGV_A_SYNC                       \
-    if constexpr (F8) { CGV_STAGE_SYNC; }
-    // bf16/fp16: A phase = k-step 0 of stage SA_ (fragments fa0/fb0), filling fa1/fb1 from the same stage's
-    //            k-step 1; B phase = k-step 1 of the previous stage (fa1/fb1), the stage barrier, filling
-    //            fa0/fb0 from stage SB_ (= SA_).
-    // fp8:       A phase = an even stage of the tile (fa0/fb0), barrier, filling fa1/fb1 from the NEXT stage
-    //            SA_; B phase = an odd stage (fa1/fb1), barrier, filling fa0/fb0 from the next stage SB_.
-#define CGV_A_PHASE(MMA, SA_) CGV_KSTEP(MMA, fa0, fb0, fa1, fb1, SA_, 1, 4, CGV_A_SYNC)
+    // A phase = k-step 0 of stage SA_ (fragments fa0/fb0), filling fa1/fb1 from the same stage's k-step 1;
+    // B phase = k-step 1 of the previous stage (fa1/fb1), the stage barrier, filling fa0/fb0 from stage SB_ (= SA_).
+#define CGV_A_PHASE(MMA, SA_) CGV_KSTEP(MMA, fa0, fb0, fa1, fb1, SA_, 1, 4, CGV_NOP_ACTION)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1))                                                                                                \
@@ -286,8 +227,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                       invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
                                                       stat_s + ((SEQ) & (NINV - 1)) * 16);
     // LDS stage the B / A phase of loop body s fills its fragments from
-    auto stage_b = [&](uint32_t s) { return smem + ((F8 ? 2 * s : s) & (NSTAGE - 1)) * STAGE; };
-    auto stage_a = [&](uint32_t s) { return smem + ((F8 ? 2 * s + 1 : s) & (NSTAGE - 1)) * STAGE; };
+    auto stage_b = [&](uint32_t s) { return smem + (s & (NSTAGE - 1)) * STAGE; };
+    auto stage_a = stage_b;
 
     // ---- prologue: side data of the first tile, three stages in flight ---------------------------------
     issue_side(t_first, 0);
@@ -310,11 +251,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // Loop body s = [B phase][A phase]; a tile is UNITS bodies and starts with an A phase (zero-C MFMAs) in the
-    // straight-line tile-boundary block. bf16/fp16: body s covers k-step 1 of stage s-1 and k-step 0 of stage s;
-    // the B phase's barrier frees slot (s-1)&3 for the DMA of stage s+3 and publishes stage s. fp8: body s covers
-    // stages 2s-1 and 2s, each phase publishing the next stage. DMA lead: 3 stages.
+    // straight-line tile-boundary block. Body s covers k-step 1 of stage s-1 and k-step 0 of stage s;
+    // the B phase's barrier frees slot (s-1)&3 for the DMA of stage s+3 and publishes stage s. DMA lead: 3 stages.
     uint32_t ct = t_first, s = 1;
-    if (!F8) { CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) }  // first half of stage 3 -> slot 3 (never used so far)
+    CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3)  // first half of stage 3 -> slot 3 (never used so far)
     CGV_A_PHASE(CGV_MMAZ, stage_a(0));
 #pragma unroll 1
     for (uint32_t u = 1; u < UNITS; ++u, ++s) {  // rest of the first tile
@@ -342,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = W4Ops<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
     __builtin_amdgcn_s_barrier();
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);

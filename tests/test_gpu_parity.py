@@ -128,6 +128,52 @@ def test_parity_medium_staged(oracle, dtype, metric):
     assert st["max_observed_err"] <= st["last_eps"]
 
 
+def test_fp8_mixed_row_scales_staged(oracle):
+    """fp8 rows and queries whose power-of-two scales differ by up to 2^40 inside every 32-row block: the
+    coarse kernel applies the scales inside the MFMA (de-scaled accumulators), so all three stages and the
+    norm-bound filter see the rows' true magnitudes. Bit-exact, fast path, no fallback."""
+    def mutate(rows, queries):
+        rng = np.random.default_rng(77)
+        rows *= np.exp2(rng.integers(-20, 21, (rows.shape[0], 1))).astype(np.float32)
+        queries *= np.exp2(rng.integers(-20, 21, (queries.shape[0], 1))).astype(np.float32)
+    st = _run(oracle, n=70_000, d=512, nq=300, k=10, dtype="fp8", metric="cosine", seed=13, mutate=mutate)
+    assert st["last_path"] == 1
+    assert st["fallback_queries"] == 0
+    assert st["max_observed_err"] <= st["last_eps"]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_one_wave_per_simd_variant(oracle, dtype):
+    """CGV_COARSE=w4 (kernels_coarse_w4.h, an opt-in A/B variant read once per process): same candidates, same
+    bit-exact results, no fallback. Runs in a child process because the switch is read at first use."""
+    import os
+    import subprocess
+    import sys
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from _util import pkg
+from oracle import oracle as o
+o.build()
+m = pkg()
+rng = np.random.default_rng(21)
+n, d, nq, k = 40_000, 1024, 300, 10
+rows = rng.standard_normal((n, d)).astype(np.float32)
+queries = rng.standard_normal((nq, d)).astype(np.float32)
+ix = m.HipKnnIndex(d, metric="cosine", dtype={dtype!r})
+ix.add(rows)
+idx, sc = ix.search(queries, k)
+st = ix.stats()
+ri, rs = o.batch_top_k(queries, rows, k, metric=0, dtype={ODT[dtype]})
+assert np.array_equal(idx, ri) and np.array_equal(sc, rs), "w4 results differ from the oracle"
+assert st["last_path"] == 1 and st["fallback_queries"] == 0, st
+print("W4-OK")
+"""
+    env = dict(os.environ, CGV_COARSE="w4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "W4-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_f32_index_with_bf16_shadow(oracle, metric):
     """CGV_DTYPE_F32_SHADOW: results are the reference's f32 arithmetic on the UNROUNDED inputs (the same
