@@ -38,6 +38,7 @@
 #include "kernels_coarse.h"
 #include "kernels_coarse_fp8.h"
 #include "kernels_coarse_w4.h"
+#include "kernels_coarse_fp8_w4.h"
 #include "kernels_exact.h"
 #include "kernels_prep.h"
 #include "kernels_select.h"
@@ -440,6 +441,7 @@ int ensure_kernel_attrs(int device) {
     CGV_ATTR((coarse_kernel<DT_FP16, true>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_w4_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
+    CGV_ATTR(coarse_fp8s_w4_kernel<0>, COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
     CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
     CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
@@ -528,13 +530,40 @@ int launch_coarse_fp8s(const CoarseArgs& a, uint32_t W, hipStream_t s) {
     return CGV_OK;
 }
 
+int launch_coarse_fp8s_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = COARSE_LDS_BYTES;
+    static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;  // timing only
+    if (abl4) {
+#define CGV_ABLK4(N)                                                                                             \
+    case N: {                                                                                                    \
+        auto k2 = coarse_fp8s_w4_kernel<N>;                                                                      \
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
+        break;                                                                                                   \
+    }
+        switch (abl4) {
+            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(9)
+            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
+        }
+#undef CGV_ABLK4
+        HIPCHK(hipGetLastError());
+        return CGV_OK;
+    }
+    hipLaunchKernelGGL(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return CGV_OK;
+}
+
 int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStream_t s) {
     if (dtype == CGV_DTYPE_BF16)
         return dump ? launch_coarse_t<DT_BF16, true>(a, W, s) : launch_coarse_t<DT_BF16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP16)
         return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
     if (dtype == CGV_DTYPE_FP8E4M3) {
-        // block-scaled K=64 MFMA kernel with the rows' power-of-two scales applied by the instruction
+        // block-scaled K=64 MFMA kernels with the rows' power-of-two scales applied by the instruction:
+        // one wave per SIMD (kernels_coarse_fp8_w4.h; even kc >= 4) or the 8-wave kernel (CGV_COARSE=w8, dumps, other kc)
+        static const bool w8 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8");
+        if (!dump && !w8 && a.kc >= 4 && (a.kc & 1u) == 0) return launch_coarse_fp8s_w4(a, W, s);
         return dump ? launch_coarse_fp8s<true>(a, W, s) : launch_coarse_fp8s<false>(a, W, s);
     }
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
