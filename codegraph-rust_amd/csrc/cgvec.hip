@@ -2,9 +2,9 @@
 //
 // Pipeline of one batched search (bf16/fp16 corpus):
 //   prep_rows(queries)                         round queries to the storage dtype, norms
-//   [stage 1] coarse(tiles [0,T1), tau=-inf) -> select      k' candidates + first tau
-//   [stage 2] coarse(strided sample, tau)    -> select      tighter tau from ~3% of the rows
-//   [stage 3] coarse(all other tiles, tau)   -> select      DOMINANT KERNEL (MFMA GEMM)
+//   [boot]    dense scores of 16 tiles spread over the corpus -> select   k' candidates + first tau
+//   [stage 1] coarse(strided sample, tau)    -> select      tighter tau from a few % of the rows
+//   [stage 2] coarse(all other tiles, tau)   -> select      DOMINANT KERNEL (MFMA GEMM)
 //   rescore                                    exact reference arithmetic on k' candidates,
 //                                              (score desc, row asc), guarantee check
 //   [fallback] exact full scan for queries whose candidate set could not be proven.
@@ -585,6 +585,7 @@ SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t ns
     sa.bn = BN;
     sa.kprime = kprime;
     sa.n_dense = n_dense;
+    sa.tau_only = 0;
     // LDS key capacity: the dense boot stage needs exactly kprime + n_dense; candidate stages get
     // the full 8192 (64 KiB) so that only pathological emission counts overflow into the exact path.
     sa.lds_keys = dense ? next_pow2(kprime + n_dense) : SELECT_LDS_KEYS;
@@ -603,9 +604,11 @@ SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t ns
 }
 
 int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
-                  const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0) {
+                  const float* dense, uint32_t n_dense, hipStream_t s, uint64_t expected = 0,
+                  bool tau_only = false) {
     size_t lds = 0;
-    const SelectArgs sa = make_select_args(c, nq, nqt, nsplit, kprime, dense, n_dense, expected, &lds);
+    SelectArgs sa = make_select_args(c, nq, nqt, nsplit, kprime, dense, n_dense, expected, &lds);
+    sa.tau_only = tau_only ? 1u : 0u;
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), lds, s, sa);
     HIPCHK(hipGetLastError());
     return CGV_OK;
@@ -678,9 +681,13 @@ __global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
     }
 }
 
-// Staged thresholds. Tiles [0, T1) are the boot tiles (dense scores by
-// boot_kernel, tau = -inf); the remaining R tiles are visited in the golden-ratio order of
-// stage_tile() in a few launches of geometrically growing size: a launch covering N rows with a
+// Staged thresholds. The first threshold comes from a SAMPLE: boot_kernel scores T1 tiles'
+// worth of rows (128 aligned 32-row groups spread over the corpus with a golden-ratio stride, boot_row())
+// densely and select_kernel publishes their k'-th best score - a valid lower bound of the final k'-th best
+// whatever the insertion order (with the first 4096 rows as the sample, a topic-sorted corpus sent 242 of 256
+// queries to the exact scan). Corpora of <= T1 tiles are covered by the boot stage alone (identity map, its
+// top-k' are the candidates). Otherwise the sample only sets tau and ALL R tiles are visited in the
+// golden-ratio order of stage_tile() (tile j = (j * P) mod R) in a few launches of geometrically growing size: a launch covering N rows with a
 // threshold learnt from C earlier rows emits about k' * N / C candidates per query, spread
 // over nsplit (workgroup, query) lists of CAND_CAPS entries — N is chosen so that the expected
 // list length stays at EMIT_TARGET and the per-query total at MERGE_TARGET. The last launch is
@@ -711,21 +718,25 @@ uint32_t gcd_u32(uint32_t a, uint32_t b) {
     return a;
 }
 
+// P ~ 0.618 R coprime to R (1 for R <= 2): j -> (j * P) mod R visits every residue once, every prefix evenly spread
+uint32_t golden_stride(uint32_t R) {
+    if (R <= 2) return 1;
+    uint32_t P = (uint32_t)((double)R * 0.6180339887498949);
+    if (P < 1) P = 1;
+    while (gcd_u32(P, R) != 1) ++P;
+    return P;
+}
+
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
     const uint32_t boot = BOOT_TILES;
     const uint32_t emit_target = kprime > 32 ? EMIT_TARGET_WIDE : EMIT_TARGET;
     p.T1 = std::min<uint32_t>(std::max<uint32_t>((kprime + BM - 1) / BM, boot), p.ntiles);
-    p.R = p.ntiles - p.T1;
-    p.P = 1;
-    if (p.R > 2) {
-        p.P = (uint32_t)((double)p.R * 0.6180339887498949);
-        if (p.P < 1) p.P = 1;
-        while (gcd_u32(p.P, p.R) != 1) ++p.P;
-    }
-    uint64_t seen = (uint64_t)p.T1 * BM;  // rows behind the current threshold
-    uint32_t left = p.R;
+    p.R = std::max<uint32_t>(p.ntiles, 1u);
+    p.P = golden_stride(p.R);
+    uint64_t seen = (uint64_t)p.T1 * BM;                    // rows behind the current threshold
+    uint32_t left = p.ntiles > p.T1 ? p.ntiles : 0;         // (<= T1 tiles: the boot stage covers them)
     while (left > 0) {
         const uint32_t nsplit = std::min<uint32_t>(left, nsplit_max);
         // rows this launch may cover: k' * N / seen / nsplit <= EMIT_TARGET
@@ -740,12 +751,12 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
 }
 
 template <int DT>
-void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, hipStream_t s) {
+void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, BootMap bmap, hipStream_t s) {
     const uint32_t nrb = (n_boot + 63) / 64, nqb = (nq + 63) / 64;
     hipLaunchKernelGGL(boot_kernel<DT>, dim3(nrb * nqb), dim3(64), 0, s,
                        (const char*)(h->shadow ? h->srows : h->rows),
                        (const char*)(h->shadow ? c->qshadow.p : c->qrows.p), (const float*)h->invn,
-                       (const float*)c->qinvn.p, n_boot, nq, h->shadow ? h->lds : h->ld, h->metric, dense,
+                       (const float*)c->qinvn.p, n_boot, nq, h->shadow ? h->lds : h->ld, h->metric, dense, bmap, (uint32_t)h->n,
                        (const int8_t*)(DT == DT_FP8 ? h->rexp : nullptr), (const int8_t*)(DT == DT_FP8 ? c->qrexp.p : nullptr));
 }
 
@@ -811,7 +822,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
         const StagePlan p = plan_stages(h->n, kprime, nsplit_max);
         const uint32_t Wmax = nqt * nsplit_max;
-        const uint32_t n_boot = (uint32_t)std::min<uint64_t>((uint64_t)p.T1 * BM, h->n);
+        // boot rows: a sample of 32-row groups when coarse launches follow (the ragged last group may be one of
+        // them: its missing rows score -inf), else the whole corpus
+        const bool sampled = !p.counts.empty();
+        const uint32_t n_boot = sampled ? p.T1 * BM : (uint32_t)h->n;
+        const uint32_t ngroups = (uint32_t)((h->n + 31) / 32);
+        const BootMap bmap{sampled ? golden_stride(ngroups) : 1u, std::max<uint32_t>(ngroups, 1u)};
         if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->nbest.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
@@ -820,15 +836,15 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         if ((rc = c->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
         if ((rc = c->dump.ensure((size_t)nq * n_boot * 4))) return rc;
 
-        // boot: dense scores of the first n_boot rows -> top-k' -> first tau
+        // boot: dense scores of the n_boot boot rows -> top-k' -> first tau
         if (h->dtype == CGV_DTYPE_BF16 || h->shadow)
-            launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), s);
+            launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
         else if (h->dtype == CGV_DTYPE_FP16)
-            launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), s);
+            launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
         else
-            launch_boot<DT_FP8>(h, c, n_boot, nq, c->dump.as<float>(), s);
+            launch_boot<DT_FP8>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
         HIPCHK(hipGetLastError());
-        if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s))) return rc;
+        if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s, 0, sampled))) return rc;
 
         const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;  // dtype the coarse pass runs in
         CoarseArgs a;
@@ -847,7 +863,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.nq = nq;
         a.ld = h->shadow ? h->lds : h->ld;
         a.kc = a.ld / kchunk_of(cdt);
-        a.T1 = p.T1;
+        a.T1 = 0;  // the visiting order covers all tiles (the boot stage was only a sample)
         a.R = p.R;
         a.P = p.P;
         a.nqt = nqt;

@@ -118,6 +118,16 @@ __host__ __device__ inline int fp8_row_exponent(float amax) {
     return e;
 }
 
+// The boot sample: logical boot row r -> corpus row. The sample is made of aligned 32-row
+// groups; group i of the sample is group (i * P) mod R of the corpus (R groups in all, P ~ 0.618 R coprime to
+// R: a golden-ratio stride, every prefix spread evenly over the corpus). P = 1: the identity.
+struct BootMap {
+    uint32_t P, R;
+};
+__host__ __device__ inline uint32_t boot_row(const BootMap& m, uint32_t r) {
+    return (uint32_t)(((uint64_t)(r >> 5) * m.P) % m.R) * 32u + (r & 31u);
+}
+
 // ---- storage layouts ---------------------------------------------------------------
 // f32 corpora: plain row-major [rows][ld] (exact path only; the reference's own layout).
 // bf16/fp16/fp8 corpora: BLOCKED layout "B32", the unit the coarse kernel streams:

@@ -595,11 +595,12 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// boot_kernel: dense coarse scores of the FIRST n_boot corpus rows against all queries,
-// straight from global memory (no LDS, no atomics): one wave = one 64 x 64 output block
-// (2 x 2 MFMA blocks), K loop unrolled so many 16-B loads are in flight. It bootstraps
+// boot_kernel: dense coarse scores of the n_boot BOOT rows (32-row groups spread over the corpus, boot_row())
+// against all queries, straight from global memory (no LDS, no atomics): one wave = one 64 x 64 output
+// block (2 x 2 MFMA blocks), K loop unrolled so many 16-B loads are in flight. It bootstraps
 // the per-query threshold tau (top-k' of n_boot scores) in ~30 us instead of running the
-// big-tile kernel on 4 workgroups. dense: [nq][n_boot].
+// big-tile kernel on 4 workgroups. dense: [nq][n_boot], column = LOGICAL boot row; rows beyond the
+// corpus (the ragged last group can be a boot group) get -inf.
 // ---------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
                                                   const float* __restrict__ invn_c,
                                                   const float* __restrict__ invn_q, uint32_t n_boot,
                                                   uint32_t nq, uint32_t ld, int metric,
-                                                  float* __restrict__ dense,
+                                                  float* __restrict__ dense, BootMap bmap, uint32_t n,
                                                   const int8_t* __restrict__ rexp_c = nullptr,
                                                   const int8_t* __restrict__ rexp_q = nullptr) {
     typedef typename Mfma<DT>::frag frag;
@@ -615,13 +616,14 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
     const uint32_t nrb = (n_boot + 63) / 64;
     const uint32_t rb = blockIdx.x % nrb, qb = blockIdx.x / nrb;
     const int hi = lane >> 5;
+    const uint32_t pbase[2] = {boot_row(bmap, rb * 64), boot_row(bmap, rb * 64 + 32)};  // corpus rows of the two 32-row groups
     const char* ap[2];
     const char* bp[2];
     uint32_t akey[2], bkey[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        uint32_t r = rb * 64 + i * 32 + (lane & 31);
-        r = r < n_boot ? r : n_boot - 1;
+        uint32_t r = pbase[i] + (lane & 31);
+        r = r < n ? r : n - 1;
         ap[i] = rows + blocked_row_base(r, ld, kchunk_of(DT));
         akey[i] = blocked_row_key(r);
         uint32_t q = qb * 64 + i * 32 + (lane & 31);
@@ -681,9 +683,10 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t row = rb * 64 + i * 32 + 8 * g4 + 4 * (lane >> 5);
-                float* dst = dense + (uint64_t)q * n_boot + row;
-                if (row + 3 < n_boot && (n_boot & 3u) == 0) {
+                const uint32_t lrow = rb * 64 + i * 32 + 8 * g4 + 4 * (lane >> 5);  // dense column
+                const uint32_t row = pbase[i] + 8 * g4 + 4 * (lane >> 5);           // corpus row
+                float* dst = dense + (uint64_t)q * n_boot + lrow;
+                if (lrow + 3 < n_boot && row + 3 < n && (n_boot & 3u) == 0) {
                     float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2],
                                            acc[i][j][4 * g4 + 3]);
                     if (metric != METRIC_DOT) {
@@ -704,11 +707,15 @@ __global__ __launch_bounds__(64) void boot_kernel(const char* __restrict__ rows,
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        if (row + t < n_boot) {
-                            const float v = acc[i][j][4 * g4 + t];
-                            float ic = invn_c[row + t];
-                            if (DT == DT_FP8 && rexp_c) ic = ldexpf(ic, -(int)rexp_c[row + t]);
-                            dst[t] = (metric == METRIC_DOT) ? v : v * ic * iq;
+                        if (lrow + t < n_boot) {
+                            if (row + t < n) {
+                                const float v = acc[i][j][4 * g4 + t];
+                                float ic = invn_c[row + t];
+                                if (DT == DT_FP8 && rexp_c) ic = ldexpf(ic, -(int)rexp_c[row + t]);
+                                dst[t] = (metric == METRIC_DOT) ? v : v * ic * iq;
+                            } else {
+                                dst[t] = -INFINITY;
+                            }
                         }
                 }
             }

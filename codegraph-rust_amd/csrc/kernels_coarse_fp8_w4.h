@@ -229,6 +229,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_DMAS(15, Q0))                              \
         MMA(3, 3, FA, FB) CGV_GAP(3, 3, NA[0], CGV_DMAS(16, Q0))                              \
     }
+    // The tile boundary: the zero-C k-step of the NEXT tile with the epilogue of the PREVIOUS one folded into its
+    // gaps, block by block: copy the block's 16 accumulators to VGPRs (v_accvgpr_read), issue the zero-C MFMA that
+    // overwrites them, and run the fast filter (+ the cold slow path) on the copy while that MFMA occupies the
+    // matrix pipe for 64 cycles. With one wave per SIMD nothing else would cover the epilogue's ~500 VALU
+    // instructions per tile (measured: 2.2 of 12.5 ms on the C5-mini main launch when run as a separate block).
+    f32x16_t etmp;
+    float emn[MB], emx[MB];
+    uint32_t ep_tile = 0, ep_row0 = 0;
+    const float* ep_invn = invn_s;
+#define CGV_EPI_READ(MBI, NBI)                          \
+    if (!(ABL & 1)) {                                   \
+        etmp = acc[MBI][NBI];                           \
+        asm volatile("" : "+v"(etmp)::"memory");        \
+    }
+#define CGV_EPI_TEST(MBI, NBI)                                                                                        \
+    if (!(ABL & 1)) {                                                                                                 \
+        const float t_ = block_threshold(a, tq[NBI], emn[MBI], emx[MBI]);                                             \
+        if (__builtin_expect(ep_row0 + (uint32_t)((MBI) * 32) < a.n && block_max(etmp) > t_, 0))                      \
+            block_hits<BM, BN>(a, etmp, t_, tauv[NBI], invq[NBI], (uint32_t)(wm * WTM + (MBI) * 32),                  \
+                               (uint32_t)(wn * WTN + (NBI) * 32 + (lane & 31)), ep_tile, lane, g, qt, cntq, ep_invn); \
+    }
+#define CGV_EGAP(MBI, NBI, NEXT_OPERAND, ACTION)                       \
+    asm volatile("" : "+a"(acc[MBI][NBI])::"memory");                  \
+    ACTION;                                                            \
+    CGV_EPI_TEST(MBI, NBI)                                             \
+    CGV_PIN_OPERAND(NEXT_OPERAND)
+#define CGV_KSTEP_EPI(FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                   \
+    {                                                                                                           \
+        CGV_PIN_ALL(FA, FB)                                                                                     \
+        CGV_EPI_READ(0, 0) CGV_MMAZ(0, 0, FA, FB) CGV_EGAP(0, 0, FB[1], FIRST; CGV_LDA(NA, 0, NBASE, NKK))      \
+        CGV_EPI_READ(0, 1) CGV_MMAZ(0, 1, FA, FB) CGV_EGAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK))            \
+        CGV_EPI_READ(0, 2) CGV_MMAZ(0, 2, FA, FB) CGV_EGAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK))            \
+        CGV_EPI_READ(0, 3) CGV_MMAZ(0, 3, FA, FB) CGV_EGAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK))            \
+        CGV_EPI_READ(1, 0) CGV_MMAZ(1, 0, FA, FB) CGV_EGAP(1, 0, FB[1], CGV_LDB(NB_, 3, NBASE, NKK))            \
+        CGV_EPI_READ(1, 1) CGV_MMAZ(1, 1, FA, FB) CGV_EGAP(1, 1, FB[2], CGV_LDA(NA, 1, NBASE, NKK))             \
+        CGV_EPI_READ(1, 2) CGV_MMAZ(1, 2, FA, FB) CGV_EGAP(1, 2, FB[3], CGV_LDA(NA, 2, NBASE, NKK))             \
+        CGV_EPI_READ(1, 3) CGV_MMAZ(1, 3, FA, FB) CGV_EGAP(1, 3, FA[2], CGV_LDA(NA, 3, NBASE, NKK))             \
+        CGV_EPI_READ(2, 0) CGV_MMAZ(2, 0, FA, FB) CGV_EGAP(2, 0, FB[1], CGV_DMAS(9, Q0))                        \
+        CGV_EPI_READ(2, 1) CGV_MMAZ(2, 1, FA, FB) CGV_EGAP(2, 1, FB[2], CGV_DMAS(10, Q0))                       \
+        CGV_EPI_READ(2, 2) CGV_MMAZ(2, 2, FA, FB) CGV_EGAP(2, 2, FB[3], CGV_DMAS(11, Q0))                       \
+        CGV_EPI_READ(2, 3) CGV_MMAZ(2, 3, FA, FB) CGV_EGAP(2, 3, FA[3], CGV_DMAS(12, Q0))                       \
+        CGV_EPI_READ(3, 0) CGV_MMAZ(3, 0, FA, FB) CGV_EGAP(3, 0, FB[1], CGV_DMAS(13, Q0))                       \
+        CGV_EPI_READ(3, 1) CGV_MMAZ(3, 1, FA, FB) CGV_EGAP(3, 1, FB[2], CGV_DMAS(14, Q0))                       \
+        CGV_EPI_READ(3, 2) CGV_MMAZ(3, 2, FA, FB) CGV_EGAP(3, 2, FB[3], CGV_DMAS(15, Q0))                       \
+        CGV_EPI_READ(3, 3) CGV_MMAZ(3, 3, FA, FB) CGV_EGAP(3, 3, NA[0], CGV_DMAS(16, Q0))                       \
+    }
     // counted wait: the DMA instructions of the stage behind the one being published may stay in flight
     // (one stage = 8; the phase's own 8 pieces are issued after the wait)
 #define CGV_STAGE_SYNC                                  \
@@ -287,10 +333,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const uint32_t nt = next_tile(ct);
             issue_side(nt, tl);                   // the tile that starts here
             issue_rexp(next_tile(nt), tl + 1);    // exponents of the one after it
-            CGV_EPILOGUE(a.T1 + ct, tl - 1);
+            // epilogue of tile ct (sequence number tl - 1), folded into the zero-C k-step of tile nt
+            ep_tile = a.T1 + ct;
+            ep_row0 = ep_tile * (uint32_t)BM + (uint32_t)(wm * WTM);
+            ep_invn = invn_s + ((tl - 1) & (NINV - 1)) * 256;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                emn[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + (wm * WTM) / 32 + mb];
+                emx[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + 8 + (wm * WTM) / 32 + mb];
+            }
             ct = nt;
             load_sa(tl);  // issued at the previous boundary: a whole tile of counted waits + barriers ago
-            CGV_A_PHASE(CGV_MMAZ, stage_a(s));
+            CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, stage_a(s), 1, 4, CGV_STAGE_SYNC);
             ++s;
         }
 #pragma unroll 1
@@ -316,6 +370,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CGV_A_PHASE
 #undef CGV_STAGE_SYNC
 #undef CGV_KSTEP
+#undef CGV_KSTEP_EPI
+#undef CGV_EGAP
+#undef CGV_EPI_TEST
+#undef CGV_EPI_READ
 #undef CGV_DMAS
 #undef CGV_NOP_ACTION
 #undef CGV_GAP

@@ -19,6 +19,7 @@ struct SelectArgs {
     float* tau;                // [nq]
     uint32_t* overflow;        // [nq]
     uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
+    uint32_t tau_only;         // dense scores of a SAMPLE of the corpus: publish tau, keep no candidates
 };
 
 // ---- shared pieces of the select / final kernels ------------------------------------
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
         merge4(part, keep0, outk, tid);
         for (uint32_t i = tid; i < keep0; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
         if (tid == 0) {
-            a.nbest[q] = keep0;
+            a.nbest[q] = a.tau_only ? 0u : keep0;
             a.tau[q] = (M0 >= a.kprime) ? key_score(outk[a.kprime - 1]) : -INFINITY;
         }
         return;
@@ -250,8 +251,11 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
         extract_topk(keys, M, keep, part, outk, tid);
         for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
         if (tid == 0) {
-            a.nbest[q] = keep;
-            a.tau[q] = (M >= a.kprime) ? key_score(outk[a.kprime - 1]) : -INFINITY;
+            a.nbest[q] = a.tau_only ? 0u : keep;
+            // fewer than k' keys: nothing was cut HERE, the threshold the launches used so far stays (candidate
+            // stages; the dense boot stage starts from nothing: -inf)
+            if (M >= a.kprime) a.tau[q] = key_score(outk[a.kprime - 1]);
+            else if (a.dense) a.tau[q] = -INFINITY;
             if (trunc) a.overflow[q] = 1u;
         }
     } else {
@@ -261,8 +265,9 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
         bitonic_sort_desc<256>(keys, P, tid);
         for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = keys[i];
         if (tid == 0) {
-            a.nbest[q] = keep;
-            a.tau[q] = (M >= a.kprime) ? key_score(keys[a.kprime - 1]) : -INFINITY;
+            a.nbest[q] = a.tau_only ? 0u : keep;
+            if (M >= a.kprime) a.tau[q] = key_score(keys[a.kprime - 1]);
+            else if (a.dense) a.tau[q] = -INFINITY;
             if (trunc) a.overflow[q] = 1u;
         }
     }
@@ -389,12 +394,10 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     if (tid == 0) {
         atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
-        if (tau > -INFINITY && nb > 0) {  // candidates were truncated: check the guarantee
-            const uint32_t kk = a.k < nb ? a.k : nb;
-            const float ek = key_score(ekeys[kk - 1]);
+        if (tau > -INFINITY) {  // rows at or below tau were dropped: check the guarantee
             if (a.stat_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
-            if (!(ek > tau + eps)) fb = true;
-            if (nb < a.k) fb = true;
+            if (nb < a.k) fb = true;  // (the corpus has more rows than candidates survived)
+            else if (!(key_score(ekeys[a.k - 1]) > tau + eps)) fb = true;
             if (tripped) fb = true;
         }
         a.fb_flag[q] = fb ? 1u : 0u;
@@ -434,7 +437,8 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     const uint32_t keep = M < sa.kprime ? M : sa.kprime;
     extract_topk(keys, M, keep, part, outk, tid);
     for (uint32_t i = tid; i < keep; i += 256) ckeys[i] = outk[i];
-    const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : -INFINITY;
+    // fewer than k' keys: nothing is cut here, but the coarse launches dropped every row at or below THEIR threshold
+    const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
     const bool overflow = trunc || sa.overflow[q] != 0;
     __syncthreads();
     rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, tid);

@@ -147,3 +147,34 @@ def test_two_devices_in_one_process_get_their_kernel_attributes():
         outs.append(ix.search(q, 10))
         ix.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dtype,odt", [("bf16", 1), ("fp8", 3)])
+def test_topic_sorted_corpus_keeps_the_fast_path(oracle, dtype, odt):
+    """Insertion order must not matter for speed either: a corpus SORTED by topic (16 tight clusters, one after
+    the other) with queries from every topic. If the first threshold came from the first 4096 rows (one topic),
+    a query from another topic would see its whole cluster (6 % of the rows, cosine ~0.8) pass the first
+    launches and overflow into the exact scan. The boot sample is spread over the corpus with the same
+    golden-ratio stride as the later stages: no fallback, results bit-equal to the oracle."""
+    m = pkg()
+    rng = np.random.default_rng(404)
+    d, ncl, per, nq, k = 256, 16, 12_500, 256, 10
+    cent = rng.standard_normal((ncl, d)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    noise = rng.standard_normal((ncl * per, d)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    rows = np.repeat(cent, per, axis=0) + np.float32(0.5) * noise          # sorted by topic
+    qn = rng.standard_normal((nq, d)).astype(np.float32)
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    queries = cent[rng.integers(0, ncl, nq)] + np.float32(0.5) * qn
+    ix = m.HipKnnIndex(d, metric="cosine", dtype=dtype)
+    try:
+        ix.add(rows)
+        idx, sc = ix.search(queries, k)
+        st = ix.stats()
+        ri, rs = oracle.batch_top_k(queries, rows, k, metric=0, dtype=odt)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        assert st["last_path"] == 1
+        assert st["fallback_queries"] == 0, st
+    finally:
+        ix.close()
