@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define CGV_NOP_ACTION
     // the DMA pieces of a stage, by gap: all 8 pieces in gaps 9..16
 #define CGV_DMAS(G, Q0) CGV_ISSUE((G)-9)
-    // One k-step: 16 MFMAs on fragments FA/FB; NA/NB (the other buffer) are filled for the next k-step from
+    // One k-step: 16 MFMAs on fragments FA/FB in serpentine block order (consecutive MFMAs share one operand block); NA/NB (the other buffer) are filled for the next k-step from
     // LDS stage NBASE; FIRST = what follows the first MFMA (the stage's counted
     // wait + barrier when the next k-step starts a new stage).
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                \
@@ -216,18 +216,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         MMA(0, 1, FA, FB) CGV_GAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK))                   \
         MMA(0, 2, FA, FB) CGV_GAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK))                   \
         MMA(0, 3, FA, FB) CGV_GAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK))                   \
-        MMA(1, 0, FA, FB) CGV_GAP(1, 0, FB[1], CGV_LDB(NB_, 3, NBASE, NKK))                   \
-        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[2], CGV_LDA(NA, 1, NBASE, NKK))                    \
-        MMA(1, 2, FA, FB) CGV_GAP(1, 2, FB[3], CGV_LDA(NA, 2, NBASE, NKK))                    \
-        MMA(1, 3, FA, FB) CGV_GAP(1, 3, FA[2], CGV_LDA(NA, 3, NBASE, NKK))                    \
+        MMA(1, 3, FA, FB) CGV_GAP(1, 3, FB[2], CGV_LDB(NB_, 3, NBASE, NKK))                   \
+        MMA(1, 2, FA, FB) CGV_GAP(1, 2, FB[1], CGV_LDA(NA, 1, NBASE, NKK))                    \
+        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], CGV_LDA(NA, 2, NBASE, NKK))                    \
+        MMA(1, 0, FA, FB) CGV_GAP(1, 0, FA[2], CGV_LDA(NA, 3, NBASE, NKK))                    \
         MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_DMAS(9, Q0))                               \
         MMA(2, 1, FA, FB) CGV_GAP(2, 1, FB[2], CGV_DMAS(10, Q0))                              \
         MMA(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_DMAS(11, Q0))                              \
         MMA(2, 3, FA, FB) CGV_GAP(2, 3, FA[3], CGV_DMAS(12, Q0))                              \
-        MMA(3, 0, FA, FB) CGV_GAP(3, 0, FB[1], CGV_DMAS(13, Q0))                              \
-        MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[2], CGV_DMAS(14, Q0))                              \
-        MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[3], CGV_DMAS(15, Q0))                              \
-        MMA(3, 3, FA, FB) CGV_GAP(3, 3, NA[0], CGV_DMAS(16, Q0))                              \
+        MMA(3, 3, FA, FB) CGV_GAP(3, 3, FB[2], CGV_DMAS(13, Q0))                              \
+        MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[1], CGV_DMAS(14, Q0))                              \
+        MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[0], CGV_DMAS(15, Q0))                              \
+        MMA(3, 0, FA, FB) CGV_GAP(3, 0, NA[0], CGV_DMAS(16, Q0))                              \
     }
     // The tile boundary: the zero-C k-step of the NEXT tile with the epilogue of the PREVIOUS one folded into its
     // gaps, block by block: copy the block's 16 accumulators to VGPRs (v_accvgpr_read), issue the zero-C MFMA that
@@ -262,18 +262,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         CGV_EPI_READ(0, 1) CGV_MMAZ(0, 1, FA, FB) CGV_EGAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK))            \
         CGV_EPI_READ(0, 2) CGV_MMAZ(0, 2, FA, FB) CGV_EGAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK))            \
         CGV_EPI_READ(0, 3) CGV_MMAZ(0, 3, FA, FB) CGV_EGAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK))            \
-        CGV_EPI_READ(1, 0) CGV_MMAZ(1, 0, FA, FB) CGV_EGAP(1, 0, FB[1], CGV_LDB(NB_, 3, NBASE, NKK))            \
-        CGV_EPI_READ(1, 1) CGV_MMAZ(1, 1, FA, FB) CGV_EGAP(1, 1, FB[2], CGV_LDA(NA, 1, NBASE, NKK))             \
-        CGV_EPI_READ(1, 2) CGV_MMAZ(1, 2, FA, FB) CGV_EGAP(1, 2, FB[3], CGV_LDA(NA, 2, NBASE, NKK))             \
-        CGV_EPI_READ(1, 3) CGV_MMAZ(1, 3, FA, FB) CGV_EGAP(1, 3, FA[2], CGV_LDA(NA, 3, NBASE, NKK))             \
+        CGV_EPI_READ(1, 3) CGV_MMAZ(1, 3, FA, FB) CGV_EGAP(1, 3, FB[2], CGV_LDB(NB_, 3, NBASE, NKK))            \
+        CGV_EPI_READ(1, 2) CGV_MMAZ(1, 2, FA, FB) CGV_EGAP(1, 2, FB[1], CGV_LDA(NA, 1, NBASE, NKK))             \
+        CGV_EPI_READ(1, 1) CGV_MMAZ(1, 1, FA, FB) CGV_EGAP(1, 1, FB[0], CGV_LDA(NA, 2, NBASE, NKK))             \
+        CGV_EPI_READ(1, 0) CGV_MMAZ(1, 0, FA, FB) CGV_EGAP(1, 0, FA[2], CGV_LDA(NA, 3, NBASE, NKK))             \
         CGV_EPI_READ(2, 0) CGV_MMAZ(2, 0, FA, FB) CGV_EGAP(2, 0, FB[1], CGV_DMAS(9, Q0))                        \
         CGV_EPI_READ(2, 1) CGV_MMAZ(2, 1, FA, FB) CGV_EGAP(2, 1, FB[2], CGV_DMAS(10, Q0))                       \
         CGV_EPI_READ(2, 2) CGV_MMAZ(2, 2, FA, FB) CGV_EGAP(2, 2, FB[3], CGV_DMAS(11, Q0))                       \
         CGV_EPI_READ(2, 3) CGV_MMAZ(2, 3, FA, FB) CGV_EGAP(2, 3, FA[3], CGV_DMAS(12, Q0))                       \
-        CGV_EPI_READ(3, 0) CGV_MMAZ(3, 0, FA, FB) CGV_EGAP(3, 0, FB[1], CGV_DMAS(13, Q0))                       \
-        CGV_EPI_READ(3, 1) CGV_MMAZ(3, 1, FA, FB) CGV_EGAP(3, 1, FB[2], CGV_DMAS(14, Q0))                       \
-        CGV_EPI_READ(3, 2) CGV_MMAZ(3, 2, FA, FB) CGV_EGAP(3, 2, FB[3], CGV_DMAS(15, Q0))                       \
-        CGV_EPI_READ(3, 3) CGV_MMAZ(3, 3, FA, FB) CGV_EGAP(3, 3, NA[0], CGV_DMAS(16, Q0))                       \
+        CGV_EPI_READ(3, 3) CGV_MMAZ(3, 3, FA, FB) CGV_EGAP(3, 3, FB[2], CGV_DMAS(13, Q0))                       \
+        CGV_EPI_READ(3, 2) CGV_MMAZ(3, 2, FA, FB) CGV_EGAP(3, 2, FB[1], CGV_DMAS(14, Q0))                       \
+        CGV_EPI_READ(3, 1) CGV_MMAZ(3, 1, FA, FB) CGV_EGAP(3, 1, FB[0], CGV_DMAS(15, Q0))                       \
+        CGV_EPI_READ(3, 0) CGV_MMAZ(3, 0, FA, FB) CGV_EGAP(3, 0, NA[0], CGV_DMAS(16, Q0))                       \
     }
     // counted wait: the DMA instructions of the stage behind the one being published may stay in flight
     // (one stage = 8; the phase's own 8 pieces are issued after the wait)
