@@ -93,6 +93,9 @@ struct DevBuf {
 };
 
 enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_MAXEPS, F_COUNT = 8 };
+// a search context's flag words are followed by the coarse kernels' pacing words (kernels_coarse.h: Pace), one
+// per workgroup, cleared together with the flags at the start of every search
+constexpr uint32_t PACE_WORDS = 1024;
 
 constexpr int BM = 256, BN = 256;  // coarse tile (corpus rows x queries)
 
@@ -776,7 +779,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     c->timed_coarse = false;
     c->coarse_rows = 0;
     c->kprime = 0;
-    HIPCHK(hipMemsetAsync(c->flags, 0, F_COUNT * 4, s));
+    HIPCHK(hipMemsetAsync(c->flags, 0, (F_COUNT + PACE_WORDS) * 4, s));
     if (h->n == 0) {
         uint64_t tot = (uint64_t)nq * k;
         hipLaunchKernelGGL(pad_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, out_idx,
@@ -871,6 +874,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.qgroup = query_group(nqt, a.ld, cdt);
         a.rexp_c = h->rexp;
         a.rexp_q = c->qrexp.as<int8_t>();
+        static const bool no_pace = getenv("CGV_NO_PACE") != nullptr;  // A/B switch
+        a.pace = (Wmax <= PACE_WORDS && !no_pace) ? c->flags + F_COUNT : nullptr;
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
         uint32_t last_nsplit = 0;
@@ -1153,9 +1158,9 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
-        if (e == hipSuccess) e = hipMalloc((void**)&c.flags, F_COUNT * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&c.flags, (F_COUNT + PACE_WORDS) * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4);
-        if (e == hipSuccess) e = hipMemset(c.flags, 0, F_COUNT * 4);
+        if (e == hipSuccess) e = hipMemset(c.flags, 0, (F_COUNT + PACE_WORDS) * 4);
     }
     if (e == hipSuccess) e = hipMemset(h->flags, 0, F_COUNT * 4);
     if (e == hipSuccess) e = hipMemset(h->max_norm_dev, 0, 4);
@@ -1901,6 +1906,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.qgroup = query_group(nqt, a.ld, cdt);
     a.rexp_c = h->rexp;
     a.rexp_q = c->qrexp.as<int8_t>();
+    a.pace = nullptr;
     if ((rc = launch_coarse(cdt, true, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;

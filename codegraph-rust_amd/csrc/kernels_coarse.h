@@ -93,6 +93,7 @@ struct CoarseArgs {
     uint32_t qgroup;        // query tiles that share one XCD (block_to_work); 0 = all of them
     const int8_t* rexp_c;   // fp8 only: [n] per-row power-of-two scale exponents of the corpus ...
     const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
+    uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -124,6 +125,45 @@ __device__ inline uint32_t block_to_work(const CoarseArgs& a, uint32_t& qt, uint
     qt = g % a.nqt;
     split = g / a.nqt;
     return g;
+}
+
+// Soft lockstep of the workgroups that stream the SAME corpus split for different query tiles of one XCD group
+// (block_to_work: logical ids g - qt % G .. + G - 1). They read the same tiles in the same order and only share
+// them through the XCD's L2 while they stay within a few tiles of each other - and nothing keeps them there: a
+// leader's misses are hidden by the 3-stage DMA lead, so it is never slowed down, and over the 1000+ tiles of a
+// C5 launch the group drifts apart until every member streams its own copy from HBM (PMC, c5mini main launch,
+// one-wave fp8 kernel: 43 GB fetched for 1.7 GB of corpus x 4 groups, L2 hit rate 0.69). So at every tile
+// boundary wave 0 publishes the workgroup's tile count and waits (bounded: never more than ~20 us, whatever the
+// others do) while an ACTIVE member of its group is more than PACE_WINDOW tiles behind; the other waves wait for
+// it at the stage barrier. Work is partitioned statically, so holding a leader back costs nothing: the launch
+// ends with its slowest workgroup either way. 0 = not started / finished (never waited for): the words are zero
+// at the start of every search (memset with the flags) and each workgroup clears its own at exit.
+constexpr uint32_t PACE_WINDOW = 2;
+struct Pace {
+    uint32_t* me;         // NULL: pacing off
+    const uint32_t* grp;  // the group's G consecutive words
+    uint32_t G;
+};
+__device__ inline Pace pace_init(const CoarseArgs& a, uint32_t g, uint32_t qt) {
+    Pace p;
+    p.G = a.qgroup ? a.qgroup : a.nqt;
+    const bool on = a.pace != nullptr && p.G > 1 && p.G <= 64 && a.nqt % p.G == 0;
+    p.me = on ? a.pace + g : nullptr;
+    p.grp = on ? a.pace + (g - qt % p.G) : nullptr;
+    return p;
+}
+// called by ONE wave; tiles = tiles this workgroup has started (>= 1)
+__device__ inline void pace_step(const Pace& p, uint32_t tiles, int lane) {
+    if (!p.me) return;
+    if (lane == 0) __hip_atomic_store(p.me, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int it = 0; it < 64; ++it) {
+        const uint32_t v = (uint32_t)lane < p.G ? __hip_atomic_load(p.grp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (!__any(v != 0u && v + PACE_WINDOW < tiles)) break;
+        __builtin_amdgcn_s_sleep(8);  // 512 cycles
+    }
+}
+__device__ inline void pace_done(const Pace& p) {
+    if (p.me) __hip_atomic_store(p.me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Order in which the corpus tiles beyond the boot tiles are visited: tile j of
@@ -324,6 +364,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 
     uint32_t qt, split;
     const uint32_t g = block_to_work(a, qt, split);
+    const Pace pace = pace_init(a, g, qt);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 
@@ -550,6 +591,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
             CGV_B_PHASE(sb);
+            if (wave == 0) pace_step(pace, tl + 1, lane);
             const uint32_t nt = next_tile(ct);
             side_wait();
             CGV_EPILOGUE(a.T1 + ct, tl - 1);
@@ -589,6 +631,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #undef CGV_BDMA
 
     __syncthreads();
+    if (tid == 0) pace_done(pace);
     for (int i = tid; i < BN; i += NT) {
         const uint32_t c = cntq[i];
         a.cand_cnt[(uint64_t)g * BN + i] = c < CAND_CAPS ? c : CAND_CAPS;

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     uint32_t qt, split;
     const uint32_t g = block_to_work(a, qt, split);
+    const Pace pace = pace_init(a, g, qt);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
             CGV_B_PHASE(stage_b(s));
+            if (wave == 0) pace_step(pace, tl + 1, lane);  // keep the split's workgroups within the L2's reach
             const uint32_t nt = next_tile(ct);
             issue_side(nt, tl);                   // the tile that starts here
             issue_rexp(next_tile(nt), tl + 1);    // exponents of the one after it
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CGV_DMA
 
     __syncthreads();
+    if (tid == 0) pace_done(pace);
     for (int i = tid; i < BN; i += NT) {
         const uint32_t c = cntq[i];
         a.cand_cnt[(uint64_t)g * BN + i] = c < CAND_CAPS ? c : CAND_CAPS;
