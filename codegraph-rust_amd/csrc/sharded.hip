@@ -496,22 +496,32 @@ int cgv_sharded_search_f32(cgv_sharded* s, const float* queries_host, uint32_t n
             if ((rc = cgv_pack_topk_dev(sh->device, (const uint64_t*)sh->oidx.p, (const float*)sh->osc.p, nq, k,
                                         (uint32_t*)sh->rec.p, sh->xs)))
                 return rc;
-            if (exchange == CGV_EXCHANGE_RCCL) {
-                const int e = rccl->AllGather(sh->rec.p, sh->gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
-                if (e != 0) return fail(CGV_ERR_HIP, std::string("ncclAllGather: ") + rccl->GetErrorString(e));
-            } else {
-                char* dst = (char*)root->gathered.p + (size_t)g * rec_bytes;
-                if (sh->device == root->device)
-                    SHIP(hipMemcpyAsync(dst, sh->rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs));
-                else
-                    SHIP(hipMemcpyPeerAsync(dst, root->device, sh->rec.p, sh->device, rec_bytes, sh->xs));
-            }
+            if (exchange == CGV_EXCHANGE_RCCL) return CGV_OK;  // the collective is entered below, by ALL shards or none
+            char* dst = (char*)root->gathered.p + (size_t)g * rec_bytes;
+            if (sh->device == root->device)
+                SHIP(hipMemcpyAsync(dst, sh->rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs));
+            else
+                SHIP(hipMemcpyPeerAsync(dst, root->device, sh->rec.p, sh->device, rec_bytes, sh->xs));
             SHIP(hipStreamSynchronize(sh->xs));
             return CGV_OK;
         };
     }
     int rc = run_all(s, jobs);
     if (rc) return rc;
+    if (G > 1 && exchange == CGV_EXCHANGE_RCCL) {
+        // A collective that one rank never enters hangs the others: it is only started once every shard's search
+        // and pack were enqueued without error (a failed shard returned above, before anyone called into RCCL).
+        for (uint32_t g = 0; g < G; ++g) {
+            Shard* sh = s->sh[g];
+            jobs[g] = [=]() -> int {
+                const int e = rccl->AllGather(sh->rec.p, sh->gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                if (e != 0) return fail(CGV_ERR_HIP, std::string("ncclAllGather: ") + rccl->GetErrorString(e));
+                SHIP(hipStreamSynchronize(sh->xs));
+                return CGV_OK;
+            };
+        }
+        if ((rc = run_all(s, jobs))) return rc;
+    }
     auto t1 = s->sh[0]->t_search_done;
     for (Shard* sh : s->sh) t1 = std::max(t1, sh->t_search_done);
     SHIP(hipSetDevice(root->device));
