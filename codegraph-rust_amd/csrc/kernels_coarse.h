@@ -166,10 +166,10 @@ __device__ inline void pace_done(const Pace& p) {
     if (p.me) __hip_atomic_store(p.me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Order in which the corpus tiles beyond the boot tiles are visited: tile j of
-// the sequence is T1 + (j * P) mod R with P ~ 0.618 R coprime to R (a golden-ratio stride), so
-// EVERY prefix of the sequence is spread evenly over the corpus: each threshold stage is a
-// representative sample of the rows still to come, whatever the insertion order of the corpus.
+// Order in which the corpus tiles are visited: tile j of the sequence is T1 + (j * P) mod R
+// with P ~ 0.618 R coprime to R (a golden-ratio stride), so EVERY prefix of the sequence is spread evenly over
+// the corpus: each threshold stage is a representative sample of the rows still to come, whatever the insertion
+// order of the corpus. (The host passes T1 = 0, R = all tiles: the boot stage is a sample of its own, boot_row().)
 __host__ __device__ inline uint32_t stage_tile(uint32_t T1, uint32_t R, uint32_t P, uint32_t j) {
     return T1 + (uint32_t)(((uint64_t)j * P) % R);
 }
