@@ -384,9 +384,12 @@ int ingest_finish(cgv_index* h, uint64_t n_new) {
     HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT, h->max_norm_dev, 4, hipMemcpyDeviceToHost, s));
     if (h->shadow) HIPCHK(hipMemcpyAsync(h->h_flags + F_COUNT + 1, h->resmax_dev, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (h->h_flags[F_NONFINITE_C])  // nothing is published; the caller rolls back to its snapshot
+    if (h->h_flags[F_NONFINITE_C] & 1u)  // nothing is published; the caller rolls back to its snapshot
         return fail(CGV_ERR_NONFINITE,
                     "corpus rows contain NaN/Inf (the reference panics on NaN at simd_ops.rs:379); the add was not applied");
+    if (h->h_flags[F_NONFINITE_C] & 2u)
+        return fail(CGV_ERR_INVALID_ARG,
+                    "fp8 storage: a row's largest magnitude is outside [2^-48, 2^48]; the add was not applied");
     h->n = n_new;
     memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
     if (h->shadow) {
@@ -1000,8 +1003,10 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     int rc;
     if ((rc = wait_stream(s))) return rc;
     c->rewrote = false;
-    if (c->h_flags[F_NONFINITE_Q])
+    if (c->h_flags[F_NONFINITE_Q] & 1u)
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
+    if (c->h_flags[F_NONFINITE_Q] & 2u)
+        return fail(CGV_ERR_INVALID_ARG, "fp8 index: a query's largest magnitude is outside [2^-48, 2^48]");
     uint32_t nfb = 0;
     float me = 0.0f;
     if (!c->mfma) {
@@ -1434,6 +1439,13 @@ int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     for (uint32_t i = 0; i < h->D; ++i)  // checked BEFORE the stored row is overwritten: a rejected update changes nothing
         if (!(fabsf(row_host[i]) <= 3.402823466e38f))
             return fail(CGV_ERR_NONFINITE, "row contains NaN/Inf (the reference panics on NaN at simd_ops.rs:379); not applied");
+    if (h->dtype == CGV_DTYPE_FP8E4M3) {
+        float amax = 0.0f;
+        for (uint32_t i = 0; i < h->D; ++i) amax = std::max(amax, fabsf(row_host[i]));
+        const int e = fp8_row_exponent(amax);
+        if (e < FP8_EXP_MIN || e > FP8_EXP_MAX)
+            return fail(CGV_ERR_INVALID_ARG, "fp8 storage: the row's largest magnitude is outside [2^-48, 2^48]; not applied");
+    }
     HIPCHK(hipSetDevice(h->device));
     int rc;
     if ((rc = h->addstage.ensure((size_t)h->D * 4))) return rc;

@@ -104,6 +104,10 @@ __host__ __device__ inline float e4m3_to_f32(uint8_t b) {
     __builtin_memcpy(&r, &u, 4);
     return r;
 }
+// fp8 rows are accepted when their largest magnitude lies in [2^-48, 2^48] (or the row is zero): the coarse pass
+// accumulates de-scaled dot products in f32 (kernels_coarse_fp8.h), which two rows at 2^64 would overflow - outside
+// that range an add / update / query is rejected with CGV_ERR_INVALID_ARG instead of being answered unsafely.
+constexpr int FP8_EXP_MIN = -40, FP8_EXP_MAX = 56;  // exponents of amax = 2^48 .. 2^-48 (amax * 2^e in (224, 448])
 // Per-row power-of-two scale exponent of the fp8 storage: largest e with amax * 2^e <= 448
 // (integer logic; pure bit arithmetic, no libm).
 __host__ __device__ inline int fp8_row_exponent(float amax) {

@@ -16,7 +16,8 @@ namespace cgv {
 // fp8 rows are stored scaled by their own power of two (rexp[r], common.h); norm / invn are those of the
 // de-scaled stored values (code * 2^-e), the domain the scaled MFMA of the coarse pass accumulates in.
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
-// coarse pass), invn[r] = 1/norm or 0. nonfinite: set to 1 if any input is NaN/Inf.
+// coarse pass), invn[r] = 1/norm or 0. nonfinite: bit 0 set if any input is NaN/Inf, bit 1 if an fp8 row's
+// magnitude is outside the supported range.
 template <int DT>
 __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ in, uint64_t n,
                                                         uint32_t D, uint32_t ld, uint64_t row0,
@@ -45,9 +46,10 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     }
     float ss = 0.0f;
     int bad = 0;
+    if (DT == DT_FP8 && (e < FP8_EXP_MIN || e > FP8_EXP_MAX)) bad = 2;  // magnitude outside the supported range (common.h)
     for (uint32_t i = lane; i < ld; i += 64) {
         float x = (i < D) ? src[i] : 0.0f;
-        if (!(fabsf(x) <= 3.402823466e38f)) bad = 1;  // NaN or Inf
+        if (!(fabsf(x) <= 3.402823466e38f)) bad |= 1;  // NaN or Inf
         if (DT == DT_FP8) x = ldexpf(x, e);            // exact
         Elem<DT>::cvt_store(elem_ptr<DT>(out, row0 + row, ld, i), x);
         float xr = Elem<DT>::round_trip(x);
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
         norm[row0 + row] = (DT == DT_FP8) ? ldexpf(nr, -e) : nr;
         invn[row0 + row] = nr > 0.0f ? ((DT == DT_FP8) ? ldexpf(1.0f / nr, e) : 1.0f / nr) : 0.0f;
     }
-    if (__any(bad) && lane == 0) atomicOr(nonfinite, 1u);
+    const uint32_t bits = (__any(bad & 1) ? 1u : 0u) | (__any(bad & 2) ? 2u : 0u);
+    if (bits && lane == 0) atomicOr(nonfinite, bits);
 }
 
 // f32 index with a bf16 SHADOW for the coarse pass (CGV_DTYPE_F32_SHADOW): second ingest pass over the

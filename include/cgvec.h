@@ -54,7 +54,9 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_DTYPE_F32 0     /* the reference's own Vec<f32> (node.rs:14) */
 #define CGV_DTYPE_BF16 1
 #define CGV_DTYPE_FP16 2
-#define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale; cosine metric only */
+#define CGV_DTYPE_FP8E4M3 3 /* OCP e4m3fn, per-row power-of-two scale; cosine metric only; rows and queries whose
+                               largest magnitude is outside [2^-48, 2^48] (zero rows excepted) are rejected with
+                               CGV_ERR_INVALID_ARG */
 #define CGV_DTYPE_F32_SHADOW 4 /* f32 rows (results = the reference's f32 arithmetic on the UNROUNDED inputs, like
                                   CGV_DTYPE_F32) + a bf16 copy that only feeds the MFMA coarse pass of batched
                                   searches; the exactness check accounts for the copy's rounding residual. 1.5x

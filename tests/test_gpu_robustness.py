@@ -178,3 +178,39 @@ def test_topic_sorted_corpus_keeps_the_fast_path(oracle, dtype, odt):
         assert st["fallback_queries"] == 0, st
     finally:
         ix.close()
+
+
+def test_fp8_magnitude_range_is_enforced(oracle):
+    """fp8 rows / queries are accepted when their largest magnitude lies in [2^-48, 2^48] (the coarse pass
+    accumulates de-scaled dot products in f32); outside it an add, an update or a search fails with
+    CGV_ERR_INVALID_ARG and changes nothing - never a silently wrong answer. Inside the range, rows 2^80
+    apart in magnitude still give the oracle's results."""
+    m = pkg()
+    rng = np.random.default_rng(9)
+    n, d = 6000, 96
+    rows = _unit(rng, n, d) * np.exp2(rng.integers(-40, 41, (n, 1))).astype(np.float32)
+    q = _unit(rng, 8, d) * np.exp2(rng.integers(-40, 41, (8, 1))).astype(np.float32)
+    ix = m.HipKnnIndex(d, dtype="fp8")
+    try:
+        ix.add(rows)
+        idx, sc = ix.search(q, 10)
+        ri, rs = oracle.batch_top_k(q, rows, 10, dtype=3)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        for scale in (np.float32(2.0) ** 60, np.float32(2.0) ** -60):
+            bad = _unit(rng, 40, d)
+            bad[7] *= scale
+            with pytest.raises(m.CgvError) as ei:
+                ix.add(bad)
+            assert ei.value.code == m.cgvec.CGV_ERR_INVALID_ARG and "not applied" in str(ei.value)
+            assert len(ix) == n
+            with pytest.raises(m.CgvError) as ei:
+                ix.update_row(3, bad[7])
+            assert ei.value.code == m.cgvec.CGV_ERR_INVALID_ARG
+            assert np.array_equal(ix.get_row(3), oracle.round_trip(rows[3], 3))
+            with pytest.raises(m.CgvError) as ei:
+                ix.search(bad[6:8], 10)
+            assert ei.value.code == m.cgvec.CGV_ERR_INVALID_ARG
+        idx, sc = ix.search(q, 10)      # the index still answers, unchanged
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    finally:
+        ix.close()
