@@ -35,10 +35,8 @@
 
 #include "../../include/cgvec.h"
 #include "common.h"
+#include "coarse_launch.h"
 #include "kernels_coarse.h"
-#include "kernels_coarse_fp8.h"
-#include "kernels_coarse_w4.h"
-#include "kernels_coarse_fp8_w4.h"
 #include "kernels_exact.h"
 #include "kernels_prep.h"
 #include "kernels_select.h"
@@ -154,7 +152,8 @@ struct SearchCtx {
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace;
+    double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
     // state of the search in flight (between begin and end)
@@ -169,7 +168,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres};
+                                &qshadow, &qres, &trace};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -177,7 +176,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres};
+                          &qshadow, &qres, &trace};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -426,10 +425,6 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, uint64_t total,
         out[i] = (float)in[i];  // `as f32`: round to nearest even
 }
 
-// 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
-// (+ for fp8 an 8-deep ring of the tiles' 256 scale exponents)
-constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(BM + BN) * 64 + (size_t)BN * 4 + 8 * 256 * 4 + 8 * 16 * 4 + 8 * 256;
-
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it for every
 // kernel that needs more than 64 KiB of dynamic LDS once per device (cgv_create calls this with the
 // device current), so that several devices in one process (cgv_sharded_*) and concurrent first
@@ -441,15 +436,9 @@ int ensure_kernel_attrs(int device) {
     std::lock_guard<std::mutex> lk(g_attr_mu);
     if ((size_t)device < g_attr_done.size() && g_attr_done[device]) return CGV_OK;
 #define CGV_ATTR(K, BYTES) HIPCHK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-    CGV_ATTR((coarse_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_kernel<DT_BF16, true>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_kernel<DT_FP16, true>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_w4_kernel<DT_BF16, false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_w4_kernel<DT_FP16, false>), COARSE_LDS_BYTES);
-    CGV_ATTR(coarse_fp8s_w4_kernel<0>, COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_fp8s_kernel<false>), COARSE_LDS_BYTES);
-    CGV_ATTR((coarse_fp8s_kernel<true>), COARSE_LDS_BYTES);
+    if (int rc = coarse_attrs_bf16()) return rc;
+    if (int rc = coarse_attrs_fp16()) return rc;
+    if (int rc = coarse_attrs_fp8()) return rc;
     CGV_ATTR(select_kernel, SELECT_LDS_KEYS * 8 + 65536);
     const int cap = 96 * 1024;
     CGV_ATTR(rescore_kernel<DT_BF16>, cap);
@@ -466,112 +455,10 @@ int ensure_kernel_attrs(int device) {
     return CGV_OK;
 }
 
-// one wave per SIMD (kernels_coarse_w4.h); CGV_ABLATE_W4 = timing-only ablation masks of the bf16 instantiation
-template <int DT>
-int launch_coarse_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = COARSE_LDS_BYTES;
-    static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
-    if (abl4 && DT == DT_BF16) {
-#define CGV_ABLK4(N)                                                                                             \
-    case N: {                                                                                                    \
-        auto k2 = coarse_w4_kernel<DT_BF16, false, N>;                                                           \
-        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
-        break;                                                                                                   \
-    }
-        switch (abl4) {
-            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(17)
-            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
-        }
-#undef CGV_ABLK4
-        HIPCHK(hipGetLastError());
-        return CGV_OK;
-    }
-    hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
-    HIPCHK(hipGetLastError());
-    return CGV_OK;
-}
-
-template <int DT, bool DUMP>
-int launch_coarse_t(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
-    constexpr size_t lds = COARSE_LDS_BYTES;  // attribute set per device by ensure_kernel_attrs()
-    auto kern = coarse_kernel<DT, DUMP>;
-    // timing-only ablations of the bf16 kernel (scripts/gpu_ablate.sh; results are wrong when set)
-    static const int abl = getenv("CGV_ABLATE") ? atoi(getenv("CGV_ABLATE")) : 0;
-    if (abl && DT == DT_BF16 && !DUMP) {
-#define CGV_ABLK(N)                                                                                              \
-    case N: {                                                                                                    \
-        auto k2 = coarse_kernel<DT_BF16, false, N>;                                                              \
-        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                                                   \
-        break;                                                                                                   \
-    }
-        switch (abl) {
-            CGV_ABLK(1) CGV_ABLK(2) CGV_ABLK(4) CGV_ABLK(8) CGV_ABLK(10) CGV_ABLK(15) CGV_ABLK(16) CGV_ABLK(32)
-            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE: unknown mask");
-        }
-#undef CGV_ABLK
-        HIPCHK(hipGetLastError());
-        return CGV_OK;
-    }
-    // CGV_COARSE=w4 selects the one-wave-per-SIMD variant (kernels_coarse_w4.h; kc >= 4) for bf16 / fp16 A/B
-    // timing: same results, measured equal to this 8-wave kernel on the main launch and slower on the hit-heavy
-    // stage-1 launch.
-    static const bool use_w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
-    if constexpr (!DUMP && DT != DT_FP8) {
-        if (use_w4 && a.kc >= 4) return launch_coarse_w4<DT>(a, W, s);
-    }
-    hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
-    HIPCHK(hipGetLastError());
-    return CGV_OK;
-}
-
-template <bool DUMP>
-int launch_coarse_fp8s(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = COARSE_LDS_BYTES;
-    auto kern = coarse_fp8s_kernel<DUMP>;
-    hipLaunchKernelGGL(kern, dim3(W), dim3(512), lds, s, a);
-    HIPCHK(hipGetLastError());
-    return CGV_OK;
-}
-
-int launch_coarse_fp8s_w4(const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    constexpr size_t lds = COARSE_LDS_BYTES;
-    static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;  // timing only
-    if (abl4) {
-#define CGV_ABLK4(N)                                                                                             \
-    case N: {                                                                                                    \
-        auto k2 = coarse_fp8s_w4_kernel<N>;                                                                      \
-        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                                                   \
-        break;                                                                                                   \
-    }
-        switch (abl4) {
-            CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(9)
-            default: return fail(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
-        }
-#undef CGV_ABLK4
-        HIPCHK(hipGetLastError());
-        return CGV_OK;
-    }
-    hipLaunchKernelGGL(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
-    HIPCHK(hipGetLastError());
-    return CGV_OK;
-}
-
-int launch_coarse(int dtype, bool dump, const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    if (dtype == CGV_DTYPE_BF16)
-        return dump ? launch_coarse_t<DT_BF16, true>(a, W, s) : launch_coarse_t<DT_BF16, false>(a, W, s);
-    if (dtype == CGV_DTYPE_FP16)
-        return dump ? launch_coarse_t<DT_FP16, true>(a, W, s) : launch_coarse_t<DT_FP16, false>(a, W, s);
-    if (dtype == CGV_DTYPE_FP8E4M3) {
-        // block-scaled K=64 MFMA kernels with the rows' power-of-two scales applied by the instruction:
-        // one wave per SIMD (kernels_coarse_fp8_w4.h; even kc >= 4) or the 8-wave kernel (CGV_COARSE=w8, dumps, other kc)
-        static const bool w8 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8");
-        if (!dump && !w8 && a.kc >= 4 && (a.kc & 1u) == 0) return launch_coarse_fp8s_w4(a, W, s);
-        return dump ? launch_coarse_fp8s<true>(a, W, s) : launch_coarse_fp8s<false>(a, W, s);
-    }
+int launch_coarse(int dtype, int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    if (dtype == CGV_DTYPE_BF16) return launch_coarse_bf16(mode, a, W, s);
+    if (dtype == CGV_DTYPE_FP16) return launch_coarse_fp16(mode, a, W, s);
+    if (dtype == CGV_DTYPE_FP8E4M3) return launch_coarse_fp8(mode, a, W, s);
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
@@ -592,6 +479,7 @@ SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t ns
     sa.kprime = kprime;
     sa.n_dense = n_dense;
     sa.tau_only = 0;
+    sa.trace = nullptr;
     // LDS key capacity: the dense boot stage needs exactly kprime + n_dense; candidate stages get
     // the full 8192 (64 KiB) so that only pathological emission counts overflow into the exact path.
     sa.lds_keys = dense ? next_pow2(kprime + n_dense) : SELECT_LDS_KEYS;
@@ -712,6 +600,7 @@ constexpr uint32_t MERGE_TARGET = 2048;  // expected candidates per query per la
 
 struct StagePlan {
     uint32_t ntiles, T1, R, P;
+    uint32_t sample_tiles = 0;     // > 0: first threshold from a sample launch of the coarse kernel (plan_stages)
     std::vector<uint32_t> counts;  // tiles per launch, in visiting order
 };
 
@@ -733,8 +622,9 @@ uint32_t golden_stride(uint32_t R) {
     return P;
 }
 
-StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
+StagePlan plan_stages_legacy(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
     StagePlan p;
+    p.sample_tiles = 0;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
     const uint32_t boot = BOOT_TILES;
     const uint32_t emit_target = kprime > 32 ? EMIT_TARGET_WIDE : EMIT_TARGET;
@@ -752,6 +642,90 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nsplit_max) {
         p.counts.push_back(tiles);
         left -= tiles;
         seen += (uint64_t)tiles * BM;
+    }
+    return p;
+}
+
+double env_double(const char* name, double dflt) {
+    const char* v = getenv(name);
+    return v ? atof(v) : dflt;
+}
+
+// Planner knobs: defaults, overridden by the environment at load time and by cgv_debug_set_() at run time (in-process
+// A/B measurements: scripts/ab.py).
+struct Tunables {
+    int plan_legacy = getenv("CGV_PLAN") && !strcmp(getenv("CGV_PLAN"), "legacy");
+    int sample_tiles = getenv("CGV_SAMPLE_TILES") ? atoi(getenv("CGV_SAMPLE_TILES")) : 0;    // 0 = automatic
+    int plan_launches = getenv("CGV_PLAN_LAUNCHES") ? atoi(getenv("CGV_PLAN_LAUNCHES")) : 0;  // 0 = cost model
+    double hit_us = env_double("CGV_PLAN_HIT_US", 1.7);
+    double launch_us = env_double("CGV_PLAN_LAUNCH_US", 40.0);
+};
+Tunables& tun() {
+    static Tunables t;
+    return t;
+}
+
+// Round-3 plan. The first threshold comes from a SAMPLE LAUNCH of the coarse kernel itself
+// (COARSE_SAMPLE: the first S tiles of the visiting order, one tile per CU, block maxima -> tau_kernel): as many
+// rows as one pass of the chip scores at tile-kernel speed (C2: 64 tiles = 16 k rows in ~25 us; the dense boot
+// kernel needed 33 + 25 us for 4 k). It contributes no candidates, so the emitting launches visit ALL tiles.
+// Their number m and sizes minimise a measured cost model:
+//   * a launch whose threshold was learnt from `seen` rows sends k' * 1024 / seen scores of every 32 x 32 block down
+//     the epilogue's slow path, ~HIT_US per tile per (hit per block) (r01d / r02 timelines: +19 us per tile at 16
+//     hits per block, +8 at 4): covering N rows costs  N / seen * kappa,  kappa = nqt * k' * 4 * HIT_US / n_cu;
+//   * every launch costs LAUNCH_US of ramp + select.
+// With `seen` growing geometrically (ratio rho per launch, rho^m = (N + S) / S) the total is m * (LAUNCH_US +
+// kappa * (rho - 1)); m is the cheapest count whose expected emissions fit the candidate lists (LIST_TARGET per
+// (workgroup, query) list of CAND_CAPS entries, MERGE_TARGET per query). C2: S = 16 k rows, m = 2 (112 k + 888 k
+// rows); the 125 k-row shard of C2 at 8 GPUs: ONE launch.
+constexpr uint32_t SAMPLE_TILES_MAX = 64;  // tau_kernel: 16 block maxima per tile, <= 1024 values per query
+constexpr uint32_t LIST_TARGET = 32;
+StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, uint32_t nsplit_max) {
+    const Tunables& t = tun();
+    StagePlan p;
+    p.ntiles = (uint32_t)((n + BM - 1) / BM);
+    if (t.plan_legacy || p.ntiles <= BOOT_TILES) return plan_stages_legacy(n, kprime, nsplit_max);
+    const int forced_s = t.sample_tiles, forced_m = t.plan_launches;
+    const double hit_us = t.hit_us, launch_us = t.launch_us;
+    uint32_t S = std::min<uint32_t>(std::max<uint32_t>(n_cu / std::max<uint32_t>(nqt, 1u), 8u), SAMPLE_TILES_MAX);
+    if (forced_s > 0) S = std::min<uint32_t>((uint32_t)forced_s, SAMPLE_TILES_MAX);
+    // the k'-th largest of 16 S block maxima: keep a few times k' of them
+    while (S < SAMPLE_TILES_MAX && 16u * S < 4u * kprime) S *= 2;
+    S = std::min(S, p.ntiles);
+    p.sample_tiles = S;
+    p.T1 = 0;
+    p.R = p.ntiles;
+    p.P = golden_stride(p.R);
+    const double seen0 = (double)S * BM, total = (double)p.ntiles * BM;
+    const double kappa = (double)nqt * kprime * 4.0 * hit_us / (double)std::max<uint32_t>(n_cu, 1u);
+    uint32_t best_m = 0;
+    double best_cost = 0.0;
+    for (uint32_t m = 1; m <= 8; ++m) {
+        const double rho = pow((total + seen0) / seen0, 1.0 / m);
+        const double emit = kprime * (rho - 1.0);  // expected candidates per query per launch
+        const bool fits = emit <= MERGE_TARGET && emit / std::min<double>(nsplit_max, total / BM / m) <= LIST_TARGET;
+        const double cost = m * (launch_us + kappa * (rho - 1.0));
+        if (forced_m > 0 ? m == (uint32_t)forced_m : (fits && (best_m == 0 || cost < best_cost))) {
+            best_m = m;
+            best_cost = cost;
+        }
+    }
+    if (best_m == 0) best_m = 8;
+    const double rho = pow((total + seen0) / seen0, 1.0 / best_m);
+    const uint32_t unit = std::max<uint32_t>(n_cu / std::max<uint32_t>(nqt, 1u), 1u);  // tiles of one full pass of the chip
+    uint32_t left = p.ntiles;
+    double seen = seen0;
+    for (uint32_t i = 0; i < best_m && left > 0; ++i) {
+        uint32_t tiles = left;
+        if (i + 1 < best_m) {
+            tiles = (uint32_t)std::min<double>(left, std::max(1.0, seen * (rho - 1.0) / BM));
+            if (tiles >= 2 * unit) tiles = (tiles + unit / 2) / unit * unit;  // whole passes: no idle CUs in the last one
+            tiles = std::min(tiles, left);
+            if ((uint64_t)tiles * 4 >= (uint64_t)left * 3) tiles = left;      // no small tail for another launch
+        }
+        p.counts.push_back(tiles);
+        left -= tiles;
+        seen += (double)tiles * BM;
     }
     return p;
 }
@@ -826,33 +800,16 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     if (mfma) {
         const uint32_t nqt = (nq + BN - 1) / BN;
         const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
-        const StagePlan p = plan_stages(h->n, kprime, nsplit_max);
+        const StagePlan p = plan_stages(h->n, kprime, nqt, (uint32_t)h->n_cu, nsplit_max);
         const uint32_t Wmax = nqt * nsplit_max;
-        // boot rows: a sample of 32-row groups when coarse launches follow (the ragged last group may be one of
-        // them: its missing rows score -inf), else the whole corpus
-        const bool sampled = !p.counts.empty();
-        const uint32_t n_boot = sampled ? p.T1 * BM : (uint32_t)h->n;
-        const uint32_t ngroups = (uint32_t)((h->n + 31) / 32);
-        const BootMap bmap{sampled ? golden_stride(ngroups) : 1u, std::max<uint32_t>(ngroups, 1u)};
+        const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;  // dtype the coarse pass runs in
         if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->nbest.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->best.ensure((size_t)nq * kprime * 8))) return rc;
         if ((rc = c->cand.ensure((size_t)Wmax * BN * CAND_CAPS * 8))) return rc;
         if ((rc = c->candcnt.ensure((size_t)Wmax * BN * 4))) return rc;
-        if ((rc = c->dump.ensure((size_t)nq * n_boot * 4))) return rc;
 
-        // boot: dense scores of the n_boot boot rows -> top-k' -> first tau
-        if (h->dtype == CGV_DTYPE_BF16 || h->shadow)
-            launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
-        else if (h->dtype == CGV_DTYPE_FP16)
-            launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
-        else
-            launch_boot<DT_FP8>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
-        HIPCHK(hipGetLastError());
-        if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s, 0, sampled))) return rc;
-
-        const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;  // dtype the coarse pass runs in
         CoarseArgs a;
         a.rows = h->shadow ? h->srows : h->rows;
         a.qrows = h->shadow ? c->qshadow.as<char>() : c->qrows.as<char>();
@@ -865,11 +822,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.cand_cnt = c->candcnt.as<uint32_t>();
         a.overflow = c->overflow.as<uint32_t>();
         a.dump = nullptr;
+        a.sample_ld = 0;
         a.n = (uint32_t)h->n;
         a.nq = nq;
         a.ld = h->shadow ? h->lds : h->ld;
         a.kc = a.ld / kchunk_of(cdt);
-        a.T1 = 0;  // the visiting order covers all tiles (the boot stage was only a sample)
+        a.T1 = 0;  // the visiting order covers all tiles (the first threshold comes from a sample)
         a.R = p.R;
         a.P = p.P;
         a.nqt = nqt;
@@ -879,6 +837,39 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.rexp_q = c->qrexp.as<int8_t>();
         static const bool no_pace = getenv("CGV_NO_PACE") != nullptr;  // A/B switch
         a.pace = (Wmax <= PACE_WORDS && !no_pace) ? c->flags + F_COUNT : nullptr;
+
+        if (p.sample_tiles > 0) {
+            // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
+            const uint32_t M = p.sample_tiles * 16u;
+            if ((rc = c->dump.ensure((size_t)nq * M * 4))) return rc;
+            CoarseArgs sa = a;
+            sa.dump = c->dump.as<float>();
+            sa.sample_ld = M;
+            sa.j0 = 0;
+            sa.cnt = p.sample_tiles;
+            sa.nsplit = std::min<uint32_t>(p.sample_tiles, nsplit_max);
+            if ((rc = launch_coarse(cdt, COARSE_SAMPLE, sa, nqt * sa.nsplit, s))) return rc;
+            hipLaunchKernelGGL(tau_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const float*)c->dump.as<float>(), M, M, nq,
+                               kprime, c->tau.as<float>(), c->nbest.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+        } else {
+            // boot rows: a sample of 32-row groups when coarse launches follow (the ragged last group may be one of
+            // them: its missing rows score -inf), else the whole corpus
+            const bool sampled = !p.counts.empty();
+            const uint32_t n_boot = sampled ? p.T1 * BM : (uint32_t)h->n;
+            const uint32_t ngroups = (uint32_t)((h->n + 31) / 32);
+            const BootMap bmap{sampled ? golden_stride(ngroups) : 1u, std::max<uint32_t>(ngroups, 1u)};
+            if ((rc = c->dump.ensure((size_t)nq * n_boot * 4))) return rc;
+            // boot: dense scores of the n_boot boot rows -> top-k' -> first tau
+            if (h->dtype == CGV_DTYPE_BF16 || h->shadow)
+                launch_boot<DT_BF16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
+            else if (h->dtype == CGV_DTYPE_FP16)
+                launch_boot<DT_FP16>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
+            else
+                launch_boot<DT_FP8>(h, c, n_boot, nq, c->dump.as<float>(), bmap, s);
+            HIPCHK(hipGetLastError());
+            if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s, 0, sampled))) return rc;
+        }
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
         uint32_t last_nsplit = 0;
@@ -890,14 +881,14 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
             const bool dominant = (st + 1 == p.counts.size());
             if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
-            if ((rc = launch_coarse(cdt, false, a, nqt * a.nsplit, s))) return rc;
+            if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s))) return rc;
             if (h->profiling && dominant) {
                 HIPCHK(hipEventRecord(c->ev[2], s));
                 c->timed_coarse = true;
                 c->coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
             // expected emissions per query of this launch: k' * rows / rows seen before it
-            const uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)p.T1 + j0) + 1;
+            const uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)(p.sample_tiles ? p.sample_tiles : p.T1) + j0) + 1;
             if (dominant && fused_final) {  // the last selection happens inside final_kernel
                 last_nsplit = a.nsplit;
                 last_expected = expected;
@@ -935,6 +926,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
+        static const bool tracing = getenv("CGV_TRACE") != nullptr;  // diagnostics: phase stamps of the final kernel
+        r.trace = nullptr;
+        if (tracing) {
+            if ((rc = c->trace.ensure((size_t)nq * 64))) return rc;
+            r.trace = c->trace.as<uint64_t>();
+        }
         c->eps = r.eps_scale;
         {
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
@@ -1113,6 +1110,49 @@ uint32_t cgv_version(void) { return (0u << 16) | 3u; }
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 const char* cgv_last_error(void) { return g_err.c_str(); }
+
+// internal (tests, scripts): the launch plan of a search over n rows with nq queries and k results on a device with
+// n_cu compute units. out[0] = tiles of the sample launch (0: dense boot stage), out[1] = number of emitting
+// launches m, out[2 .. 2+m) = tiles per launch. Returns the number of words written (0 if cap is too small).
+// internal (scripts): diagnostics of the last search on context `ctx` (CGV_TRACE=1): host timeline of cgv_search_f32
+// in microseconds since entry {order, H2D enqueued, pipeline enqueued, D2H enqueued, stream done} and the final
+// kernel's per-query phase stamps (100 MHz ticks: start, keys gathered, top-k' extracted, rows staged, scored, sorted, end)
+int cgv_debug_trace_(cgv_index* h, uint32_t ctx, double* host_us8, uint64_t* stamps, uint32_t nq) {
+    if (!h || ctx >= (uint32_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "bad argument");
+    SearchCtx* c = &h->ctx[ctx];
+    if (host_us8) memcpy(host_us8, c->host_us, sizeof(c->host_us));
+    if (stamps && nq) {
+        if (c->trace.bytes < (size_t)nq * 64) return fail(CGV_ERR_INVALID_ARG, "no trace recorded (CGV_TRACE unset?)");
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpy(stamps, c->trace.p, (size_t)nq * 64, hipMemcpyDeviceToHost));
+    }
+    return CGV_OK;
+}
+
+// internal (scripts/ab.py): set a planner knob at run time. Returns 0, or -1 for an unknown key.
+int cgv_debug_set_(const char* key, double v) {
+    if (!key) return -1;
+    Tunables& t = tun();
+    if (!strcmp(key, "plan_legacy")) t.plan_legacy = (int)v;
+    else if (!strcmp(key, "sample_tiles")) t.sample_tiles = (int)v;
+    else if (!strcmp(key, "plan_launches")) t.plan_launches = (int)v;
+    else if (!strcmp(key, "hit_us")) t.hit_us = v;
+    else if (!strcmp(key, "launch_us")) t.launch_us = v;
+    else return -1;
+    return 0;
+}
+
+uint32_t cgv_debug_plan_(uint64_t n, uint32_t k, uint32_t nq, uint32_t n_cu, int shadow, uint32_t* out, uint32_t cap) {
+    const uint32_t kprime = shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
+    const uint32_t nqt = (nq + BN - 1) / BN;
+    const uint32_t nsplit_max = std::max<uint32_t>(1u, n_cu / std::max<uint32_t>(nqt, 1u));
+    const StagePlan p = plan_stages(n, kprime, nqt, n_cu, nsplit_max);
+    if (!out || cap < 2 + p.counts.size()) return 0;
+    out[0] = p.sample_tiles;
+    out[1] = (uint32_t)p.counts.size();
+    for (size_t i = 0; i < p.counts.size(); ++i) out[2 + i] = p.counts[i];
+    return (uint32_t)(2 + p.counts.size());
+}
 
 int cgv_device_count(void) {
     int n = 0;
@@ -1549,15 +1589,23 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     SearchCtx* c = acquire_ctx(h, lk);
     if (!c) return fail(CGV_ERR_BUSY, "this thread holds every search context of the handle (cgv_search_begin without cgv_search_end)");
     hipStream_t s = c->stream;
+    static const bool tracing = getenv("CGV_TRACE") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto stamp = [&](int i) {
+        if (tracing) c->host_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
+    };
     auto body = [&]() -> int {
         int r;
         if ((r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
         if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
         if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
         if ((r = order_after_caller(h, c))) return r;
+        stamp(0);
         HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, s));
+        stamp(1);
         if ((r = search_enqueue(h, c, c->qstage.as<float>(), nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>())))
             return r;
+        stamp(2);
         lk.unlock();
         // MFMA path: the results exist once the enqueued pipeline has run, so their D2H copies ride the same
         // stream and ONE host synchronisation (inside search_finish) covers flags and results; only when the
@@ -1569,7 +1617,9 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
             return CGV_OK;
         };
         if (early && (r = copy_out())) return r;
+        stamp(3);
         if ((r = search_finish(h, c))) return r;
+        stamp(4);
         if (!early || c->rewrote) {
             if ((r = copy_out())) return r;
             HIPCHK(hipStreamSynchronize(s));
@@ -1919,7 +1969,8 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.rexp_c = h->rexp;
     a.rexp_q = c->qrexp.as<int8_t>();
     a.pace = nullptr;
-    if ((rc = launch_coarse(cdt, true, a, nqt * nsplit, s))) return rc;
+    a.sample_ld = 0;
+    if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;
 }

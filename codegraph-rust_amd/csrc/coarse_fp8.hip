@@ -1,0 +1,74 @@
+// coarse_fp8.hip — the fp8 (e4m3, block-scaled K=64 MFMA) coarse kernels: kernels_coarse_fp8.h (8 waves) and
+// kernels_coarse_fp8_w4.h (one wave per SIMD, the default for even K/64 >= 4).
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/cgvec.h"
+#include "coarse_launch.h"
+#include "kernels_coarse_fp8.h"
+#include "kernels_coarse_fp8_w4.h"
+
+extern "C" int cgv_set_error_(int code, const char* msg);
+
+namespace cgv {
+namespace {
+int status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return CGV_OK;
+    return cgv_set_error_(CGV_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
+}
+int set_lds(const void* kern) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+    if (e == hipSuccess) return CGV_OK;
+    return cgv_set_error_(CGV_ERR_HIP, (std::string("hipFuncSetAttribute(fp8 coarse kernel): ") + hipGetErrorString(e)).c_str());
+}
+}  // namespace
+
+int coarse_attrs_fp8() {
+    int rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_w4_kernel<0>))) return rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_EMIT>))) return rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_DUMP>))) return rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_SAMPLE>))) return rc;
+    return CGV_OK;
+}
+
+int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = COARSE_LDS_BYTES;
+    if (mode == COARSE_DUMP) {
+        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_DUMP>, dim3(W), dim3(512), lds, s, a);
+        return status("coarse_fp8s_kernel (dump)");
+    }
+    if (mode == COARSE_SAMPLE) {
+        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_SAMPLE>, dim3(W), dim3(512), lds, s, a);
+        return status("coarse_fp8s_kernel (sample)");
+    }
+    // one wave per SIMD (even kc >= 4) or the 8-wave kernel (CGV_COARSE=w8, other kc)
+    static const bool w8 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8");
+    if (!w8 && a.kc >= 4 && (a.kc & 1u) == 0) {
+        static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;  // timing only
+        if (abl4) {
+#define CGV_ABLK4(N)                                                           \
+    case N: {                                                                  \
+        auto k2 = coarse_fp8s_w4_kernel<N>;                                    \
+        if (int rc = set_lds((const void*)k2)) return rc;                      \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                 \
+        break;                                                                 \
+    }
+            switch (abl4) {
+                CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(9)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
+            }
+#undef CGV_ABLK4
+            return status("coarse_fp8s_w4_kernel (ablation)");
+        }
+        hipLaunchKernelGGL(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
+        return status("coarse_fp8s_w4_kernel");
+    }
+    hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_EMIT>, dim3(W), dim3(512), lds, s, a);
+    return status("coarse_fp8s_kernel");
+}
+
+}  // namespace cgv

@@ -1,0 +1,30 @@
+// coarse_launch.h — host-side entry points of the coarse (MFMA) kernels. Each storage dtype's
+// kernels live in their own translation unit (coarse_bf16.hip, coarse_fp16.hip, coarse_fp8.hip): they are
+// the expensive instantiations of the library, and separate objects build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_coarse.h"
+
+namespace cgv {
+
+// what one launch does with the scores of a tile (tile_epilogue, kernels_coarse.h)
+constexpr int COARSE_EMIT = 0;    // candidates above the per-query threshold -> (workgroup, query) lists
+constexpr int COARSE_DUMP = 1;    // dense [nq][n] coarse scores (debug / guarantee tests)
+constexpr int COARSE_SAMPLE = 2;  // per-lane maxima of every 32 x 32 block -> [nq][16 per tile] (first threshold)
+
+// 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
+// (+ for fp8 an 8-deep ring of the tiles' 256 scale exponents)
+constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(256 + 256) * 64 + (size_t)256 * 4 + 8 * 256 * 4 + 8 * 16 * 4 + 8 * 256;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: called once per device by ensure_kernel_attrs()
+int coarse_attrs_bf16();
+int coarse_attrs_fp16();
+int coarse_attrs_fp8();
+
+// W workgroups on stream s; status = CGV_OK or a CGV_ERR_* with the thread's error message set
+int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
+int launch_coarse_fp16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
+int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
+
+}  // namespace cgv

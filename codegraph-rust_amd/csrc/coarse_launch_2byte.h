@@ -1,0 +1,98 @@
+// coarse_launch_2byte.h — launchers of the bf16 / fp16 coarse kernels (included by coarse_bf16.hip and
+// coarse_fp16.hip only: one translation unit per dtype).
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/cgvec.h"
+#include "coarse_launch.h"
+#include "kernels_coarse_w4.h"
+
+extern "C" int cgv_set_error_(int code, const char* msg);
+
+namespace cgv {
+
+inline int coarse_hip_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return CGV_OK;
+    return cgv_set_error_(CGV_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
+}
+inline int coarse_set_lds(const void* kern) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+    if (e == hipSuccess) return CGV_OK;
+    return cgv_set_error_(CGV_ERR_HIP, (std::string("hipFuncSetAttribute(coarse kernel): ") + hipGetErrorString(e)).c_str());
+}
+
+template <int DT>
+int coarse_attrs_2byte() {
+    int rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_DUMP>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_SAMPLE>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_w4_kernel<DT, false>))) return rc;
+    return CGV_OK;
+}
+
+// ABLATE: the timing-only ablation instantiations (bf16 only; scripts/gpu_ablate.sh, gpu_clock.sh)
+template <int DT, bool ABLATE>
+int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+    constexpr size_t lds = COARSE_LDS_BYTES;  // attribute set per device by ensure_kernel_attrs()
+    if (mode == COARSE_DUMP) {
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_DUMP>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (dump)");
+    }
+    if (mode == COARSE_SAMPLE) {
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_SAMPLE>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (sample)");
+    }
+    if constexpr (ABLATE) {
+        // results are wrong when set: only the launch time means anything
+        static const int abl = getenv("CGV_ABLATE") ? atoi(getenv("CGV_ABLATE")) : 0;
+        if (abl) {
+#define CGV_ABLK(N)                                                            \
+    case N: {                                                                  \
+        auto k2 = coarse_kernel<DT, COARSE_EMIT, N>;                           \
+        if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                 \
+        break;                                                                 \
+    }
+            switch (abl) {
+                CGV_ABLK(1) CGV_ABLK(2) CGV_ABLK(4) CGV_ABLK(8) CGV_ABLK(10) CGV_ABLK(15) CGV_ABLK(16) CGV_ABLK(32)
+                CGV_ABLK(65) CGV_ABLK(197)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: unknown mask");
+            }
+#undef CGV_ABLK
+            return coarse_hip_status("coarse_kernel (ablation)");
+        }
+        static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
+        static const bool w4a = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
+        if (abl4 && w4a && a.kc >= 4) {
+#define CGV_ABLK4(N)                                                           \
+    case N: {                                                                  \
+        auto k2 = coarse_w4_kernel<DT, false, N>;                              \
+        if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                 \
+        break;                                                                 \
+    }
+            switch (abl4) {
+                CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(17)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
+            }
+#undef CGV_ABLK4
+            return coarse_hip_status("coarse_w4_kernel (ablation)");
+        }
+    }
+    // CGV_COARSE=w4 selects the one-wave-per-SIMD variant (kernels_coarse_w4.h; kc >= 4) for A/B timing: same
+    // results, measured equal to the 8-wave kernel on the main launch and slower on hit-heavy launches.
+    static const bool use_w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
+    if (use_w4 && a.kc >= 4) {
+        hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
+        return coarse_hip_status("coarse_w4_kernel");
+    }
+    hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);
+    return coarse_hip_status("coarse_kernel");
+}
+
+}  // namespace cgv

@@ -87,13 +87,14 @@ struct CoarseArgs {
     uint2* cand;            // [W][BN][CAND_CAPS] (score bits, row)
     uint32_t* cand_cnt;     // [W][BN]
     uint32_t* overflow;     // [nq]
-    float* dump;            // DUMP mode: dense [nq][n] coarse scores
+    float* dump;            // DUMP mode: dense [nq][n] coarse scores; SAMPLE mode: [nq][sample_ld] block maxima
     uint32_t n, nq, ld, kc;
     uint32_t T1, R, P, j0, cnt, nsplit, nqt, metric;
     uint32_t qgroup;        // query tiles that share one XCD (block_to_work); 0 = all of them
     const int8_t* rexp_c;   // fp8 only: [n] per-row power-of-two scale exponents of the corpus ...
     const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
     uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
+    uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump` (16 per sampled tile)
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -273,19 +274,48 @@ __device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, 
 // tile, each a dependent chain with nothing to overlap; measured 43 % of the one-wave-per-SIMD fp8 kernel.)
 // The accumulators are NOT cleared here: the first k-step of the next tile starts from a zero C operand (free in
 // the MFMA encoding).
-template <int BM, int BN, int WTM, int WTN, int MB, int NB, bool DUMP, bool ACC_AGPR = false>
+template <int BM, int BN, int WTM, int WTN, int MB, int NB, int MODE /* 0 emit, 1 dump, 2 sample */, bool ACC_AGPR = false>
 __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], uint32_t tile, int wm,
                                               int wn, int lane, uint32_t g, uint32_t qt, const float (&tq)[NB],
                                               const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
                                               const float* invn_s /* LDS: inverse norms of this tile's 256 rows */,
-                                              const float* stat_s /* LDS: 8 block-min + 8 block-max norms */) {
+                                              const float* stat_s /* LDS: 8 block-min + 8 block-max norms */,
+                                              uint32_t seq = 0 /* SAMPLE: position of the tile in the sample */) {
     const uint32_t trow0 = tile * (uint32_t)BM + (uint32_t)(wm * WTM);
     // Opaque copy of the lane id: stops LICM from hoisting per-register row offsets out of the K loop
     // (it cost ~50 VGPRs in the first build).
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     lane = lane_o;
-    if (DUMP) {
+    if (MODE == 2) {
+        // SAMPLE: no threshold exists yet. Every lane reduces each of its 32 x 32 blocks to the
+        // maximum of its 16 coarse scores (16 distinct corpus rows); a query collects 16 such maxima per sampled
+        // tile, and the k'-th largest of them all is a valid first threshold: >= k' DISTINCT rows score at least
+        // that much (tau_kernel, kernels_select.h). Layout [q][seq * 16 + wm * 8 + (lane >> 5) * 4 + mb]: one
+        // 16-byte store per lane and N-block.
+        static_assert(MODE != 2 || MB == 4, "sample layout assumes 4 M-blocks per wave");
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+            float m[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                float mm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t rl = (uint32_t)(wm * WTM + mb * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (uint32_t)(lane >> 5);
+                    const float sc = (a.metric == METRIC_DOT) ? acc[mb][nb][r] : acc[mb][nb][r] * invn_s[rl];
+                    if (tile * (uint32_t)BM + rl < a.n) mm = fmaxf(mm, sc);
+                }
+                m[mb] = (mm == -INFINITY) ? -INFINITY : mm * invq[nb];
+            }
+            if (q < a.nq)
+                *(float4*)(a.dump + (uint64_t)q * a.sample_ld + seq * 16u + (uint32_t)(wm * 8 + (lane >> 5) * 4)) =
+                    make_float4(m[0], m[1], m[2], m[3]);
+        }
+        return;
+    }
+    if (MODE == 1) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -340,11 +370,13 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
     }
 }
 
-// ABL: timing-only ablation mask for scripts/gpu_ablate.sh (results are WRONG for ABL != 0):
+// MODE: COARSE_EMIT / COARSE_DUMP / COARSE_SAMPLE (coarse_launch.h; tile_epilogue).
+// ABL: timing-only ablation mask for scripts/gpu_ablate.sh / gpu_clock.sh (results are WRONG for ABL != 0):
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
-// (results stay correct for 32). DESIGN.md §9 quotes the numbers.
-template <int DT, bool DUMP, int ABL = 0>
+// (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
+// 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
+template <int DT, int MODE, int ABL = 0>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_BDMA(RS, DST, IMM) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
     auto issue_q = [&](int q) {
-        if (ABL & 2) {
+        if ((ABL & 2) || ((ABL & 64) && issued >= (uint32_t)NSTAGE)) {
             if (q == 3) ++issued;
             return;
         }
@@ -495,8 +527,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int i = 0; i < MB; ++i) fa0[i] = fa1[i] = (frag)0;
         for (int i = 0; i < NB; ++i) fb0[i] = fb1[i] = (frag)0;
     }
-#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & 8)) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
-#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & 8)) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
+#define CGV_LDA(FA, I, BASE, KK) if (!(ABL & (8 | 128))) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
+#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & (8 | 128))) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
 #define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                         \
     {                                                                                            \
         CGV_LDA(FA, 0, BASE, KK) CGV_LDA(FA, 1, BASE, KK) CGV_LDA(FA, 2, BASE, KK) CGV_LDA(FA, 3, BASE, KK) \
@@ -566,12 +598,24 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
     __builtin_amdgcn_s_barrier();
     CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
+    if (ABL & 128) {  // both fragment sets once, from the first stage (real data), never again
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            fa0[i] = *(const frag*)(smem + aoff + i * 2048 + xo[0]);
+            fa1[i] = *(const frag*)(smem + aoff + i * 2048 + xo[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            fb0[i] = *(const frag*)(smem + boff + i * 2048 + xo[0]);
+            fb1[i] = *(const frag*)(smem + boff + i * 2048 + xo[1]);
+        }
+    }
 
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1))                                                                                                \
-        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
                                                       invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
-                                                      stat_s + ((SEQ) & (NINV - 1)) * 16);
+                                                      stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ));
 
     // Tile-structured: [first stage of a tile: zero-C MFMAs] then KC-1 ordinary stages; at a tile
     // boundary the iteration is B phase (last k-step of the previous tile), its epilogue, zero-C A phase.

@@ -40,7 +40,7 @@ __device__ inline f32x16_t mma_fp8_k64_scaled(const Fp8Frag& a, const Fp8Frag& b
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, SA, sa, SB, sb);
 }
 
-template <bool DUMP>
+template <int MODE>  // COARSE_EMIT / COARSE_DUMP / COARSE_SAMPLE (coarse_launch.h)
 __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
 #define F8_SB __builtin_amdgcn_sched_barrier(0)
 #define F8_EPILOGUE()                                                                                          \
     {                                                                                                          \
-        tile_epilogue<BM, BN, WTM, WTN, MB, NB, DUMP>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
+        tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
                                                       invn_s + (pj & (NINV - 1)) * 256,                        \
-                                                      stat_s + (pj & (NINV - 1)) * 16);                        \
+                                                      stat_s + (pj & (NINV - 1)) * 16, a.j0 + jlo + pj);       \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)    \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;                              \
     }

@@ -20,7 +20,13 @@ struct SelectArgs {
     uint32_t* overflow;        // [nq]
     uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
     uint32_t tau_only;         // dense scores of a SAMPLE of the corpus: publish tau, keep no candidates
+    uint64_t* trace;           // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps of the kernel's phases, or NULL
 };
+
+// diagnostics: phase stamp i of query q (s_memrealtime, 100 MHz), thread 0 only; free when trace == NULL
+__device__ inline void phase_stamp(uint64_t* trace, uint32_t q, int i, int tid) {
+    if (trace && tid == 0) trace[(uint64_t)q * 8 + i] = wall_clock64();
+}
 
 // ---- shared pieces of the select / final kernels ------------------------------------
 
@@ -245,10 +251,13 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
         }
         return;
     }
+    phase_stamp(a.trace, q, 0, tid);
     const uint32_t M = gather_keys(a, q, keys, pre, tid, &trunc);
+    phase_stamp(a.trace, q, 1, tid);
     const uint32_t keep = M < a.kprime ? M : a.kprime;
     if (a.kprime <= 64) {
         extract_topk(keys, M, keep, part, outk, tid);
+        phase_stamp(a.trace, q, 2, tid);
         for (uint32_t i = tid; i < keep; i += 256) a.best[(uint64_t)q * a.kprime + i] = outk[i];
         if (tid == 0) {
             a.nbest[q] = a.tau_only ? 0u : keep;
@@ -270,6 +279,75 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
             else if (a.dense) a.tau[q] = -INFINITY;
             if (trunc) a.overflow[q] = 1u;
         }
+    }
+}
+
+// ---- first threshold from the sample launch (coarse kernels, COARSE_SAMPLE) -----------------------
+// dense[q][0..M): maxima of DISJOINT groups of 16 corpus rows (one per lane and 32 x 32 block of the sampled
+// tiles; -inf for groups without a valid row). tau[q] = the k'-th largest of them: at least k' distinct rows of
+// the corpus score that much or more, so it is a valid lower bound of the final k'-th best coarse score, and a tight
+// one - with M / 16 >> k' groups the k' best rows of the sample almost surely sit in k' different groups.
+// ONE WAVE per query, values only (32-bit ordered keys, no row ids): <= 16 keys per lane sorted in registers, then
+// k' rounds of wave maximum + pop. Also clears nbest / overflow of the query (the launches that follow append).
+__device__ inline void cmpx_desc32(uint32_t& x, uint32_t& y) {
+    const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
+    x = hi;
+    y = lo;
+}
+__global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
+                                                  uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* d = dense + (uint64_t)q * ld;
+    uint32_t r[16];
+    // lane l owns elements 4l..4l+3 of every 256-element slab (16-byte loads, coalesced); M <= 1024
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t e = 256u * j + 4u * (uint32_t)lane;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (e + 3 < M) {
+            v = *(const float4*)(d + e);
+        } else {
+            if (e < M) v.x = d[e];
+            if (e + 1 < M) v.y = d[e + 1];
+            if (e + 2 < M) v.z = d[e + 2];
+        }
+        // NaN never occurs (non-finite inputs are rejected); -inf = "no row": key 0x007fffff, never 0
+        r[4 * j] = f2ord(v.x + 0.0f);
+        r[4 * j + 1] = f2ord(v.y + 0.0f);
+        r[4 * j + 2] = f2ord(v.z + 0.0f);
+        r[4 * j + 3] = f2ord(v.w + 0.0f);
+    }
+    // bitonic sorting network on 16 registers, descending
+#pragma unroll
+    for (int k2 = 2; k2 <= 16; k2 <<= 1)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    if ((i & k2) == 0) cmpx_desc32(r[i], r[ixj]);
+                    else cmpx_desc32(r[ixj], r[i]);
+                }
+            }
+    uint32_t cnt = 0, last = 0;
+    while (cnt < kprime) {
+        const uint32_t w = wave_max_u32(r[0]);
+        if (w == 0u) break;  // fewer than k' values
+        const bool own = (r[0] == w);
+        cnt += (uint32_t)__popcll(__ballot(own));  // equal values in several lanes count once each
+        last = w;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) r[i] = r[i + 1];
+            r[15] = 0u;
+        }
+    }
+    if (lane == 0) {
+        tau[q] = (cnt >= kprime) ? ord2f(last) : -INFINITY;
+        nbest[q] = 0u;
     }
 }
 
@@ -296,6 +374,7 @@ struct RescoreArgs {
     float res_rel_c;        // max over the corpus of |dc| / min(|c|, |c^|)
     float res_abs_c;        // max over the corpus of |dc|
     uint32_t* stat_maxeps;  // [1] f2ord-free max of the eps actually used (non-negative float bits)
+    uint64_t* trace;        // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps (100 MHz) of the phases, or NULL
 };
 
 // Exact reference arithmetic on the k' candidates of each query, exact (score desc, row asc)
@@ -361,6 +440,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             }
         }
         __syncthreads();
+        phase_stamp(a.trace, q, 3, tid);
         const LdsRow<DT> ql{qs};
         for (uint32_t c = (uint32_t)tid >> 3; c < nbat; c += 32) {
             const uint64_t key = ckeys[c0 + c];
@@ -380,7 +460,9 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         }
     }
     __syncthreads();
+    phase_stamp(a.trace, q, 4, tid);
     bitonic_sort_desc<256>(ekeys, P, tid);
+    phase_stamp(a.trace, q, 5, tid);
     for (uint32_t j = tid; j < a.k; j += 256) {
         uint64_t oi = UINT64_MAX;
         float os = -INFINITY;
@@ -403,6 +485,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);
     }
+    phase_stamp(a.trace, q, 6, tid);
 }
 
 template <int DT>
@@ -433,9 +516,12 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     bool trunc = false;
+    phase_stamp(a.trace, q, 0, tid);
     const uint32_t M = gather_keys(sa, q, keys, pre, tid, &trunc);
+    phase_stamp(a.trace, q, 1, tid);
     const uint32_t keep = M < sa.kprime ? M : sa.kprime;
     extract_topk(keys, M, keep, part, outk, tid);
+    phase_stamp(a.trace, q, 2, tid);
     for (uint32_t i = tid; i < keep; i += 256) ckeys[i] = outk[i];
     // fewer than k' keys: nothing is cut here, but the coarse launches dropped every row at or below THEIR threshold
     const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
