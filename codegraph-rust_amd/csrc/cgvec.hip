@@ -1085,12 +1085,25 @@ void release_ctx(cgv_index* h, SearchCtx* c) {
     h->cv.notify_all();
 }
 
-void wait_all_idle(cgv_index* h, std::unique_lock<std::mutex>& lk) {
+// Writers wait until no search is in flight. A context held by the CALLING thread through cgv_search_begin_f32_dev
+// (released only by its own later cgv_search_end) would make that wait a wait for itself: CGV_ERR_BUSY instead,
+// mirroring acquire_ctx.
+int wait_all_idle(cgv_index* h, std::unique_lock<std::mutex>& lk) {
+    const std::thread::id me = std::this_thread::get_id();
+    bool self = false;
     h->cv.wait(lk, [&] {
-        for (SearchCtx& c : h->ctx)
-            if (c.busy) return false;
-        return true;
+        bool idle = true;
+        for (SearchCtx& c : h->ctx) {
+            if (!c.busy) continue;
+            idle = false;
+            if (c.split && c.owner == me) self = true;
+        }
+        return idle || self;
     });
+    if (self)
+        return fail(CGV_ERR_BUSY, "this thread holds a search ticket of the handle (cgv_search_begin_f32_dev): call "
+                                  "cgv_search_end before changing or reading the index");
+    return CGV_OK;
 }
 
 // order the context's stream after everything the caller queued on the handle's stream
@@ -1255,7 +1268,7 @@ int cgv_destroy(cgv_index* h) {
 int cgv_reserve(cgv_index* h, uint64_t n_rows) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     HIPCHK(hipSetDevice(h->device));
     return grow(h, n_rows);
 }
@@ -1264,7 +1277,7 @@ int cgv_add_f32_dev(cgv_index* h, const float* rows_dev, uint64_t n) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (n && !rows_dev) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     HIPCHK(hipSetDevice(h->device));
     return atomic_ingest(h, [&] { return add_dev_locked(h, rows_dev, n); });
 }
@@ -1273,7 +1286,7 @@ int cgv_add_f32(cgv_index* h, const float* rows_host, uint64_t n) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (n && !rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + n);
     if (rc) return rc;
@@ -1295,7 +1308,7 @@ int cgv_add_f64(cgv_index* h, const double* rows_host, uint64_t n) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     if (n && !rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + n);
     if (rc) return rc;
@@ -1360,7 +1373,7 @@ int cgv_load_mmap(cgv_index* h, const char* path, uint64_t* out_rows) {
     const float* src = (const float*)((const char*)mf.p + 16);
 
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n + count);
     if (rc) return rc;
@@ -1433,7 +1446,7 @@ int cgv_write_mmap_f32(const char* path, const float* rows_host, uint64_t n, uin
 int cgv_save_mmap(cgv_index* h, const char* path) {
     if (!h || !path) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     if (h->n == 0) return CGV_OK;
     HIPCHK(hipSetDevice(h->device));
     SearchCtx* c = &h->ctx[0];
@@ -1474,7 +1487,7 @@ int cgv_save_mmap(cgv_index* h, const char* path) {
 int cgv_update_row_f32(cgv_index* h, uint64_t id, const float* row_host) {
     if (!h || !row_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     for (uint32_t i = 0; i < h->D; ++i)  // checked BEFORE the stored row is overwritten: a rejected update changes nothing
         if (!(fabsf(row_host[i]) <= 3.402823466e38f))
@@ -1510,7 +1523,7 @@ int cgv_set_id_map(cgv_index* h, uint32_t chunk_rows, uint32_t n_shards, uint32_
     if (n_shards == 0 || shard >= n_shards || (n_shards > 1 && chunk_rows == 0))
         return fail(CGV_ERR_INVALID_ARG, "cgv_set_id_map: need chunk_rows > 0 and shard < n_shards");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     h->idmap.chunk = n_shards > 1 ? chunk_rows : 0;
     h->idmap.nshards = n_shards;
     h->idmap.shard = shard;
@@ -1636,7 +1649,7 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
 int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {
     if (!h || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     SearchCtx* c = &h->ctx[0];
     if (id >= h->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     HIPCHK(hipSetDevice(h->device));
@@ -1682,7 +1695,7 @@ int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint
     if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     SearchCtx* c = &h->ctx[0];
     HIPCHK(hipSetDevice(h->device));
     const uint64_t n = limit_rows ? std::min<uint64_t>(limit_rows, h->n) : h->n;
@@ -1754,7 +1767,7 @@ int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int 
 int cgv_truncate(cgv_index* h, uint64_t n_rows) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     if (n_rows >= h->n) return CGV_OK;
     HIPCHK(hipSetDevice(h->device));
     // the corpus-wide maxima (largest norm, shadow residuals) stay as they are: over-estimates only widen the
@@ -1768,7 +1781,7 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
     *out_n = 0;
     if (limit > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "limit exceeds CGV_MAX_K");
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     SearchCtx* c = &h->ctx[0];
     if (h->n == 0 || limit == 0) return CGV_OK;  // optimization.rs:382-384
     HIPCHK(hipSetDevice(h->device));
@@ -1910,7 +1923,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
         return fail(CGV_ERR_INVALID_ARG, "coarse path needs a bf16/fp16/fp8 index or an f32 index with a shadow");
     if (nq == 0 || h->n == 0) return CGV_OK;
     std::unique_lock<std::mutex> lk(h->mu);
-    wait_all_idle(h, lk);
+    if (int brc = wait_all_idle(h, lk)) return brc;
     SearchCtx* c = &h->ctx[0];
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = c->stream;

@@ -67,24 +67,34 @@ struct Rccl {
 std::mutex g_rccl_mu;
 Rccl g_rccl;
 bool g_rccl_tried = false;
+std::string g_rccl_err;  // why the library is unusable (dlerror() text is consumed by the call that reads it)
 
-const Rccl* load_rccl() {
+// why: receives the reason when NULL is returned. CGV_RCCL_LIB overrides the library name (tests: a name that
+// cannot be loaded exercises the fall-back to the copy exchange).
+const Rccl* load_rccl(std::string* why = nullptr) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (!g_rccl_tried) {
         g_rccl_tried = true;
         // a copy already mapped into the process (e.g. PyTorch's) is found first by its soname
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        std::vector<std::string> names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (const char* forced = getenv("CGV_RCCL_LIB")) names = {forced};
+        for (const std::string& name : names) {
+            g_rccl.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (g_rccl.lib) break;
+            const char* de = dlerror();  // read ONCE: the call clears the message
+            g_rccl_err = de ? de : ("dlopen(" + name + ") failed");
         }
         if (g_rccl.lib) {
             g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(g_rccl.lib, "ncclCommInitAll");
             g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
             g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
             g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+            if (!g_rccl.ok()) g_rccl_err = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
         }
     }
-    return g_rccl.ok() ? &g_rccl : nullptr;
+    if (g_rccl.ok()) return &g_rccl;
+    if (why) *why = g_rccl_err.empty() ? "librccl not loadable" : g_rccl_err;
+    return nullptr;
 }
 
 struct Buf {
@@ -226,8 +236,9 @@ int set_exchange_locked(cgv_sharded* s, int kind) {
     if (kind != CGV_EXCHANGE_RCCL) return fail(CGV_ERR_INVALID_ARG, "exchange must be CGV_EXCHANGE_RCCL or CGV_EXCHANGE_COPY");
     if (!s->distinct) return fail(CGV_ERR_INVALID_ARG, "RCCL needs distinct devices (one communicator rank per GPU)");
     if (!s->sh[0]->comm) {
-        const Rccl* r = load_rccl();
-        if (!r) return fail(CGV_ERR_HIP, std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing"));
+        std::string why;
+        const Rccl* r = load_rccl(&why);
+        if (!r) return fail(CGV_ERR_HIP, "librccl could not be loaded: " + why);
         std::vector<int> devs(s->G);
         std::vector<ncclComm_t> comms(s->G, nullptr);
         for (uint32_t g = 0; g < s->G; ++g) devs[g] = s->sh[g]->device;
@@ -242,6 +253,18 @@ int set_exchange_locked(cgv_sharded* s, int kind) {
 }  // namespace
 
 extern "C" {
+
+// internal (tests): try to load RCCL the way cgv_sharded_create does. Returns 1 when usable, else 0 with the
+// reason in msg (truncated to cap bytes). Needs no device.
+int cgv_debug_rccl_probe_(char* msg, uint32_t cap) {
+    std::string why;
+    const Rccl* r = load_rccl(&why);
+    if (msg && cap) {
+        strncpy(msg, r ? "" : why.c_str(), cap - 1);
+        msg[cap - 1] = 0;
+    }
+    return r ? 1 : 0;
+}
 
 int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, const int* device_ids, cgv_sharded** out) {
     if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");

@@ -72,8 +72,10 @@ int cgvs_upsert_node_metadata(cgvs_store* s, const uint8_t* id16, const char* la
                               const char* file_path, const char* const* attr_keys,
                               const char* const* attr_values, uint32_t n_attrs);
 
+#define CGVS_ID_TEXT 48 /* bytes per id slot of cgvs_vector_knn: "nodes:" + 36-char uuid + NUL, padded */
+
 /* SurrealVectorBackend::vector_knn (surreal_store.rs:14-20): ids as "nodes:<uuid>" (each written
- * at out_ids + i*48, NUL-terminated), distance = 1 - cosine ascending. `limit` is served up to the number of
+ * at out_ids + i*CGVS_ID_TEXT, NUL-terminated), distance = 1 - cosine ascending. `limit` is served up to the number of
  * rows in the column; more than CGV_MAX_K (2048) neighbours per query is CGV_ERR_INVALID_ARG, never a silent
  * truncation (the SemanticSearch entry points over-fetch prefetch_k(max(4*limit, limit+25)) = 12*limit
  * neighbours, search.rs:113,293: limit <= 170 fits). */

@@ -13,14 +13,17 @@ from _util import ROOT, pkg
 SRC = os.path.join(ROOT, "tests", "c_client", "abi_client.c")
 
 
-def _build(tmp_path):
+def _build(tmp_path, src=SRC, name="abi_client"):
     m = pkg()
     m.build_library()
-    exe = str(tmp_path / "abi_client")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(m.cgvec.LIB_PATH)
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                            "-L", libdir, "-lcgvec_hip", "-Wl,-rpath," + libdir])
     return exe
+
+
+SHIM = os.path.join(ROOT, "tests", "c_client", "shim_replay.c")
 
 
 def _write_input(path, rows, q, k):
@@ -40,6 +43,50 @@ def test_c_client_compiles_and_fails_loudly_without_gpu(tmp_path):
                  rng.standard_normal((2, 16)).astype(np.float32), 5)
     p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert p.returncode == 3 and "no CPU fallback" in p.stderr
+
+
+def test_shim_replay_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build(tmp_path, SHIM, "shim_replay")
+    if pkg().device_count() > 0:
+        pytest.skip("GPU present")
+    rng = np.random.default_rng(0)
+    _write_input(tmp_path / "in.bin", rng.standard_normal((64, 16)).astype(np.float32),
+                 rng.standard_normal((2, 16)).astype(np.float32), 5)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.txt")], capture_output=True, text=True)
+    assert p.returncode == 3 and "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,odt", [(4, 0), (1, 1)])
+def test_shim_call_sequence_replay(tmp_path, oracle, dtype, odt):
+    """The Rust shim of INTEGRATION.md §3 has no logic: tests/c_client/shim_replay.c issues its exact call sequence
+    (upsert in two batches, kNN by column, RE-UPSERT of a known id, kNN, get_embedding, search_similar). Expected:
+    the seam's contract (surreal_store.rs:11-22, 61-85) evaluated by the oracle - ids by row, distance = 1 - cosine
+    ascending, the re-upserted node found once by its NEW embedding (UPSERT), its old embedding gone."""
+    exe = _build(tmp_path, SHIM, "shim_replay")
+    rng = np.random.default_rng(21)
+    n, d, k = 6000, 384, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((2, d)).astype(np.float32)
+    q[1] = rows[7] * np.float32(-1.0) + rng.standard_normal(d).astype(np.float32) * np.float32(0.05)   # far from row 7's old value
+    _write_input(tmp_path / "in.bin", rows, q, k)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.txt"), str(dtype)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = {0: [], 1: [], 2: []}
+    for line in open(tmp_path / "out.txt"):
+        ph, rank, row, bits = line.split()
+        got[int(ph)].append((int(row), np.array([int(bits, 16)], dtype=np.uint32).view(np.float32)[0]))
+    # phase 0: the first query against the original rows
+    ri, rs = oracle.batch_top_k(q[:1], rows, k, dtype=odt)
+    assert [r for r, _ in got[0]] == ri[0].tolist()
+    assert np.array_equal(np.array([x for _, x in got[0]], np.float32), np.float32(1.0) - rs[0])
+    # phases 1, 2: row 7 now holds q[1]
+    rows2 = rows.copy()
+    rows2[7] = q[1]
+    ri, rs = oracle.batch_top_k(q[1:], rows2, k, dtype=odt)
+    assert [r for r, _ in got[1]] == ri[0].tolist() and ri[0][0] == 7
+    assert np.array_equal(np.array([x for _, x in got[1]], np.float32), np.float32(1.0) - rs[0])
+    assert [r for r, _ in got[2]] == ri[0].tolist()
 
 
 @pytest.mark.gpu

@@ -35,6 +35,30 @@ def test_search_optimized_matches_reference_policy(oracle, n, d, limit):
         ix.close()
 
 
+def test_reference_optimization_fixture_gate(oracle):
+    """The reference's own fixture (tests/model_optimization_tests.rs:36-58, :347-427; inputs regenerated bit for
+    bit, tests/golden/make_optimization_fixture.py): the device int8 scan and the device baseline return the
+    recorded oracle lists and pass the test's gate (positional top-10 agreement >= 0.8)."""
+    import os
+    m = pkg()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optimization_11223.npz"))
+    v, q = g["vectors"], g["vectors"][0]
+    ix8 = m.Int8ScanIndex(128)
+    ix = m.HipKnnIndex(128, metric="cosine", dtype="f32", device=0)
+    try:
+        ix8.add(v)                                   # device-side quantize_batch (optimization.rs:226-283)
+        opt = ix8.search_optimized(q, 10)            # optimization.rs:63-150
+        ix.add(v)
+        base, dist = ix.search_baseline(q, 10)       # optimization.rs:376-418
+        assert len(opt) == len(base) == 10
+        assert sum(int(a == b) for a, b in zip(opt, base)) / 10.0 >= 0.8
+        assert np.array_equal(opt, g["int8_idx"]) and np.array_equal(base, g["baseline_idx"])
+        assert np.array_equal(dist, g["baseline_dist"])
+    finally:
+        ix8.close()
+        ix.close()
+
+
 def test_quantize_batch_matches(oracle):
     m = pkg()
     rng = np.random.default_rng(4)

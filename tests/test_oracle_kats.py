@@ -212,6 +212,53 @@ def test_int8_path_agreement(oracle):
     assert agree >= 0.8
 
 
+def _golden(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+def test_siphash_restatement_known_answers():
+    """The hasher behind the reference fixture's inputs: generic SipHash-c-d pinned on the published SipHash-2-4
+    vectors (Aumasson & Bernstein 2012, appendix A: key 00..0f) and on the first entry of the SipHash-1-3 table
+    used by Rust's own hasher tests; DefaultHasher = c 1, d 3, zero keys."""
+    import struct
+    import sys
+    sys.path.insert(0, _golden(""))
+    import siphash13 as sh
+    k0, k1 = struct.unpack("<QQ", bytes(range(16)))
+    assert sh.sip_hash(2, 4, k0, k1, b"") == 0x726FDB47DD0E0E31
+    assert sh.sip_hash(2, 4, k0, k1, bytes(range(15))) == 0xA129CA6149BE45E5
+    assert sh.sip_hash(1, 3, k0, k1, b"") == 0xABAC0158050FC4DC
+    # Rust `u64 as f32`: round to nearest even, also across the 2^24 mantissa boundary
+    assert sh.u64_as_f32(2**24 + 1) == np.float32(2**24) and sh.u64_as_f32(2**24 + 3) == np.float32(2**24 + 4)
+    assert sh.u64_as_f32(2**64 - 1) == np.float32(2.0**64) and sh.u64_as_f32(0) == 0
+
+
+def test_reference_optimization_fixture(oracle):
+    """/root/reference/crates/codegraph-vector/tests/model_optimization_tests.rs:36-58 + :347-427 on the
+    reference's OWN inputs (generate_optimization_vectors(1000, 128, 11223), query = vectors[0]): the committed
+    vectors are what siphash13.py regenerates, every value lies in [-1, 1], and the oracle passes the test's gate
+    (int8 search_optimized vs search_baseline, positional top-10 agreement >= 0.8) with the recorded lists."""
+    import hashlib
+    import sys
+    sys.path.insert(0, _golden(""))
+    import siphash13 as sh
+    g = np.load(_golden("optimization_11223.npz"))
+    v = g["vectors"]
+    assert v.shape == (1000, 128) and v.dtype == np.float32
+    assert np.array_equal(sh.generate_optimization_vectors(24, 128, 11223), v[:24])      # bit-equal regeneration
+    assert hashlib.sha256(v.tobytes()).hexdigest() == "e8899e8d8d982fbb68ffba1390ae66df3b66d87b3d8a569891a9683641b3f4a3"
+    assert v.min() >= -1.0 and v.max() <= 1.0
+    q = v[0]
+    base, dist = oracle.search_baseline(q, v, 10)
+    opt = oracle.search_optimized_u8(q, oracle.quantize_u8(v), 10)
+    assert len(opt) == len(base) == 10                                                   # :400
+    assert sum(int(a == b) for a, b in zip(opt, base)) / 10.0 >= 0.8                     # :423
+    assert base[0] == 0 and dist[0] <= 1e-6                                               # the query is row 0
+    assert np.array_equal(base, g["baseline_idx"]) and np.array_equal(opt, g["int8_idx"])
+    assert np.array_equal(dist, g["baseline_dist"])
+
+
 def test_dtype_round_trips(oracle):
     import torch
     rng = np.random.default_rng(1)
