@@ -90,7 +90,8 @@ struct DevBuf {
     }
 };
 
-enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_MAXEPS, F_COUNT = 8 };
+enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COMPACT, F_MAXEPS, F_DONE, F_COUNT = 8 };
+// F_DONE: workgroups of the last kernel that have finished (rescore_body publishes the flags to the pinned mirror)
 // a search context's flag words are followed by the coarse kernels' pacing words (kernels_coarse.h: Pace), one
 // per workgroup, cleared together with the flags at the start of every search
 constexpr uint32_t PACE_WORDS = 1024;
@@ -151,6 +152,9 @@ struct SearchCtx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
+    uint32_t* h_flags_dev = nullptr;  // ... as the device sees it (the last kernel of a search publishes the flags there)
+    bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
+    bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
         keysA, keysB, outidx, outscore, dump, qshadow, qres, trace;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
@@ -659,6 +663,8 @@ struct Tunables {
     int plan_launches = getenv("CGV_PLAN_LAUNCHES") ? atoi(getenv("CGV_PLAN_LAUNCHES")) : 0;  // 0 = cost model
     double hit_us = env_double("CGV_PLAN_HIT_US", 1.7);
     double launch_us = env_double("CGV_PLAN_LAUNCH_US", 40.0);
+    int zero_copy = getenv("CGV_ZERO_COPY") ? atoi(getenv("CGV_ZERO_COPY")) : 1;  // pinned host buffers are read / written in place
+    int pace = getenv("CGV_NO_PACE") ? 0 : 1;                                      // soft lockstep of the coarse workgroups (Pace)
 };
 Tunables& tun() {
     static Tunables t;
@@ -756,7 +762,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     c->timed_coarse = false;
     c->coarse_rows = 0;
     c->kprime = 0;
-    HIPCHK(hipMemsetAsync(c->flags, 0, (F_COUNT + PACE_WORDS) * 4, s));
+    c->published = false;
+    // flag + pacing words: zero after a search that ran to completion (its last kernel resets them), else cleared here
+    if (!c->flags_clean) HIPCHK(hipMemsetAsync(c->flags, 0, (F_COUNT + PACE_WORDS) * 4, s));
+    c->flags_clean = false;
     if (h->n == 0) {
         uint64_t tot = (uint64_t)nq * k;
         hipLaunchKernelGGL(pad_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, out_idx,
@@ -784,8 +793,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     if (h->shadow) {  // bf16 copy of the queries + their rounding residuals
         if ((rc = c->qshadow.ensure(shadow_bytes(h, nq)))) return rc;
         if ((rc = c->qres.ensure((size_t)nq * 8))) return rc;
-        hipLaunchKernelGGL(shadow_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, qdev, (uint64_t)nq, h->D, h->lds,
-                           (uint64_t)0, c->qshadow.as<char>(), c->qnorm.as<float>(), c->qinvn.as<float>(),
+        // second pass over the f32 COPY prep just made in device memory (row stride ld, zero padded - the sums do not
+        // change), not over the caller's buffer: that one may be pinned host memory, read over PCIe
+        hipLaunchKernelGGL(shadow_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const float*)c->qrows.as<float>(), (uint64_t)nq,
+                           h->ld, h->lds, (uint64_t)0, c->qshadow.as<char>(), c->qnorm.as<float>(), c->qinvn.as<float>(),
                            c->qres.as<float>(), (uint32_t*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -835,8 +846,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.qgroup = query_group(nqt, a.ld, cdt);
         a.rexp_c = h->rexp;
         a.rexp_q = c->qrexp.as<int8_t>();
-        static const bool no_pace = getenv("CGV_NO_PACE") != nullptr;  // A/B switch
-        a.pace = (Wmax <= PACE_WORDS && !no_pace) ? c->flags + F_COUNT : nullptr;
+        a.pace = (Wmax <= PACE_WORDS && tun().pace) ? c->flags + F_COUNT : nullptr;
 
         if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
@@ -926,6 +936,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
+        r.flags = c->flags;
+        r.flags_host = c->h_flags_dev;
+        r.n_flags = F_COUNT;
+        r.done_word = F_DONE;
+        c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
+        c->published = true;
         static const bool tracing = getenv("CGV_TRACE") != nullptr;  // diagnostics: phase stamps of the final kernel
         r.trace = nullptr;
         if (tracing) {
@@ -937,36 +953,45 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
             // LDS for staged rows: small enough (with the query row) to fit beside a coarse workgroup of the
             // next batch in flight; k' candidates then take one or two passes
-            const size_t budget = h->shadow ? 45 * 1024 : 15 * 1024;  // (the f32 rows of 4k+16 candidates)
+            // all k' rows in ONE pass when they fit 40 KB (k' = 16 at D = 768: 25 KB; r03a: two passes of 9 + 7 rows cost
+            // 14 us per query); several passes beyond
+            const size_t budget = h->shadow ? 45 * 1024 : 40 * 1024;
             uint32_t rpb = (uint32_t)std::max<size_t>(1, std::min<size_t>(kprime, budget / pitch));
             r.rows_per_batch = rpb;
-            size_t lds = rowb + (size_t)rpb * pitch;
+            // [work region][query row]: the query row is fetched first and must survive the selection's key buffer
+            size_t work = (size_t)rpb * pitch;
             if (fused_final) {
                 size_t sel_lds = 0;
                 const SelectArgs sa = make_select_args(c, nq, nqt, last_nsplit, kprime, nullptr, 0, last_expected, &sel_lds);
-                lds = std::max(lds, sel_lds);
+                work = (std::max(work, sel_lds) + 15) / 16 * 16;
+                const uint32_t qoff = (uint32_t)work;
+                const size_t lds = work + rowb;
                 if (h->dtype == CGV_DTYPE_F32)
-                    hipLaunchKernelGGL(final_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, sa, r);
+                    hipLaunchKernelGGL(final_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, sa, r, qoff);
                 else if (h->dtype == CGV_DTYPE_BF16)
-                    hipLaunchKernelGGL(final_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, sa, r);
+                    hipLaunchKernelGGL(final_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, sa, r, qoff);
                 else if (h->dtype == CGV_DTYPE_FP16)
-                    hipLaunchKernelGGL(final_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, sa, r);
+                    hipLaunchKernelGGL(final_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, sa, r, qoff);
                 else
-                    hipLaunchKernelGGL(final_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, sa, r);
-            } else if (h->dtype == CGV_DTYPE_F32) {
-                hipLaunchKernelGGL(rescore_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, r);
-            } else if (h->dtype == CGV_DTYPE_BF16) {
-                hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r);
-            } else if (h->dtype == CGV_DTYPE_FP16) {
-                hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r);
+                    hipLaunchKernelGGL(final_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, sa, r, qoff);
             } else {
-                hipLaunchKernelGGL(rescore_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, r);
+                work = (work + 15) / 16 * 16;
+                const uint32_t qoff = (uint32_t)work;
+                const size_t lds = work + rowb;
+                if (h->dtype == CGV_DTYPE_F32)
+                    hipLaunchKernelGGL(rescore_kernel<DT_F32>, dim3(nq), dim3(256), lds, s, r, qoff);
+                else if (h->dtype == CGV_DTYPE_BF16)
+                    hipLaunchKernelGGL(rescore_kernel<DT_BF16>, dim3(nq), dim3(256), lds, s, r, qoff);
+                else if (h->dtype == CGV_DTYPE_FP16)
+                    hipLaunchKernelGGL(rescore_kernel<DT_FP16>, dim3(nq), dim3(256), lds, s, r, qoff);
+                else
+                    hipLaunchKernelGGL(rescore_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, r, qoff);
             }
         }
         HIPCHK(hipGetLastError());
     }
     if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
-    HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
+    if (!c->published) HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
     return CGV_OK;
 }
 
@@ -975,6 +1000,17 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 // Called WITHOUT h->mu (the context is owned by the caller); takes it for the statistics.
 // Wait for a stream: poll for up to CGV_SPIN_US microseconds (default 3000; 0 = never) before blocking. A
 // batch takes ~1.5 ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it.
+// Device-visible alias of a pinned / registered HOST pointer, or NULL (pageable memory, device memory, unknown).
+void* device_alias(const void* p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (at.type == hipMemoryTypeHost) ? at.devicePointer : nullptr;
+}
+
 int wait_stream(hipStream_t s) {
     static const long spin_us = getenv("CGV_SPIN_US") ? atol(getenv("CGV_SPIN_US")) : 3000;
     if (spin_us > 0) {
@@ -1000,6 +1036,8 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     int rc;
     if ((rc = wait_stream(s))) return rc;
     c->rewrote = false;
+    if (c->published && c->h_flags[F_DONE] != nq)
+        return fail(CGV_ERR_INTERNAL, "search pipeline finished without publishing its flags");
     if (c->h_flags[F_NONFINITE_Q] & 1u)
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
     if (c->h_flags[F_NONFINITE_Q] & 2u)
@@ -1031,6 +1069,8 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         if (c->timed_coarse && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) coarse_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) total_ms = ms;
     }
+    // the last kernel reset the flag words - unless the exact scan ran afterwards (its kernels use them too)
+    c->flags_clean = c->published && !c->rewrote;
     std::lock_guard<std::mutex> lk(h->mu);
     h->st.max_observed_err = std::max(h->st.max_observed_err, me);
     h->st.fallback_queries += nfb;
@@ -1151,6 +1191,8 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "plan_launches")) t.plan_launches = (int)v;
     else if (!strcmp(key, "hit_us")) t.hit_us = v;
     else if (!strcmp(key, "launch_us")) t.launch_us = v;
+    else if (!strcmp(key, "zero_copy")) t.zero_copy = (int)v;
+    else if (!strcmp(key, "pace")) t.pace = (int)v;
     else return -1;
     return 0;
 }
@@ -1217,8 +1259,10 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, (F_COUNT + PACE_WORDS) * 4);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_flags_dev, c.h_flags, 0);
         if (e == hipSuccess) e = hipMemset(c.flags, 0, (F_COUNT + PACE_WORDS) * 4);
+        if (e == hipSuccess) c.flags_clean = true;
     }
     if (e == hipSuccess) e = hipMemset(h->flags, 0, F_COUNT * 4);
     if (e == hipSuccess) e = hipMemset(h->max_norm_dev, 0, 4);
@@ -1609,21 +1653,35 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     };
     auto body = [&]() -> int {
         int r;
-        if ((r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
-        if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
-        if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
+        // Pinned (hipHostMalloc / hipHostRegister) caller buffers are used IN PLACE: the query conversion kernel reads
+        // the f32 batch over PCIe while it converts, the last kernel writes ids and scores straight into the caller's
+        // arrays - no staging copies, no copy-engine launches on the critical path (r03a: -60 us per C2 step).
+        // Pageable buffers go through the context's staging buffers as before.
+        const float* qsrc = tun().zero_copy ? (const float*)device_alias(queries_host) : nullptr;
+        uint64_t* oi = tun().zero_copy ? (uint64_t*)device_alias(out_idx_host) : nullptr;
+        float* os = oi ? (float*)device_alias(out_score_host) : nullptr;
+        const bool direct_out = oi && os;
+        if (!qsrc && (r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
+        if (!direct_out) {
+            if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
+            if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
+            oi = c->outidx.as<uint64_t>();
+            os = c->outscore.as<float>();
+        }
         if ((r = order_after_caller(h, c))) return r;
         stamp(0);
-        HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, s));
+        if (!qsrc) {
+            HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, s));
+            qsrc = c->qstage.as<float>();
+        }
         stamp(1);
-        if ((r = search_enqueue(h, c, c->qstage.as<float>(), nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>())))
-            return r;
+        if ((r = search_enqueue(h, c, qsrc, nq, k, oi, os))) return r;
         stamp(2);
         lk.unlock();
         // MFMA path: the results exist once the enqueued pipeline has run, so their D2H copies ride the same
         // stream and ONE host synchronisation (inside search_finish) covers flags and results; only when the
         // exact scan then rewrote some queries (fallbacks, f32 index) are they copied again.
-        const bool early = c->mfma;
+        const bool early = c->mfma && !direct_out;
         auto copy_out = [&]() -> int {
             HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(out_score_host, c->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -1633,7 +1691,7 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         stamp(3);
         if ((r = search_finish(h, c))) return r;
         stamp(4);
-        if (!early || c->rewrote) {
+        if (!direct_out && (!early || c->rewrote)) {
             if ((r = copy_out())) return r;
             HIPCHK(hipStreamSynchronize(s));
         }
@@ -1683,6 +1741,7 @@ static int prep_single_query(cgv_index* h, SearchCtx* c, const float* query_host
     if ((rc = c->qrexp.ensure(16))) return rc;
     if ((rc = c->qlist.ensure(4))) return rc;
     HIPCHK(hipMemcpyAsync(c->qstage.p, query_host, (size_t)h->D * 4, hipMemcpyHostToDevice, s));
+    c->flags_clean = false;
     HIPCHK(hipMemsetAsync(c->flags + F_NONFINITE_Q, 0, (F_COUNT - F_NONFINITE_Q) * 4, s));
     HIPCHK(hipMemsetAsync(c->qlist.p, 0, 4, s));
     return prep_dispatch(h->dtype, c->qstage.as<float>(), 1, h->D, h->ld, 0, c->qrows.as<char>(),
@@ -1935,6 +1994,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     if ((rc = c->qrexp.ensure((size_t)nq + 16))) return rc;
     if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
     if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
+    c->flags_clean = false;
     rc = prep_dispatch(h->dtype, queries_dev, nq, h->D, h->ld, 0, c->qrows.as<char>(), c->qnorm.as<float>(),
                        c->qinvn.as<float>(), c->qrexp.as<int8_t>(), c->flags + F_NONFINITE_Q, s);
     if (rc) return rc;

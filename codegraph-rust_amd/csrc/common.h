@@ -253,6 +253,9 @@ __device__ inline float exact_cosine_group8(const RQ& q, const RC& c, uint32_t D
     if (D >= 32) {  // adaptive_cosine_similarity dispatch, simd_ops.rs:281-295
         float dp = 0.0f, na = 0.0f, nb = 0.0f;
         const uint32_t chunks = D / 8;
+        // (unrolled: the element loads of 8 iterations are issued together; out of LDS one load at a time costs its
+        //  full latency per iteration - the FMA order per lane is unchanged)
+#pragma unroll 8
         for (uint32_t j = 0; j < chunks; ++j) {
             float x = q.at(8 * j + l);
             float y = c.at(8 * j + l);
@@ -294,6 +297,7 @@ __device__ inline float exact_dot_group8(const RQ& q, const RC& c, uint32_t D, i
     // dot_product_avx2, simd_ops.rs:149-183
     float dp = 0.0f;
     const uint32_t chunks = D / 8;
+#pragma unroll 8
     for (uint32_t j = 0; j < chunks; ++j) dp = fmaf(q.at(8 * j + l), c.at(8 * j + l), dp);
     dp = group8_hsum(dp);
     float result = 0.0f;

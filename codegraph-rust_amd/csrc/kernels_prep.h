@@ -1,5 +1,5 @@
 // kernels_prep.h — ingest: f32 rows -> storage dtype (RNE) + per-row norms.
-// HBM-bound streaming kernels: one wave per row, coalesced 4-byte lanes.
+// HBM-bound streaming kernels: one wave per row, 16-byte loads and stores.
 // Replaces the host-side work of store_embeddings / upload_vectors
 // (crates/codegraph-core/src/traits.rs:13; crates/codegraph-vector/src/gpu.rs:221-246)
 // and the normalise step of parallel_normalize_vectors (simd_ops.rs:386-419) — the
@@ -18,6 +18,36 @@ namespace cgv {
 // norm[r] = sqrt(sum of squares of the ROUNDED values) (any order; used only by the
 // coarse pass), invn[r] = 1/norm or 0. nonfinite: bit 0 set if any input is NaN/Inf, bit 1 if an fp8 row's
 // magnitude is outside the supported range.
+// 16 storage bytes from EPP = 16 / esize consecutive f32 values (RNE)
+template <int DT>
+__device__ inline uint4 pack_piece(const float* x) {
+    uint4 o;
+    if (DT == DT_F32) {
+        o = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+    } else if (DT == DT_BF16) {
+        o.x = (uint32_t)f32_to_bf16_rne(x[0]) | ((uint32_t)f32_to_bf16_rne(x[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16_rne(x[2]) | ((uint32_t)f32_to_bf16_rne(x[3]) << 16);
+        o.z = (uint32_t)f32_to_bf16_rne(x[4]) | ((uint32_t)f32_to_bf16_rne(x[5]) << 16);
+        o.w = (uint32_t)f32_to_bf16_rne(x[6]) | ((uint32_t)f32_to_bf16_rne(x[7]) << 16);
+    } else if (DT == DT_FP16) {
+        o.x = (uint32_t)f32_to_f16_rne(x[0]) | ((uint32_t)f32_to_f16_rne(x[1]) << 16);
+        o.y = (uint32_t)f32_to_f16_rne(x[2]) | ((uint32_t)f32_to_f16_rne(x[3]) << 16);
+        o.z = (uint32_t)f32_to_f16_rne(x[4]) | ((uint32_t)f32_to_f16_rne(x[5]) << 16);
+        o.w = (uint32_t)f32_to_f16_rne(x[6]) | ((uint32_t)f32_to_f16_rne(x[7]) << 16);
+    } else {
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            w[d] = (uint32_t)f32_to_e4m3_rne(x[4 * d]) | ((uint32_t)f32_to_e4m3_rne(x[4 * d + 1]) << 8) |
+                   ((uint32_t)f32_to_e4m3_rne(x[4 * d + 2]) << 16) | ((uint32_t)f32_to_e4m3_rne(x[4 * d + 3]) << 24);
+        o = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return o;
+}
+
+// One wave per row; a lane converts whole 16-byte OUTPUT pieces (4 f32 / 8 two-byte / 16 fp8 elements): 16-byte loads
+// of the f32 input (the query batch may sit in pinned HOST memory and travel over PCIe right here - wide requests
+// matter), one 16-byte store per piece straight into the blocked layout (round 2 stored 2 bytes per lane).
 template <int DT>
 __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ in, uint64_t n,
                                                         uint32_t D, uint32_t ld, uint64_t row0,
@@ -28,6 +58,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
                                                         uint32_t* __restrict__ nonfinite,
                                                         uint32_t* __restrict__ zero0,
                                                         uint32_t* __restrict__ zero1) {
+    constexpr int EPP = 16 / Elem<DT>::bytes;
     const int lane = threadIdx.x & 63;
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -36,10 +67,33 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
         if (zero1) zero1[row0 + row] = 0u;
     }
     const float* src = in + row * (uint64_t)D;
+    const bool vec = (D & 3u) == 0 && (((uintptr_t)in) & 15u) == 0;  // every row starts 16-byte aligned
+    const uint32_t pieces = ld / EPP;
+    auto load_piece = [&](uint32_t pc, float* x) {
+        const uint32_t i0 = pc * EPP;
+        if (vec && i0 + EPP <= D) {
+#pragma unroll
+            for (int v = 0; v < EPP / 4; ++v) {
+                const float4 f = *(const float4*)(src + i0 + 4 * v);
+                x[4 * v] = f.x;
+                x[4 * v + 1] = f.y;
+                x[4 * v + 2] = f.z;
+                x[4 * v + 3] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < EPP; ++t) x[t] = (i0 + t < D) ? src[i0 + t] : 0.0f;
+        }
+    };
     int e = 0;
     if (DT == DT_FP8) {  // per-row power-of-two scale: amax * 2^e <= 448 (common.h)
         float amax = 0.0f;
-        for (uint32_t i = lane; i < D; i += 64) amax = fmaxf(amax, fabsf(src[i]));
+        for (uint32_t pc = lane; pc < pieces; pc += 64) {
+            float x[EPP];
+            load_piece(pc, x);
+#pragma unroll
+            for (int t = 0; t < EPP; ++t) amax = fmaxf(amax, fabsf(x[t]));
+        }
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
         e = fp8_row_exponent(amax);
         if (lane == 0) rexp[row0 + row] = (int8_t)e;
@@ -47,13 +101,20 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     float ss = 0.0f;
     int bad = 0;
     if (DT == DT_FP8 && (e < FP8_EXP_MIN || e > FP8_EXP_MAX)) bad = 2;  // magnitude outside the supported range (common.h)
-    for (uint32_t i = lane; i < ld; i += 64) {
-        float x = (i < D) ? src[i] : 0.0f;
-        if (!(fabsf(x) <= 3.402823466e38f)) bad |= 1;  // NaN or Inf
-        if (DT == DT_FP8) x = ldexpf(x, e);            // exact
-        Elem<DT>::cvt_store(elem_ptr<DT>(out, row0 + row, ld, i), x);
-        float xr = Elem<DT>::round_trip(x);
-        ss = fmaf(xr, xr, ss);
+    const uint64_t R = row0 + row;
+    char* obase = (DT == DT_F32) ? out + R * (uint64_t)ld * 4 : out + blocked_row_base(R, ld, kchunk_of(DT));
+    const uint32_t key = blocked_row_key(R);
+    for (uint32_t pc = lane; pc < pieces; pc += 64) {
+        float x[EPP];
+        load_piece(pc, x);
+#pragma unroll
+        for (int t = 0; t < EPP; ++t) {
+            if (!(fabsf(x[t]) <= 3.402823466e38f)) bad |= 1;  // NaN or Inf
+            if (DT == DT_FP8) x[t] = ldexpf(x[t], e);          // exact
+            const float xr = Elem<DT>::round_trip(x[t]);
+            ss = fmaf(xr, xr, ss);
+        }
+        *(uint4*)(obase + ((DT == DT_F32) ? (uint64_t)pc * 16 : blocked_piece_off(pc, key))) = pack_piece<DT>(x);
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if (lane == 0) {

@@ -189,6 +189,31 @@ __device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, u
                                     uint64_t* outk /*[64]*/, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
     auto from_lds = [&](uint32_t e) { return keys[e]; };
+    if (M <= 512) {
+        // the common case (a good threshold leaves ~100 keys): ONE wave, 8 keys per lane, its sorted output is the
+        // result - no per-wave lists, no merge (measured r03a: 9.4 us of the final kernel's 40 us per workgroup went
+        // to the four-wave extraction + single-lane merge)
+        if (wv == 0) {
+            uint64_t r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t e = (uint32_t)lane + 64u * i;
+                r[i] = e < M ? keys[e] : 0ull;
+            }
+            sort8_desc(r);
+            for (uint32_t rd = 0; rd < keep; ++rd) {
+                const uint64_t w = wave_max_u64(r[0]);
+                if (w != 0ull && r[0] == w) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) r[i] = r[i + 1];
+                    r[7] = 0ull;
+                }
+                if (lane == 0) outk[rd] = w;
+            }
+        }
+        __syncthreads();
+        return;
+    }
     if (M <= 2048) {
         extract_regs<8>(from_lds, M, keep, part, tid);
     } else if (M <= 4096) {
@@ -375,6 +400,13 @@ struct RescoreArgs {
     float res_abs_c;        // max over the corpus of |dc|
     uint32_t* stat_maxeps;  // [1] f2ord-free max of the eps actually used (non-negative float bits)
     uint64_t* trace;        // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps (100 MHz) of the phases, or NULL
+    // End-of-search publication: the LAST workgroup to finish copies the search's n_flags flag words (fallback count,
+    // non-finite bits, error maxima, ...) into the pinned host mirror and clears them for the next search, so the host
+    // needs neither a flags D2H copy after the pipeline nor a memset before the next one. flags[done_word] counts
+    // finished workgroups.
+    uint32_t* flags;        // device flag words of the search context
+    uint32_t* flags_host;   // their pinned, device-mapped mirror; NULL = do not publish
+    uint32_t n_flags, done_word;
 };
 
 // Exact reference arithmetic on the k' candidates of each query, exact (score desc, row asc)
@@ -386,14 +418,22 @@ struct RescoreArgs {
 // of the reference (common.h) run the FMA chains out of LDS, 32 candidates at a time.
 // Dynamic LDS: [query row: ld*esize B][batch rows: (ld*esize + 16) B each, +16 B pad against bank
 // conflicts]. rows_per_batch is chosen by the host (>= 1).
+// Query row -> LDS (linear element order), issued as early as the caller can: the loads are independent of the
+// selection that runs first. Visible to all waves after the caller's next __syncthreads().
+template <int DT>
+__device__ inline void stage_query_row(const RescoreArgs& a, uint32_t q, char* qs, int tid) {
+    const uint32_t pieces = a.ld * Elem<DT>::bytes / 16;
+    const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
+    for (uint32_t pc = tid; pc < pieces; pc += 256) *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)piece_ptr<DT>(qr, pc);
+}
+
 template <int DT>
 __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t nb, const uint64_t* ckeys /* LDS [nb] */,
-                                    float tau, bool overflow, char* smem, int tid) {
+                                    float tau, bool overflow, char* rs /* LDS: staged candidate rows */,
+                                    const char* qs /* LDS: the query row (stage_query_row) */, int tid) {
     __shared__ uint64_t ekeys[CAND_CAPS];
     __shared__ uint32_t maxerr, tripped;
     const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
-    char* qs = smem;
-    char* rs = smem + rowb;
     if (tid == 0) {
         maxerr = 0;
         tripped = 0;
@@ -413,31 +453,35 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     const float trip = 0.5f * eps;
     const uint32_t P = next_pow2(nb < 2 ? 2 : nb);
     for (uint32_t i = nb + tid; i < P; i += 256) ekeys[i] = 0ull;
-    {   // query row -> LDS (linear element order)
-        const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
-        for (uint32_t pc = tid; pc < pieces; pc += 256)
-            *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)piece_ptr<DT>(qr, pc);
-    }
+    // Gather: 8 candidates at a time, 32 lanes per candidate, lane l of a candidate's group fetches pieces l, l + 32, ...
+    // (no integer division per piece); up to 8 independent 16-byte loads per thread are issued before the first LDS
+    // store, so the 16 x 96 pieces of a C2 query travel in ONE memory round trip (r03a: two round trips, 14 us).
+    const uint32_t grp = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u;
+    const uint32_t nj = (pieces + 31) / 32;  // 32-piece slabs per row
     for (uint32_t c0 = 0; c0 < nb; c0 += a.rows_per_batch) {
         const uint32_t nbat = (nb - c0) < a.rows_per_batch ? (nb - c0) : a.rows_per_batch;
         __syncthreads();
-        const uint32_t total = nbat * pieces;
-        for (uint32_t e0 = tid; e0 < total; e0 += 4 * 256) {
-            uint4 v[4];
+        const uint32_t items = ((nbat + 7) / 8) * nj;  // (round of 8 candidates, slab) pairs, slab fastest
+        uint32_t cr = 0, j = 0;                         // round and slab of item i0 (uniform, kept incrementally)
+        for (uint32_t i0 = 0; i0 < items; i0 += 8) {
+            uint4 v[8];
+            uint32_t cu[8], pu[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t e = e0 + i * 256;
-                if (e < total) {
-                    const uint32_t c = e / pieces, pc = e % pieces;
-                    const uint32_t row = key_row(ckeys[c0 + c]);
-                    v[i] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pc);
+            for (int u = 0; u < 8; ++u) {
+                cu[u] = (i0 + u < items) ? cr * 8 + grp : 0xFFFFFFFFu;
+                pu[u] = j * 32 + l32;
+                if (++j == nj) {
+                    j = 0;
+                    ++cr;
+                }
+                if (cu[u] < nbat && pu[u] < pieces) {
+                    const uint32_t row = key_row(ckeys[c0 + cu[u]]);
+                    v[u] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pu[u]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t e = e0 + i * 256;
-                if (e < total) *(uint4*)(rs + (size_t)(e / pieces) * pitch + (size_t)(e % pieces) * 16) = v[i];
-            }
+            for (int u = 0; u < 8; ++u)
+                if (cu[u] < nbat && pu[u] < pieces) *(uint4*)(rs + (size_t)cu[u] * pitch + (size_t)pu[u] * 16) = v[u];
         }
         __syncthreads();
         phase_stamp(a.trace, q, 3, tid);
@@ -484,29 +528,46 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         }
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);
+        if (a.flags_host) {
+            // publish + reset by the last workgroup (G16 counter form: release fence, ticket, acquire fence)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t = __hip_atomic_fetch_add(a.flags + a.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == gridDim.x) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (uint32_t i = 0; i < a.n_flags; ++i) {
+                    const uint32_t v = __hip_atomic_load(a.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.flags_host[i] = (i == a.done_word) ? t + 1 : v;
+                    __hip_atomic_store(a.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
     phase_stamp(a.trace, q, 6, tid);
 }
 
+// Dynamic LDS of rescore_kernel / final_kernel: [work region: staged candidate rows (and, in final_kernel, the
+// selection's key buffer first)][query row: ld * esize bytes at offset a.qoff].
 template <int DT>
-__global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a) {
+__global__ __launch_bounds__(256) void rescore_kernel(const RescoreArgs a, uint32_t qoff) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint64_t ckeys[CAND_CAPS];
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
+    stage_query_row<DT>(a, q, smem + qoff, tid);
     const uint32_t nb = a.nbest[q];
     for (uint32_t i = tid; i < nb; i += 256) ckeys[i] = a.best[(uint64_t)q * a.kprime + i];
     __syncthreads();
-    rescore_body<DT>(a, q, nb, ckeys, a.tau[q], a.overflow[q] != 0, smem, tid);
+    rescore_body<DT>(a, q, nb, ckeys, a.tau[q], a.overflow[q] != 0, smem, smem + qoff, tid);
 }
 
 // Last stage, k' <= 64: the final selection (merge of best[q] with the last launch's candidate
 // sub-lists) and the exact re-score in ONE launch - the top-k' keys go from the extraction straight
 // into the re-score through LDS instead of a best[]/tau[] round trip and a second launch.
-// Dynamic LDS = max(select's key buffer + prefix, re-score's staged rows); the key buffer is dead
-// once the extraction is done.
+// Dynamic LDS = max(select's key buffer + prefix, re-score's staged rows) + the query row behind it (fetched
+// first, while the selection runs); the key buffer is dead once the extraction is done.
 template <int DT>
-__global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const RescoreArgs a) {
+__global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const RescoreArgs a, uint32_t qoff) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint64_t ckeys[CAND_CAPS];
     __shared__ uint64_t part[4 * 64];
@@ -517,6 +578,7 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     const uint32_t q = blockIdx.x;
     bool trunc = false;
     phase_stamp(a.trace, q, 0, tid);
+    stage_query_row<DT>(a, q, smem + qoff, tid);
     const uint32_t M = gather_keys(sa, q, keys, pre, tid, &trunc);
     phase_stamp(a.trace, q, 1, tid);
     const uint32_t keep = M < sa.kprime ? M : sa.kprime;
@@ -527,7 +589,7 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
     const bool overflow = trunc || sa.overflow[q] != 0;
     __syncthreads();
-    rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, tid);
+    rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);
 }
 
 // Per-shard results -> one packed record row per query for the single all-gather of SURVEY.md §8(e):
