@@ -663,7 +663,7 @@ struct Tunables {
     int plan_launches = getenv("CGV_PLAN_LAUNCHES") ? atoi(getenv("CGV_PLAN_LAUNCHES")) : 0;  // 0 = cost model
     double hit_us = env_double("CGV_PLAN_HIT_US", 1.7);
     double launch_us = env_double("CGV_PLAN_LAUNCH_US", 40.0);
-    int zero_copy = getenv("CGV_ZERO_COPY") ? atoi(getenv("CGV_ZERO_COPY")) : 1;  // pinned host buffers are read / written in place
+    int zero_copy = getenv("CGV_ZERO_COPY") ? atoi(getenv("CGV_ZERO_COPY")) : 3;  // pinned host buffers in place: 1 queries, 2 results
     int pace = getenv("CGV_NO_PACE") ? 0 : 1;                                      // soft lockstep of the coarse workgroups (Pace)
 };
 Tunables& tun() {
@@ -846,7 +846,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.qgroup = query_group(nqt, a.ld, cdt);
         a.rexp_c = h->rexp;
         a.rexp_q = c->qrexp.as<int8_t>();
-        a.pace = (Wmax <= PACE_WORDS && tun().pace) ? c->flags + F_COUNT : nullptr;
+        const uint32_t* pace_words = (Wmax <= PACE_WORDS && tun().pace) ? c->flags + F_COUNT : nullptr;
+        a.pace = const_cast<uint32_t*>(pace_words);
 
         if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
@@ -854,6 +855,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             if ((rc = c->dump.ensure((size_t)nq * M * 4))) return rc;
             CoarseArgs sa = a;
             sa.dump = c->dump.as<float>();
+            sa.pace = nullptr;
             sa.sample_ld = M;
             sa.j0 = 0;
             sa.cnt = p.sample_tiles;
@@ -889,6 +891,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             a.j0 = j0;
             a.cnt = cnt;
             a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
+            // Soft lockstep pays where the workgroups of a group can drift apart: launches of 100+ tiles per workgroup
+            // (C5: 1000+). On short walks (C2: 55 tiles) the group stays together by itself and the per-tile poll only
+            // costs (r03b: C2 step 1.458 -> 1.453 ms, the 125 k-row shard 0.381 -> 0.378 without it).
+            a.pace = (cnt / a.nsplit >= 128u || tun().pace > 1) ? const_cast<uint32_t*>(pace_words) : nullptr;
             const bool dominant = (st + 1 == p.counts.size());
             if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
             if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s))) return rc;
@@ -1657,8 +1663,8 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         // the f32 batch over PCIe while it converts, the last kernel writes ids and scores straight into the caller's
         // arrays - no staging copies, no copy-engine launches on the critical path (r03a: -60 us per C2 step).
         // Pageable buffers go through the context's staging buffers as before.
-        const float* qsrc = tun().zero_copy ? (const float*)device_alias(queries_host) : nullptr;
-        uint64_t* oi = tun().zero_copy ? (uint64_t*)device_alias(out_idx_host) : nullptr;
+        const float* qsrc = (tun().zero_copy & 1) ? (const float*)device_alias(queries_host) : nullptr;
+        uint64_t* oi = (tun().zero_copy & 2) ? (uint64_t*)device_alias(out_idx_host) : nullptr;
         float* os = oi ? (float*)device_alias(out_score_host) : nullptr;
         const bool direct_out = oi && os;
         if (!qsrc && (r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;

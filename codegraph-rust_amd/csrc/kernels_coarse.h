@@ -370,6 +370,42 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
     }
 }
 
+// Emitting epilogue of the 8-wave bf16 / fp16 kernel with the conservative thresholds thr[mb][nb] PRECOMPUTED (the
+// kernel forms them in the MFMA gaps of the tile's last k-step, under matrix-pipe cover): what is left between the
+// last MFMA of a tile and the first of the next is, per 32 x 32 block, the maximum of the lane's 16 scores (10 VALU),
+// one compare and a scalar OR of the compare mask - ~90 VALU per wave instead of ~200 (r03a clock ablation: the
+// epilogue cost 0.14 of the main launch's 1.17 ms while the matrix pipe sat idle in all 8 waves). Blocks are flagged
+// wave-wide: the slow path runs block_hits for every lane of a flagged block (lanes without a hit fall through its
+// group maxima). Blocks beyond the end of the corpus hold zero accumulators; block_hits drops rows >= n.
+template <int BM, int BN, int WTM, int WTN, int MB, int NB>
+__device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], const float (&thr)[MB][NB],
+                                                 uint32_t tile, int wm, int wn, int lane, uint32_t g, uint32_t qt,
+                                                 const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
+                                                 const float* invn_s) {
+    int lane_o = lane;  // opaque copy: no hoisting of per-register row offsets out of the K loop (see tile_epilogue)
+    asm volatile("" : "+v"(lane_o));
+    lane = lane_o;
+    // vmax3 (inline asm) reads MFMA results: up to 18 wait states, and hipcc pads nothing for asm. The maxima are plain
+    // (movable) asm: the pad is tied to the accumulators of the k-step's LAST four MFMAs (serpentine order), so no read
+    // of those can be scheduled above it; the first four blocks' MFMAs are >= 4 matrix instructions old by then.
+    static_assert(MB == 4 && NB == 2, "pad tied to the serpentine order of a 4 x 2 wave tile");
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][1]), "+v"(acc[3][0])::"memory");
+    unsigned long long anyhit = 0ull;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) anyhit |= __ballot(block_max(acc[mb][nb]) > thr[mb][nb]);
+    if (__builtin_expect(anyhit != 0ull, 0)) {  // cold
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if (__ballot(block_max(acc[mb][nb]) > thr[mb][nb]) != 0ull)
+                    block_hits<BM, BN>(a, acc[mb][nb], thr[mb][nb], tauv[nb], invq[nb], (uint32_t)(wm * WTM + mb * 32),
+                                       (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane, g, qt, cntq, invn_s);
+    }
+}
+
 // MODE: COARSE_EMIT / COARSE_DUMP / COARSE_SAMPLE (coarse_launch.h; tile_epilogue).
 // ABL: timing-only ablation mask for scripts/gpu_ablate.sh / gpu_clock.sh (results are WRONG for ABL != 0):
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
@@ -410,6 +446,19 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         tauv[nb] = tau;
         invq[nb] = iq;
         tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
+    }
+    // Conservative per-block threshold in raw-accumulator units (block_threshold): thr(mb, nb) = ta[nb] * (the block's
+    // smallest row norm when tq >= 0, its largest when tq < 0; 1 for the dot metric and for infinite thresholds),
+    // 2^-18 head room folded into ta. Formed per tile in the MFMA gaps of its last k-step (CGV_THR below).
+    float ta[NB], thr[MB][NB];
+    bool tneg[NB], tone[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        tone[nb] = (a.metric == METRIC_DOT) || !(fabsf(tq[nb]) < INFINITY);
+        tneg[nb] = tq[nb] < 0.0f;
+        ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) thr[mb][nb] = INFINITY;
     }
 
     // uniform by construction; readfirstlane makes it provable (the 64-bit divisions run on the VALU and would
@@ -570,6 +619,34 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[0], CGV_NOP_ACTION)                                                   \
         MMA(3, 0, FA, FB) CGV_GAP(3, 0, NA[0], CGV_NOP_ACTION)                                                   \
     }
+    // The same k-step with every gap's action spelled out (the tile's LAST k-step carries the threshold set-up).
+#define CGV_KSTEP_X(MMA, FA, FB, NA, G0, G1, G2, G3, G4, G5, G6, G7)                     \
+    {                                                                                    \
+        MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], G0)                                       \
+        MMA(0, 1, FA, FB) CGV_GAP(0, 1, FA[1], G1)                                       \
+        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], G2)                                       \
+        MMA(1, 0, FA, FB) CGV_GAP(1, 0, FA[2], G3)                                       \
+        MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], G4)                                       \
+        MMA(2, 1, FA, FB) CGV_GAP(2, 1, FA[3], G5)                                       \
+        MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[0], G6)                                       \
+        MMA(3, 0, FA, FB) CGV_GAP(3, 0, NA[0], G7)                                       \
+    }
+    // thresholds of the tile that ends here: block norm bounds from the side-data ring (safe to read once the
+    // stage's counted wait + barrier in gap 0 have passed: KC >= 3, see issue_side), then 3 VALU per block
+    float4 mn4, mx4;
+#define CGV_THR_LOAD(SEQ)                                                                             \
+    {                                                                                                 \
+        const float* st_ = stat_s + ((SEQ) & (NINV - 1)) * 16 + wm * MB;                              \
+        mn4 = *(const float4*)st_;                                                                    \
+        mx4 = *(const float4*)(st_ + 8);                                                              \
+    }
+#define CGV_THR(MBI, NBI, MN, MX)                                                                     \
+    {                                                                                                 \
+        float mul_ = tone[NBI] ? 1.0f : (tneg[NBI] ? (MX) : (MN));                                    \
+        asm volatile("" : "+v"(mul_));                                                                \
+        thr[MBI][NBI] = ta[NBI] * mul_;                                                               \
+        asm volatile("" : "+v"(thr[MBI][NBI]));                                                       \
+    }
 #define CGV_STAGE_SYNC                                                      \
     if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
@@ -580,6 +657,17 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_A_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_A_PHASE_Z(SB_) CGV_KSTEP(CGV_MMAZ, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
+#define CGV_B_PHASE_LAST(SB_, SEQ)                                                                                  \
+    CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_LOAD_FRAGS(fa0, fb0, SB_, 0), CGV_THR_LOAD(SEQ),        \
+                CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y),   \
+                CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
+                CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
+#define CGV_THR_ALL(SEQ)                                                                                            \
+    {                                                                                                               \
+        CGV_THR_LOAD(SEQ)                                                                                           \
+        CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x) CGV_THR(1, 0, mn4.y, mx4.y) CGV_THR(1, 1, mn4.y, mx4.y) \
+        CGV_THR(2, 0, mn4.z, mx4.z) CGV_THR(2, 1, mn4.z, mx4.z) CGV_THR(3, 0, mn4.w, mx4.w) CGV_THR(3, 1, mn4.w, mx4.w) \
+    }
 
     // ---- prologue: three stages in flight --------------------------------------------
     if (total == 0) {  // uniform: nothing to stream for this workgroup
@@ -612,10 +700,15 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     }
 
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
-    if (!(ABL & 1))                                                                                                \
-        tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,      \
-                                                      invn_s + ((SEQ) & (NINV - 1)) * 256,                         \
-                                                      stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ));
+    if (!(ABL & 1)) {                                                                                              \
+        if (MODE == 0)                                                                                             \
+            tile_filter_emit<BM, BN, WTM, WTN, MB, NB>(a, acc, thr, TILE, wm, wn, lane, g, qt, tauv, invq, cntq,     \
+                                                       invn_s + ((SEQ) & (NINV - 1)) * 256);                       \
+        else                                                                                                       \
+            tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,  \
+                                                          invn_s + ((SEQ) & (NINV - 1)) * 256,                     \
+                                                          stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ)); \
+    }
 
     // Tile-structured: [first stage of a tile: zero-C MFMAs] then KC-1 ordinary stages; at a tile
     // boundary the iteration is B phase (last k-step of the previous tile), its epilogue, zero-C A phase.
@@ -634,10 +727,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-            CGV_B_PHASE(sb);
+            CGV_B_PHASE_LAST(sb, tl - 1);
             if (wave == 0) pace_step(pace, tl + 1, lane);
             const uint32_t nt = next_tile(ct);
             side_wait();
+            if (MODE == 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
             CGV_EPILOGUE(a.T1 + ct, tl - 1);
             issue_side(nt, tl);  // the tile that starts here
             ct = nt;
@@ -658,9 +752,15 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
     __builtin_amdgcn_s_barrier();
+    if (MODE == 0) CGV_THR_ALL(ntl - 1);
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);
 #undef CGV_A_PHASE_Z
 #undef CGV_B_PHASE
+#undef CGV_B_PHASE_LAST
+#undef CGV_THR_ALL
+#undef CGV_THR
+#undef CGV_THR_LOAD
+#undef CGV_KSTEP_X
 #undef CGV_A_PHASE
 #undef CGV_EPILOGUE
 #undef CGV_STAGE_SYNC

@@ -517,6 +517,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         a.out_idx[(uint64_t)q * a.k + j] = oi;
         a.out_score[(uint64_t)q * a.k + j] = os;
     }
+    phase_stamp(a.trace, q, 6, tid);
     if (tid == 0) {
         atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
@@ -529,12 +530,14 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);
         if (a.flags_host) {
-            // publish + reset by the last workgroup (G16 counter form: release fence, ticket, acquire fence)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // Publish + reset by the last workgroup. Everything it reads was written by device-scope ATOMICS (performed
+            // at the coherent level, never cached in a CU's L1 or an XCD's L2), so no cache write-back / invalidate is
+            // needed - only that this lane's atomics above are complete before its ticket: vmcnt(0) (gfx9: stores and
+            // non-returning atomics count on vmcnt too). A release fence here (buffer_wbl2 in each of 1024 workgroups)
+            // measured +23 us on the final kernel (r03b).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t t = __hip_atomic_fetch_add(a.flags + a.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t + 1 == gridDim.x) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 for (uint32_t i = 0; i < a.n_flags; ++i) {
                     const uint32_t v = __hip_atomic_load(a.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     a.flags_host[i] = (i == a.done_word) ? t + 1 : v;
@@ -543,7 +546,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             }
         }
     }
-    phase_stamp(a.trace, q, 6, tid);
+    phase_stamp(a.trace, q, 7, tid);
 }
 
 // Dynamic LDS of rescore_kernel / final_kernel: [work region: staged candidate rows (and, in final_kernel, the

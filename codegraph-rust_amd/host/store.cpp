@@ -571,7 +571,9 @@ int cgvs_store_create(int dtype, int device_id, uint32_t ef_search, cgvs_store**
     if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (cgv_device_count() == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
-    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16) return fail(CGV_ERR_INVALID_ARG, "bad dtype");
+    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16 && dtype != CGV_DTYPE_FP8E4M3 &&
+        dtype != CGV_DTYPE_F32_SHADOW)
+        return fail(CGV_ERR_INVALID_ARG, "bad dtype (f32, bf16, fp16, fp8e4m3, f32 + bf16 shadow)");
     cgvs_store* s = new cgvs_store();
     s->backend.reset(new HipKnnBackend(dtype, device_id));
     s->ef_search = ef_search;

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (workload table + generators)
 
-KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 1, "pace": 1}
+KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1}
 
 
 def main():
@@ -137,14 +137,14 @@ def main():
         print("host timeline us (median): order=%.1f h2d_enq=%.1f pipeline_enq=%.1f d2h_enq=%.1f stream_done=%.1f" % tuple(h[:5]))
         s = np.stack(stamps[2:]).astype(np.int64)            # [steps][nq][8], 100 MHz ticks
         t0 = s[:, :, 0].min(axis=1, keepdims=True)
-        rel = (s[:, :, :7] - t0[:, :, None]) / 100.0         # us since the first workgroup started
-        names = ["start", "keys", "topk", "rows_staged", "scored", "sorted", "end"]
+        rel = (s[:, :, :8] - t0[:, :, None]) / 100.0         # us since the first workgroup started
+        names = ["start", "keys", "topk", "rows_staged", "scored", "sorted", "outputs", "end"]
         print("final kernel phases, us since the first workgroup's start (median over steps of: min / median / max over queries)")
         for j, nme in enumerate(names):
             print("  %-12s min %.2f  med %.2f  max %.2f" % (nme, np.median(rel[:, :, j].min(axis=1)), np.median(np.median(rel[:, :, j], axis=1)),
                                                          np.median(rel[:, :, j].max(axis=1))))
-        dur = (s[:, :, 1:7] - s[:, :, 0:6]) / 100.0
-        print("  per-workgroup phase durations us (median over all): " + ", ".join("%s %.2f" % (names[j + 1], np.median(dur[:, :, j])) for j in range(6)))
+        dur = (s[:, :, 1:8] - s[:, :, 0:7]) / 100.0
+        print("  per-workgroup phase durations us (median over all): " + ", ".join("%s %.2f" % (names[j + 1], np.median(dur[:, :, j])) for j in range(7)))
     ix.close()
 
 
