@@ -664,6 +664,7 @@ struct Tunables {
     double hit_us = env_double("CGV_PLAN_HIT_US", 1.7);
     double launch_us = env_double("CGV_PLAN_LAUNCH_US", 40.0);
     int zero_copy = getenv("CGV_ZERO_COPY") ? atoi(getenv("CGV_ZERO_COPY")) : 3;  // pinned host buffers in place: 1 queries, 2 results
+    int epi = getenv("CGV_EPI") ? atoi(getenv("CGV_EPI")) : 1;   // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int pace = getenv("CGV_NO_PACE") ? 0 : 1;                                      // soft lockstep of the coarse workgroups (Pace)
 };
 Tunables& tun() {
@@ -834,6 +835,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.overflow = c->overflow.as<uint32_t>();
         a.dump = nullptr;
         a.sample_ld = 0;
+        a.epi = (uint32_t)tun().epi;
         a.n = (uint32_t)h->n;
         a.nq = nq;
         a.ld = h->shadow ? h->lds : h->ld;
@@ -942,12 +944,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
-        r.flags = c->flags;
-        r.flags_host = c->h_flags_dev;
-        r.n_flags = F_COUNT;
-        r.done_word = F_DONE;
         c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
-        c->published = true;
+        c->published = true;     // publish_flags_kernel behind the last kernel, below
         static const bool tracing = getenv("CGV_TRACE") != nullptr;  // diagnostics: phase stamps of the final kernel
         r.trace = nullptr;
         if (tracing) {
@@ -994,6 +992,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                     hipLaunchKernelGGL(rescore_kernel<DT_FP8>, dim3(nq), dim3(256), lds, s, r, qoff);
             }
         }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
+                           (uint32_t)F_DONE, nq);
         HIPCHK(hipGetLastError());
     }
     if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1199,6 +1200,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "launch_us")) t.launch_us = v;
     else if (!strcmp(key, "zero_copy")) t.zero_copy = (int)v;
     else if (!strcmp(key, "pace")) t.pace = (int)v;
+    else if (!strcmp(key, "epi")) t.epi = (int)v;
     else return -1;
     return 0;
 }
@@ -2049,6 +2051,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.rexp_q = c->qrexp.as<int8_t>();
     a.pace = nullptr;
     a.sample_ld = 0;
+    a.epi = 1;
     if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;

@@ -91,6 +91,26 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
         return coarse_hip_status("coarse_w4_kernel");
     }
+    if constexpr (ABLATE) {  // A/B of the emitting epilogue (bf16 build only): a.epi, set from the `epi` knob
+        if (a.epi == 0) {
+            auto k0 = coarse_kernel<DT, COARSE_EMIT, 0, 0>;
+            if (int rc = coarse_set_lds((const void*)k0)) return rc;
+            hipLaunchKernelGGL(k0, dim3(W), dim3(512), lds, s, a);
+            return coarse_hip_status("coarse_kernel (epi 0)");
+        }
+        if (a.epi == 3) {
+            auto k3 = coarse_kernel<DT, COARSE_EMIT, 0, 3>;
+            if (int rc = coarse_set_lds((const void*)k3)) return rc;
+            hipLaunchKernelGGL(k3, dim3(W), dim3(512), lds, s, a);
+            return coarse_hip_status("coarse_kernel (epi 3)");
+        }
+        if (a.epi == 2) {
+            auto k2 = coarse_kernel<DT, COARSE_EMIT, 0, 2>;
+            if (int rc = coarse_set_lds((const void*)k2)) return rc;
+            hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);
+            return coarse_hip_status("coarse_kernel (epi 2)");
+        }
+    }
     hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);
     return coarse_hip_status("coarse_kernel");
 }

@@ -42,6 +42,11 @@ namespace cgv {
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
 
 template <int DT>
 struct Mfma;
@@ -95,6 +100,7 @@ struct CoarseArgs {
     const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
     uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
     uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump` (16 per sampled tile)
+    uint32_t epi;           // A/B switch of the emitting epilogue (coarse_kernel's EPI; bf16 build only), default 1
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -412,7 +418,12 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
 // 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
-template <int DT, int MODE, int ABL = 0>
+// EPI (A/B of the emitting epilogue, scripts/ab.py knob `epi`): 0 = round-2 form (thresholds + per-lane hit mask at the
+// tile boundary, tile_epilogue); 1 = thresholds in the last k-step's MFMA gaps (plain LDS reads) + lean wave-wide filter;
+// 2 = the same with the block norm bounds read AHEAD of the fragment loads and a counted lgkmcnt wait; 3 = thresholds as
+// in 1, and each block's filter sits right in front of the zero-C MFMA that overwrites the block (first k-step of the next
+// tile): one wave's 11 filter VALU run beside its SIMD partner's MFMA instead of all 8 waves filtering with the pipe idle.
+template <int DT, int MODE, int ABL = 0, int EPI = 1>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -633,13 +644,24 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     }
     // thresholds of the tile that ends here: block norm bounds from the side-data ring (safe to read once the
     // stage's counted wait + barrier in gap 0 have passed: KC >= 3, see issue_side), then 3 VALU per block
-    float4 mn4, mx4;
+    f32x4_t mn4, mx4;
 #define CGV_THR_LOAD(SEQ)                                                                             \
     {                                                                                                 \
         const float* st_ = stat_s + ((SEQ) & (NINV - 1)) * 16 + wm * MB;                              \
-        mn4 = *(const float4*)st_;                                                                    \
-        mx4 = *(const float4*)(st_ + 8);                                                              \
+        mn4 = *(const f32x4_t*)st_;                                                                   \
+        mx4 = *(const f32x4_t*)(st_ + 8);                                                             \
     }
+    // EPI 2: the two reads go out FIRST in gap 0 (LDS returns in order), the 6 fragment reads behind them; gap 2 then
+    // waits for "all but the 6 youngest" - the wave never waits for its fragments there. Inline asm: hipcc would wait
+    // lgkmcnt(0).
+#define CGV_THR_LOAD_ASM(SEQ)                                                                         \
+    {                                                                                                 \
+        const uint32_t sa_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(   \
+            stat_s + ((SEQ) & (NINV - 1)) * 16 + wm * MB);                                            \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32"                          \
+                     : "=&v"(mn4), "=&v"(mx4) : "v"(sa_) : "memory");                                 \
+    }
+#define CGV_THR_WAIT asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(mn4), "+v"(mx4)::"memory");
 #define CGV_THR(MBI, NBI, MN, MX)                                                                     \
     {                                                                                                 \
         float mul_ = tone[NBI] ? 1.0f : (tneg[NBI] ? (MX) : (MN));                                    \
@@ -657,11 +679,40 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_A_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_A_PHASE_Z(SB_) CGV_KSTEP(CGV_MMAZ, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
+#define CGV_B_PHASE_LAST2(SB_, SEQ)                                                                                 \
+    CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_THR_LOAD_ASM(SEQ); CGV_LOAD_FRAGS(fa0, fb0, SB_, 0),    \
+                CGV_NOP_ACTION,                                                                                     \
+                CGV_THR_WAIT CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y), \
+                CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
+                CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
 #define CGV_B_PHASE_LAST(SB_, SEQ)                                                                                  \
     CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_LOAD_FRAGS(fa0, fb0, SB_, 0), CGV_THR_LOAD(SEQ),        \
                 CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y),   \
                 CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
                 CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
+    // EPI 3: filter of block (MBI, NBI) of the tile that just ended (ftile; inverse norms finv), placed in the gap in
+    // front of the zero-C MFMA that overwrites the block. The opening pin keeps the (movable) maxima behind everything
+    // issued so far: the block's last MFMA is then >= 7 matrix instructions old, no hazard pad needed.
+    uint32_t ftile = 0;
+    const float* finv = invn_s;
+    auto filt_block = [&](auto mb_c, auto nb_c) __attribute__((always_inline)) {
+        constexpr int MBI = decltype(mb_c)::value, NBI = decltype(nb_c)::value;
+        if (!(ABL & 1)) {
+            asm volatile("" : "+v"(acc[MBI][NBI])::"memory");
+            if (__builtin_expect(__ballot(block_max(acc[MBI][NBI]) > thr[MBI][NBI]) != 0ull, 0))  // cold, out of line
+                block_hits<BM, BN>(a, acc[MBI][NBI], thr[MBI][NBI], tauv[NBI], invq[NBI], (uint32_t)(wm * WTM + MBI * 32),
+                                   (uint32_t)(wn * WTN + NBI * 32 + (lane & 31)), ftile, lane, g, qt, cntq, finv);
+        }
+    };
+#define CGV_FILT(MBI, NBI) filt_block(IntC<MBI>{}, IntC<NBI>{});
+#define CGV_A_PHASE_ZF(SB_)                                                                                         \
+    {                                                                                                               \
+        CGV_FILT(0, 0)                                                                                              \
+        asm volatile("" : "+v"(fa0[0])::"memory");                                                                  \
+        CGV_KSTEP_X(CGV_MMAZ, fa0, fb0, fa1, CGV_LOAD_FRAGS(fa1, fb1, SB_, 1); CGV_FILT(0, 1), CGV_FILT(1, 1),      \
+                    CGV_FILT(1, 0), issue_q(2); CGV_FILT(2, 0), CGV_FILT(2, 1), issue_q(3); CGV_FILT(3, 1),         \
+                    CGV_FILT(3, 0), CGV_NOP_ACTION)                                                                 \
+    }
 #define CGV_THR_ALL(SEQ)                                                                                            \
     {                                                                                                               \
         CGV_THR_LOAD(SEQ)                                                                                           \
@@ -701,7 +752,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1)) {                                                                                              \
-        if (MODE == 0)                                                                                             \
+        if (MODE == 0 && EPI != 0)                                                                                 \
             tile_filter_emit<BM, BN, WTM, WTN, MB, NB>(a, acc, thr, TILE, wm, wn, lane, g, qt, tauv, invq, cntq,     \
                                                        invn_s + ((SEQ) & (NINV - 1)) * 256);                       \
         else                                                                                                       \
@@ -727,15 +778,31 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-            CGV_B_PHASE_LAST(sb, tl - 1);
+            if (MODE != 0 || EPI == 0) {
+                CGV_B_PHASE(sb);
+            } else if (EPI == 2) {
+                CGV_B_PHASE_LAST2(sb, tl - 1);
+            } else if (EPI == 3) {
+                CGV_B_PHASE_LAST(sb, tl - 1);
+            } else {
+                CGV_B_PHASE_LAST(sb, tl - 1);
+            }
             if (wave == 0) pace_step(pace, tl + 1, lane);
             const uint32_t nt = next_tile(ct);
             side_wait();
-            if (MODE == 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
-            CGV_EPILOGUE(a.T1 + ct, tl - 1);
-            issue_side(nt, tl);  // the tile that starts here
-            ct = nt;
-            CGV_A_PHASE_Z(sb);
+            if (MODE == 0 && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
+            if (MODE == 0 && EPI == 3) {
+                ftile = a.T1 + ct;
+                finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
+                issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)
+                ct = nt;
+                CGV_A_PHASE_ZF(sb);
+            } else {
+                CGV_EPILOGUE(a.T1 + ct, tl - 1);
+                issue_side(nt, tl);  // the tile that starts here
+                ct = nt;
+                CGV_A_PHASE_Z(sb);
+            }
             ++s;
         }
 #pragma unroll 1
@@ -752,11 +819,16 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
     __builtin_amdgcn_s_barrier();
-    if (MODE == 0) CGV_THR_ALL(ntl - 1);
+    if (MODE == 0 && EPI != 0) CGV_THR_ALL(ntl - 1);
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);
 #undef CGV_A_PHASE_Z
 #undef CGV_B_PHASE
 #undef CGV_B_PHASE_LAST
+#undef CGV_B_PHASE_LAST2
+#undef CGV_A_PHASE_ZF
+#undef CGV_FILT
+#undef CGV_THR_WAIT
+#undef CGV_THR_LOAD_ASM
 #undef CGV_THR_ALL
 #undef CGV_THR
 #undef CGV_THR_LOAD

@@ -400,14 +400,23 @@ struct RescoreArgs {
     float res_abs_c;        // max over the corpus of |dc|
     uint32_t* stat_maxeps;  // [1] f2ord-free max of the eps actually used (non-negative float bits)
     uint64_t* trace;        // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps (100 MHz) of the phases, or NULL
-    // End-of-search publication: the LAST workgroup to finish copies the search's n_flags flag words (fallback count,
-    // non-finite bits, error maxima, ...) into the pinned host mirror and clears them for the next search, so the host
-    // needs neither a flags D2H copy after the pipeline nor a memset before the next one. flags[done_word] counts
-    // finished workgroups.
-    uint32_t* flags;        // device flag words of the search context
-    uint32_t* flags_host;   // their pinned, device-mapped mirror; NULL = do not publish
-    uint32_t n_flags, done_word;
 };
+
+// End-of-search publication (one wave, launched behind the last kernel of a search): the flag words (fallback count,
+// non-finite bits, error maxima, ...) go to the pinned, device-mapped host mirror and are cleared for the next search,
+// so the host needs neither a flags D2H copy after the pipeline (a copy-engine launch on the critical path) nor a
+// memset before the next one. host[done_word] = marker tells the host the mirror is current. (A ticket counter in
+// the last kernel instead - 1024 returning atomics on one word - cost 25 us: r03b.)
+__global__ void publish_flags_kernel(uint32_t* __restrict__ flags, uint32_t* __restrict__ host, uint32_t n_flags,
+                                     uint32_t done_word, uint32_t marker) {
+    const uint32_t i = threadIdx.x;
+    if (i < n_flags) {
+        const uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        host[i] = (i == done_word) ? marker : v;
+        __hip_atomic_store(flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 
 // Exact reference arithmetic on the k' candidates of each query, exact (score desc, row asc)
 // ordering, and the guarantee check  e_k > tau + eps  (every row outside the candidate set has
@@ -451,6 +460,24 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             eps += 1.01f * (rq_rel + a.res_rel_c);
     }
     const float trip = 0.5f * eps;
+    // Re-score only the candidates that can reach the top-k. The list is sorted by coarse score c_0 >= c_1 >= ...; with
+    // |coarse - exact| <= eps the k best by coarse score have exact >= c_{k-1} - eps, so a candidate with
+    // c_i < c_{k-1} - 2 eps cannot be among the exact top-k. On random data that leaves k or k + 1 of the k' = 16
+    // candidates: a third fewer rows to gather (the gather is the longest phase of this kernel: 25 MB of 64-byte
+    // pieces per C2 batch, ~16 us at the memory system's random-access rate). Everything not re-scored - the other
+    // candidates and every row outside the list - has coarse <= tau_eff, the first skipped candidate's score.
+    const uint32_t nb_all = nb;
+    float tau_eff = tau;
+    if (nb > a.k && a.k > 0) {
+        const float cut = key_score(ckeys[a.k - 1]) - 2.0f * eps;
+        uint32_t m = a.k;
+        while (m < nb && key_score(ckeys[m]) >= cut) ++m;  // uniform: every thread walks the same short list
+        if (m < nb) {
+            tau_eff = key_score(ckeys[m]);
+            nb = m;
+        }
+    }
+    const uint32_t nres = nb;
     const uint32_t P = next_pow2(nb < 2 ? 2 : nb);
     for (uint32_t i = nb + tid; i < P; i += 256) ekeys[i] = 0ull;
     // Gather: 8 candidates at a time, 32 lanes per candidate, lane l of a candidate's group fetches pieces l, l + 32, ...
@@ -519,32 +546,21 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     }
     phase_stamp(a.trace, q, 6, tid);
     if (tid == 0) {
-        atomicMax(a.stat_maxerr, maxerr);
+        // statistics: one word for the whole batch. An unconditional atomicMax from each of the 1024 workgroups
+        // serialises at ~12 ns apiece on that word; almost none of them raises the maximum, so look first (a stale
+        // read only costs a redundant atomic).
+        if (maxerr > __hip_atomic_load(a.stat_maxerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
-        if (tau > -INFINITY) {  // rows at or below tau were dropped: check the guarantee
-            if (a.stat_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
-            if (nb < a.k) fb = true;  // (the corpus has more rows than candidates survived)
-            else if (!(key_score(ekeys[a.k - 1]) > tau + eps)) fb = true;
+        if (tau_eff > -INFINITY) {  // rows at or below tau_eff were dropped / not re-scored: check the guarantee
+            if (a.stat_maxeps && __float_as_uint(eps) > __hip_atomic_load(a.stat_maxeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(a.stat_maxeps, __float_as_uint(eps));
+            if (nres < a.k && nres < nb_all) fb = true;  // (cannot happen: the re-scored prefix holds >= k candidates)
+            if (nb_all < a.k) fb = true;                 // (the corpus has more rows than candidates survived)
+            else if (!(key_score(ekeys[a.k - 1]) > tau_eff + eps)) fb = true;
             if (tripped) fb = true;
         }
         a.fb_flag[q] = fb ? 1u : 0u;
         if (fb) atomicAdd(a.fb_count, 1u);
-        if (a.flags_host) {
-            // Publish + reset by the last workgroup. Everything it reads was written by device-scope ATOMICS (performed
-            // at the coherent level, never cached in a CU's L1 or an XCD's L2), so no cache write-back / invalidate is
-            // needed - only that this lane's atomics above are complete before its ticket: vmcnt(0) (gfx9: stores and
-            // non-returning atomics count on vmcnt too). A release fence here (buffer_wbl2 in each of 1024 workgroups)
-            // measured +23 us on the final kernel (r03b).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t t = __hip_atomic_fetch_add(a.flags + a.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == gridDim.x) {
-                for (uint32_t i = 0; i < a.n_flags; ++i) {
-                    const uint32_t v = __hip_atomic_load(a.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.flags_host[i] = (i == a.done_word) ? t + 1 : v;
-                    __hip_atomic_store(a.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
     }
     phase_stamp(a.trace, q, 7, tid);
 }

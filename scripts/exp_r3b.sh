@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3b; rm -rf $O; mkdir -p $O
 cd $R
-timeout 1200 python -m pytest tests -m gpu -x -q --tb=short -p no:cacheprovider --timeout 600 2>&1 | tail -15 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
-V="zc0:zero_copy=0;zc_in:zero_copy=1;zc_io:;pace_on:pace=2"
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 2>&1 | tail -15 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+V="zc0:zero_copy=0;zc_in:zero_copy=1;zc_io:;pace_on:pace=2;legacy_zc0:plan_legacy=1,zero_copy=0"
 timeout 300 python scripts/ab.py --workload c2 --variants "$V" --rounds 3 --steps 12 > $O/ab_c2.txt 2>$O/ab_c2.err
 timeout 200 python scripts/ab.py --workload c2shard8 --variants "zc0:zero_copy=0;zc_in:zero_copy=1;zc_io:" --rounds 3 --steps 12 > $O/ab_c2shard8.txt 2>$O/ab_c2shard8.err
 timeout 300 python scripts/ab.py --workload c4 --variants "zc0:zero_copy=0;zc_in:zero_copy=1;zc_io:" --rounds 3 --steps 12 > $O/ab_c4.txt 2>$O/ab_c4.err
