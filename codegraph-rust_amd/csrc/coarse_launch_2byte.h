@@ -31,6 +31,7 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_DUMP>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_SAMPLE>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_w4_kernel<DT, false>))) return rc;
     return CGV_OK;
 }
@@ -91,25 +92,19 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
         return coarse_hip_status("coarse_w4_kernel");
     }
-    if constexpr (ABLATE) {  // A/B of the emitting epilogue (bf16 build only): a.epi, set from the `epi` knob
-        if (a.epi == 0) {
+    if constexpr (ABLATE) {  // A/B reference: the round-2 epilogue (bf16 build only)
+        if ((a.epi & 1u) == 0) {
             auto k0 = coarse_kernel<DT, COARSE_EMIT, 0, 0>;
             if (int rc = coarse_set_lds((const void*)k0)) return rc;
             hipLaunchKernelGGL(k0, dim3(W), dim3(512), lds, s, a);
             return coarse_hip_status("coarse_kernel (epi 0)");
         }
-        if (a.epi == 3) {
-            auto k3 = coarse_kernel<DT, COARSE_EMIT, 0, 3>;
-            if (int rc = coarse_set_lds((const void*)k3)) return rc;
-            hipLaunchKernelGGL(k3, dim3(W), dim3(512), lds, s, a);
-            return coarse_hip_status("coarse_kernel (epi 3)");
-        }
-        if (a.epi == 2) {
-            auto k2 = coarse_kernel<DT, COARSE_EMIT, 0, 2>;
-            if (int rc = coarse_set_lds((const void*)k2)) return rc;
-            hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);
-            return coarse_hip_status("coarse_kernel (epi 2)");
-        }
+    }
+    // every corpus tile read by exactly ONE workgroup (a single query tile per XCD group): stream it non-temporally
+    if (a.nqt == 1 && (a.epi & 2u) == 0) {
+        auto kn = coarse_kernel<DT, COARSE_EMIT, 0, 1, true>;
+        hipLaunchKernelGGL(kn, dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (nt)");
     }
     hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);
     return coarse_hip_status("coarse_kernel");

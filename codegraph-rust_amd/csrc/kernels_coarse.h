@@ -100,7 +100,7 @@ struct CoarseArgs {
     const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
     uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
     uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump` (16 per sampled tile)
-    uint32_t epi;           // A/B switch of the emitting epilogue (coarse_kernel's EPI; bf16 build only), default 1
+    uint32_t epi;           // A/B switches (scripts/ab.py): bit 0 clear = round-2 epilogue (bf16 build only); bit 1 = no NT hint
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -418,12 +418,15 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
 // 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
-// EPI (A/B of the emitting epilogue, scripts/ab.py knob `epi`): 0 = round-2 form (thresholds + per-lane hit mask at the
-// tile boundary, tile_epilogue); 1 = thresholds in the last k-step's MFMA gaps (plain LDS reads) + lean wave-wide filter;
-// 2 = the same with the block norm bounds read AHEAD of the fragment loads and a counted lgkmcnt wait; 3 = thresholds as
-// in 1, and each block's filter sits right in front of the zero-C MFMA that overwrites the block (first k-step of the next
-// tile): one wave's 11 filter VALU run beside its SIMD partner's MFMA instead of all 8 waves filtering with the pipe idle.
-template <int DT, int MODE, int ABL = 0, int EPI = 1>
+// EPI, the emitting epilogue: 1 (default) = the conservative thresholds are formed in the MFMA gaps of a tile's last
+// k-step, and each 32 x 32 block's filter (10 VALU maxima + one compare) sits right in front of the zero-C MFMA of the
+// next tile's first k-step that overwrites the block - one wave's filter runs beside its SIMD partner's MFMA instead of
+// all 8 waves filtering while the matrix pipe idles. 0 = the round-2 form (everything at the tile boundary,
+// tile_epilogue), kept in the bf16 build as the A/B reference (scripts/ab.py knob `epi`). Measured r03c, C2 main
+// launch: 1.070 -> 1.049 ms (EPI 0 -> 1); thresholds in the gaps alone, with the filter left at the boundary: 1.070.
+// NTA: the corpus (A operand) DMA carries the non-temporal hint - for launches in which every corpus tile is read by
+// exactly one workgroup (one query tile per XCD group: C4).
+template <int DT, int MODE, int ABL = 0, int EPI = 1, bool NTA = false>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -515,6 +518,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     char* d_dst = smem;
 #define CGV_BDMA(RS, DST, IMM) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
+#define CGV_BDMA_A(RS, DST, IMM) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, NTA ? 2 : 0)
     auto issue_q = [&](int q) {
         if ((ABL & 2) || ((ABL & 64) && issued >= (uint32_t)NSTAGE)) {
             if (q == 3) ++issued;
@@ -524,9 +529,9 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         if (q == 0) {
             d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 2048;
             d_so = (uint32_t)koff + (uint32_t)wave * 2048u;
-            if (BUFDMA) CGV_BDMA(rsA, d_dst, 0); else glds16(acur + koff, d_dst);
+            if (BUFDMA) CGV_BDMA_A(rsA, d_dst, 0); else glds16(acur + koff, d_dst);
         } else if (q == 1) {
-            if (BUFDMA) CGV_BDMA(rsA, d_dst, 1024); else glds16(acur + koff + 1024, d_dst + 1024);
+            if (BUFDMA) CGV_BDMA_A(rsA, d_dst, 1024); else glds16(acur + koff + 1024, d_dst + 1024);
         } else if (q == 2) {
             if (BUFDMA) CGV_BDMA(rsB, d_dst + A_BYTES, 0); else glds16(bq + koff, d_dst + A_BYTES);
         } else {
@@ -651,17 +656,6 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         mn4 = *(const f32x4_t*)st_;                                                                   \
         mx4 = *(const f32x4_t*)(st_ + 8);                                                             \
     }
-    // EPI 2: the two reads go out FIRST in gap 0 (LDS returns in order), the 6 fragment reads behind them; gap 2 then
-    // waits for "all but the 6 youngest" - the wave never waits for its fragments there. Inline asm: hipcc would wait
-    // lgkmcnt(0).
-#define CGV_THR_LOAD_ASM(SEQ)                                                                         \
-    {                                                                                                 \
-        const uint32_t sa_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(   \
-            stat_s + ((SEQ) & (NINV - 1)) * 16 + wm * MB);                                            \
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32"                          \
-                     : "=&v"(mn4), "=&v"(mx4) : "v"(sa_) : "memory");                                 \
-    }
-#define CGV_THR_WAIT asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(mn4), "+v"(mx4)::"memory");
 #define CGV_THR(MBI, NBI, MN, MX)                                                                     \
     {                                                                                                 \
         float mul_ = tone[NBI] ? 1.0f : (tneg[NBI] ? (MX) : (MN));                                    \
@@ -679,18 +673,12 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_A_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_A_PHASE_Z(SB_) CGV_KSTEP(CGV_MMAZ, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
-#define CGV_B_PHASE_LAST2(SB_, SEQ)                                                                                 \
-    CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_THR_LOAD_ASM(SEQ); CGV_LOAD_FRAGS(fa0, fb0, SB_, 0),    \
-                CGV_NOP_ACTION,                                                                                     \
-                CGV_THR_WAIT CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y), \
-                CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
-                CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
 #define CGV_B_PHASE_LAST(SB_, SEQ)                                                                                  \
     CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_LOAD_FRAGS(fa0, fb0, SB_, 0), CGV_THR_LOAD(SEQ),        \
                 CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y),   \
                 CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
                 CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
-    // EPI 3: filter of block (MBI, NBI) of the tile that just ended (ftile; inverse norms finv), placed in the gap in
+    // filter of block (MBI, NBI) of the tile that just ended (ftile; inverse norms finv), placed in the gap in
     // front of the zero-C MFMA that overwrites the block. The opening pin keeps the (movable) maxima behind everything
     // issued so far: the block's last MFMA is then >= 7 matrix instructions old, no hazard pad needed.
     uint32_t ftile = 0;
@@ -780,10 +768,6 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
             if (MODE != 0 || EPI == 0) {
                 CGV_B_PHASE(sb);
-            } else if (EPI == 2) {
-                CGV_B_PHASE_LAST2(sb, tl - 1);
-            } else if (EPI == 3) {
-                CGV_B_PHASE_LAST(sb, tl - 1);
             } else {
                 CGV_B_PHASE_LAST(sb, tl - 1);
             }
@@ -791,7 +775,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             const uint32_t nt = next_tile(ct);
             side_wait();
             if (MODE == 0 && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
-            if (MODE == 0 && EPI == 3) {
+            if (MODE == 0 && EPI != 0) {
                 ftile = a.T1 + ct;
                 finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
                 issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)
@@ -824,11 +808,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #undef CGV_A_PHASE_Z
 #undef CGV_B_PHASE
 #undef CGV_B_PHASE_LAST
-#undef CGV_B_PHASE_LAST2
 #undef CGV_A_PHASE_ZF
 #undef CGV_FILT
-#undef CGV_THR_WAIT
-#undef CGV_THR_LOAD_ASM
 #undef CGV_THR_ALL
 #undef CGV_THR
 #undef CGV_THR_LOAD
@@ -845,6 +826,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #undef CGV_LDA
 #undef CGV_LDB
 #undef CGV_BDMA
+#undef CGV_BDMA_A
 
     __syncthreads();
     if (tid == 0) pace_done(pace);

@@ -460,6 +460,12 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             eps += 1.01f * (rq_rel + a.res_rel_c);
     }
     const float trip = 0.5f * eps;
+    // the batch-wide statistics words, looked at before they are raised (below): fetched now, used ~20 us later
+    uint32_t seen_maxerr = 0, seen_maxeps = 0;
+    if (tid == 0) {
+        seen_maxerr = __hip_atomic_load(a.stat_maxerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.stat_maxeps) seen_maxeps = __hip_atomic_load(a.stat_maxeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // Re-score only the candidates that can reach the top-k. The list is sorted by coarse score c_0 >= c_1 >= ...; with
     // |coarse - exact| <= eps the k best by coarse score have exact >= c_{k-1} - eps, so a candidate with
     // c_i < c_{k-1} - 2 eps cannot be among the exact top-k. On random data that leaves k or k + 1 of the k' = 16
@@ -532,7 +538,23 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     }
     __syncthreads();
     phase_stamp(a.trace, q, 4, tid);
-    bitonic_sort_desc<256>(ekeys, P, tid);
+    if (P <= 64) {  // the usual case: one key per lane of wave 0, bitonic network over lane shuffles - no barriers
+        if (tid < 64) {
+            uint64_t kx = (uint32_t)tid < P ? ekeys[tid] : 0ull;
+            for (uint32_t k2 = 2; k2 <= 64; k2 <<= 1)
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                    const uint64_t other = __shfl_xor(kx, (int)j, 64);
+                    const bool upper = ((uint32_t)tid & j) != 0, desc = ((uint32_t)tid & k2) == 0;
+                    // descending block: the lower lane keeps the larger key
+                    const bool take_max = (upper != desc);
+                    kx = take_max ? (kx > other ? kx : other) : (kx < other ? kx : other);
+                }
+            if ((uint32_t)tid < P) ekeys[tid] = kx;
+        }
+        __syncthreads();
+    } else {
+        bitonic_sort_desc<256>(ekeys, P, tid);
+    }
     phase_stamp(a.trace, q, 5, tid);
     for (uint32_t j = tid; j < a.k; j += 256) {
         uint64_t oi = UINT64_MAX;
@@ -549,11 +571,10 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         // statistics: one word for the whole batch. An unconditional atomicMax from each of the 1024 workgroups
         // serialises at ~12 ns apiece on that word; almost none of them raises the maximum, so look first (a stale
         // read only costs a redundant atomic).
-        if (maxerr > __hip_atomic_load(a.stat_maxerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.stat_maxerr, maxerr);
+        if (maxerr > seen_maxerr) atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
         if (tau_eff > -INFINITY) {  // rows at or below tau_eff were dropped / not re-scored: check the guarantee
-            if (a.stat_maxeps && __float_as_uint(eps) > __hip_atomic_load(a.stat_maxeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(a.stat_maxeps, __float_as_uint(eps));
+            if (a.stat_maxeps && __float_as_uint(eps) > seen_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
             if (nres < a.k && nres < nb_all) fb = true;  // (cannot happen: the re-scored prefix holds >= k candidates)
             if (nb_all < a.k) fb = true;                 // (the corpus has more rows than candidates survived)
             else if (!(key_score(ekeys[a.k - 1]) > tau_eff + eps)) fb = true;

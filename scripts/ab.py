@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (workload table + generators)
 
-KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1}
+KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1, "profiling": 1}
 
 
 def main():
@@ -66,6 +66,9 @@ def main():
 
     def apply(knobs):
         for key, val in knobs.items():
+            if key == "profiling":       # HIP events around the dominant launch / the pipeline (cgv_set_profiling)
+                ix.set_profiling(bool(val))
+                continue
             assert L.cgv_debug_set_(key.encode(), float(val)) == 0, key
 
     def step(i):
