@@ -68,6 +68,21 @@ ESIZE = {"bf16": 2, "fp16": 2, "fp8": 1, "f32s": 2}   # bytes per element the co
 SEED_CORPUS, SEED_QUERY = 0xC0DE6001, 0xC0DE6002
 
 
+def source_sha16():
+    """Identity of the kernel sources a PMC pass was taken on: sha256 over codegraph-rust_amd/csrc/*.{h,hip} and host/*.cpp.
+    scripts/pmc_summary.py stamps it into <tag>_<workload>_pmc_main_kernel.json; `roofline.traffic` is only quoted from a
+    file whose stamp equals the sources this run was built from (VERDICT r2 #8: the field used to be a stale constant)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "codegraph-rust_amd")
+    for f in sorted(glob.glob(os.path.join(base, "csrc", "*.h")) + glob.glob(os.path.join(base, "csrc", "*.hip")) +
+                    glob.glob(os.path.join(base, "host", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def storage_values(x, dtype):
     """f32 values the index scores on (SURVEY.md §8(c): rounded-then-upcast); fp8 = e4m3fn codes
     under the per-row power-of-two scale (largest e with amax * 2^e <= 448)."""
@@ -102,6 +117,54 @@ def respawn_under_launcher(n):
     return subprocess.call(cmd, env=env)
 
 
+def bench_sharded_handle(args, m, dev):
+    """ONE cgv_sharded handle (the object the Rust seam would hold) over G shards, devices i % device_count: on a 1-GPU
+    box device 0 is listed G times (exchange = device copies), on a multi-GPU box the devices are distinct and the
+    exchange is the in-library ncclAllGather. Serial steps (begin + end per batch) and two batches in flight."""
+    n_total, dim, dtype, metric, batch, k = WORKLOADS[args.workload]
+    G = args.sharded_handle
+    nd = m.device_count()
+    sx = m.ShardedIndex(dim, [i % nd for i in range(G)], metric=metric, dtype=dtype)
+    sx.reserve(n_total)
+    for c in range((n_total + CHUNK - 1) // CHUNK):
+        c_lo, c_hi = c * CHUNK, min(n_total, (c + 1) * CHUNK)
+        sx.add(gen_chunk(c, c_hi - c_lo, dim, dev).cpu().numpy())
+    gq = torch.Generator(device=dev).manual_seed(SEED_QUERY)
+    qhost = [torch.nn.functional.normalize(torch.randn((batch, dim), generator=gq, device=dev), dim=1).cpu().numpy()
+             for _ in range(4)]
+    for i in range(args.warmup):
+        sx.search(qhost[i % 4], k)
+    t0 = time.perf_counter()
+    xms = []
+    for i in range(args.steps):
+        sx.search(qhost[i % 4], k)
+        xms.append(sx.stats()["last_exchange_ms"])
+    serial = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    prev = sx.search_begin(qhost[0], k)
+    for i in range(1, args.steps):
+        nxt = sx.search_begin(qhost[i % 4], k)
+        prev.wait()
+        prev = nxt
+    prev.wait()
+    piped = time.perf_counter() - t0
+    st = sx.stats()
+    print(json.dumps({
+        "metric": "queries_per_sec", "value": round(batch * args.steps / serial, 1), "unit": "queries/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * serial / args.steps, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload.upper()} through ONE cgv_sharded handle: {n_total} x {dim} {dtype} {metric}, "
+                               f"batch={batch}, k={k}, {G} shards on {min(G, nd)} device(s)",
+                   "rows": n_total, "dim": dim, "batch": batch, "k": k, "metric": metric, "sharding": f"block-cyclic rows/{G}",
+                   "step": "cgv_sharded_search_f32: host queries -> every shard -> pack -> exchange -> merge -> host results",
+                   "exchange": st["exchange"]},
+        "two_in_flight": {"queries_per_sec": round(batch * args.steps / piped, 1), "ms_per_batch": round(1e3 * piped / args.steps, 4),
+                          "note": "cgv_sharded_search_begin_f32 of batch i + 1 before cgv_sharded_search_end of batch i"},
+        "last_exchange_ms": round(float(np.median(xms)), 4), "fallback_queries": int(st["fallback_queries"]),
+        "roofline": None, "cpu_baseline": None}), flush=True)
+    sx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +176,13 @@ def main():
     ap.add_argument("--depth", type=int, default=2, help="batches in flight of the pipelined side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=128)
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed searches before the W warm-up steps until this much wall time has passed: the part clocks "
+                         "up over tens of milliseconds of load (a 20-step bench started cold measured 3-5 %% slower launches "
+                         "than the same binary in steady state, r03d); 0 = off")
+    ap.add_argument("--sharded-handle", type=int, default=0,
+                    help="G > 0: drive ONE cgv_sharded handle over G shards (devices i %% device_count) with two batches in "
+                         "flight (cgv_sharded_search_begin_f32 / _end) instead of the single index; N = 1 only")
     ap.add_argument("--spawn-check", action="store_true",
                     help="print this rank's RANK/WORLD_SIZE and exit before touching a GPU (CPU test of the self-spawn)")
     args = ap.parse_args()
@@ -140,6 +210,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     m = importlib.import_module("codegraph-rust_amd")
+    if args.sharded_handle > 0:
+        if world != 1:
+            sys.exit("bench.py: --sharded-handle runs in ONE process (N = 1); the handle itself spans the devices")
+        return bench_sharded_handle(args, m, dev)
     lo, hi = m.shard_range(n_total, rank, world)
     ix = m.HipKnnIndex(dim, metric=metric, dtype=dtype, device=local_rank)
     ix.reserve(hi - lo)
@@ -149,13 +223,18 @@ def main():
     if n_total > 4_000_000:
         want_cpu = False   # the f32 upcast of the corpus would not fit the CPU leg's time/memory bound
     nchunks = (n_total + CHUNK - 1) // CHUNK
+    ingest_s, ingest_rows = 0.0, 0
     for c in range(nchunks):
         c_lo, c_hi = c * CHUNK, min(n_total, (c + 1) * CHUNK)
         a, b = max(lo, c_lo), min(hi, c_hi)
         if a >= b:
             continue
         x = gen_chunk(c, c_hi - c_lo, dim, dev)[a - c_lo: b - c_lo]
-        ix.add(x)
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        ix.add(x)                      # device f32 rows -> storage dtype + norms + block bounds (synchronous)
+        ingest_s += time.perf_counter() - ti
+        ingest_rows += b - a
         if want_cpu:
             host_chunks.append(storage_values(x, dtype).cpu().numpy())   # rounded-then-upcast values
         del x
@@ -182,13 +261,33 @@ def main():
         def step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
             m.cgvec._check(L.cgv_search_f32(ix._h, C.c_void_p(qhost[i % npool].data_ptr()), batch, k, oi_p, os_p))
     else:
+        ev_x0, ev_x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        exchange_ms = []
+
         def step(i):   # every rank: H2D of the (replicated) batch, shard search, all-gather + merge, D2H
             q = qhost[i % npool].to(dev, non_blocking=True)
-            gi, gs = searcher.search(q, k)
+            li, ls = ix.search(q, k)                  # this rank's shard (ids already global)
+            ev_x0.record()
+            gi, gs = searcher._exchange(li, ls, k)    # ONE RCCL all-gather of packed records + merge kernel
+            ev_x1.record()
             out_i.copy_(gi, non_blocking=True)
             out_s.copy_(gs, non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            exchange_ms.append(ev_x0.elapsed_time(ev_x1))
 
+    if args.settle_ms > 0:   # steady-state clocks before anything is measured (setup, like the index build)
+        ts = time.perf_counter()
+        i = 0
+        while True:
+            step(i)
+            i += 1
+            go = 1e3 * (time.perf_counter() - ts) < args.settle_ms
+            if dist is not None:   # every rank runs the same number of (collective-carrying) steps: rank 0 decides
+                flag = torch.tensor([1 if go else 0], device=dev)
+                dist.broadcast(flag, 0)
+                go = bool(flag.item())
+            if not go:
+                break
     for i in range(args.warmup):
         step(i)
     sync_all()
@@ -207,7 +306,32 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ix.set_profiling(2)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step)
+    step(0)
+    step(1)
     st = ix.stats()
+    ix.set_profiling(1)
+    multi = None
+    if dist is not None:
+        # self-proof of the N-rank run: a collective-derived rank count, every rank's dominant-launch
+        # time and shard size, and the exchange time - gathered with RCCL itself, not built from WORLD_SIZE
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([float(np.mean([c for c in coarse_ms if c > 0] or [0.0])), float(coarse_rows),
+                             float(np.mean(exchange_ms[-args.steps:])), float(hi - lo), float(local_rank)],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = [t.cpu().tolist() for t in allr]
+        multi = {"rccl_ranks_seen": int(round(float(ones.item()))),
+                 "per_rank_avg_launch_ms": [round(r[0], 4) for r in allr],
+                 "per_rank_rows_per_launch": [int(r[1]) for r in allr],
+                 "per_rank_exchange_ms": [round(r[2], 4) for r in allr],
+                 "per_rank_shard_rows": [int(r[3]) for r in allr],
+                 "per_rank_device": [int(r[4]) for r in allr],
+                 "exchange_ms": round(max(r[2] for r in allr), 4),
+                 "exchange": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) of packed 12-byte records "
+                             "+ merge kernel, timed with events on the stream it runs on"}
 
     # side measurement: device-resident queries and results, `depth` batches in flight (round 1's headline)
     pipelined = None
@@ -245,11 +369,17 @@ def main():
             pdir = os.path.join(ROOT, "profiles")
             pmc = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{args.workload}_pmc_main_kernel.json")) \
                 if os.path.isdir(pdir) else []
+            traffic_note = None
             if pmc and world == 1:
-                # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes
-                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/collect_profiles.sh)
-                traffic = json.load(open(os.path.join(pdir, pmc[-1]))).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/" + pmc[-1]
+                # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+                # correction + WRITE_SIZE; scripts/collect_profiles.sh) - only from a pass taken on THESE kernel sources
+                pj = json.load(open(os.path.join(pdir, pmc[-1])))
+                if pj.get("source_sha16") == source_sha16():
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/" + pmc[-1]
+                else:
+                    traffic_note = (f"profiles/{pmc[-1]} was collected on other kernel sources (stamp "
+                                    f"{pj.get('source_sha16')} != {source_sha16()}): not quoted")
             abytes = float(coarse_rows) * dim * ESIZE[dtype] + batch * dim * ESIZE[dtype] + coarse_rows * 4
             gbs = abytes / (cms * 1e-3) / 1e9
             mfma_frac, hbm_frac = ach / PEAK_TFLOPS[dtype], gbs / PEAK_HBM_GBS
@@ -262,7 +392,7 @@ def main():
                 roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                         "frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4)}
             roof.update({"kernel": "coarse_kernel (main stage)", "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "avg_launch_ms": round(cms, 4),
+                         "traffic_source": traffic_src, "traffic_note": traffic_note, "avg_launch_ms": round(cms, 4),
                          "rows_per_launch": int(coarse_rows), "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes, "rank": 0})
         result = {
@@ -274,11 +404,16 @@ def main():
                                    f"batch={batch}, k={k}", "rows": n_total, "dim": dim, "batch": batch, "k": k,
                        "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
                        "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
-                       "exchange": f"RCCL all-gather, world={world}" if world > 1 else "none"},
+                       "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none"},
             "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
             "pipelined": pipelined,
             "roofline": roof,
+            "multi_gpu": multi,
+            "ingest": {"gb_per_s": round(ingest_rows * dim * (4 + ESIZE[dtype]) / max(ingest_s, 1e-9) / 1e9, 1),
+                       "rows": int(ingest_rows), "seconds": round(ingest_s, 4),
+                       "note": "device-resident f32 rows -> storage dtype + norms + block bounds (cgv_add_f32_dev, "
+                               "synchronous per 125k-row chunk); bytes = rows x dim x (4 in + storage out)"},
             "pipeline": {"device_ms_last_step": round(st["last_total_ms"], 4), "kprime": st["last_kprime"],
                          "fallback_queries": int(st["fallback_queries"]), "eps": st["last_eps"],
                          "max_observed_coarse_err": st["max_observed_err"]},

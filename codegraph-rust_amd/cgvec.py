@@ -129,12 +129,17 @@ def lib():
     L.cgv_sharded_shard.argtypes = [vp, u32]
     L.cgv_sharded_shard.restype = vp
     L.cgv_sharded_search_f32.argtypes = [vp, vp, u32, u32, vp, vp]
+    L.cgv_sharded_search_begin_f32.argtypes = [vp, vp, u32, u32, vp, vp, C.POINTER(u64)]
+    L.cgv_sharded_search_end.argtypes = [vp, u64]
+    L.cgv_sharded_max_batches_in_flight.argtypes = [vp]
+    L.cgv_sharded_max_batches_in_flight.restype = u32
     L.cgv_sharded_exchange.argtypes = [vp]
     L.cgv_sharded_set_exchange.argtypes = [vp, i32]
     L.cgv_sharded_get_stats.argtypes = [vp, C.POINTER(ShardedStats)]
     for name in ("cgv_set_id_map", "cgv_truncate", "cgv_score_ids_f32", "cgv_sharded_create", "cgv_sharded_destroy",
                  "cgv_sharded_reserve", "cgv_sharded_add_f32", "cgv_sharded_update_row_f32", "cgv_sharded_get_row_f32",
-                 "cgv_sharded_search_f32", "cgv_sharded_exchange", "cgv_sharded_set_exchange", "cgv_sharded_get_stats"):
+                 "cgv_sharded_search_f32", "cgv_sharded_search_begin_f32", "cgv_sharded_search_end",
+                 "cgv_sharded_exchange", "cgv_sharded_set_exchange", "cgv_sharded_get_stats"):
         getattr(L, name).restype = i32
     for name in ("cgv_pack_topk_dev", "cgv_merge_packed_dev", "cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
@@ -226,7 +231,8 @@ class HipKnnIndex:
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_profiling(self, on=True):
-        _check(lib().cgv_set_profiling(self._h, 1 if on else 0))
+        """False / 0: off; True / 1: events around the dominant coarse launch; 2: also around the whole pipeline."""
+        _check(lib().cgv_set_profiling(self._h, int(on)))
 
     def set_force_exact(self, on=True):
         _check(lib().cgv_set_force_exact(self._h, 1 if on else 0))
@@ -478,6 +484,33 @@ class ShardedIndex:
             _check(lib().cgv_sharded_search_f32(self._h, q.ctypes.data_as(C.c_void_p), nq, k,
                                                 idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return idx, sc
+
+
+    @property
+    def max_in_flight(self):
+        return int(lib().cgv_sharded_max_batches_in_flight(self._h))
+
+    def search_begin(self, queries, k):
+        """First half of a batch (cgv_sharded_search_begin_f32): returns a handle whose .wait() is the second half
+        and yields (ids, scores). The query buffer is copied before the call returns."""
+        q = np.ascontiguousarray(queries.detach().float().cpu().numpy() if _is_torch(queries) else queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query dim {q.shape} != {self.dim}")
+        nq, k = q.shape[0], int(k)
+        idx = np.empty((nq, k), dtype=np.uint64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        t = C.c_uint64(0)
+        _check(lib().cgv_sharded_search_begin_f32(self._h, q.ctypes.data_as(C.c_void_p), nq, k, idx.ctypes.data_as(C.c_void_p),
+                                                  sc.ctypes.data_as(C.c_void_p), C.byref(t)))
+        owner = self
+
+        class _Pending:
+            def wait(self_inner):
+                _check(lib().cgv_sharded_search_end(owner._h, t.value))
+                return idx, sc
+        return _Pending()
 
 
 def normalize_rows(rows, device=0):

@@ -216,7 +216,8 @@ struct cgv_index {
     SearchCtx ctx[N_CTX];
     std::mutex mu;
     std::condition_variable cv;
-    bool profiling = false, force_exact = false;
+    int profiling = 0;  // 0 off; 1 = HIP events around the dominant coarse launch; 2 = also around the whole pipeline
+    bool force_exact = false;
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
     cgv_index() { memset(&st, 0, sizeof(st)); }
@@ -777,7 +778,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         return CGV_OK;
     }
 
-    if (h->profiling) HIPCHK(hipEventRecord(c->ev[0], s));
+    if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[0], s));
     // --- queries: round to storage dtype, norms ---
     if ((rc = c->qrows.ensure(storage_bytes(h, nq)))) return rc;  // whole 256-query tiles (DMA reads them)
     if ((rc = c->qnorm.ensure((size_t)nq * 4))) return rc;
@@ -997,7 +998,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                            (uint32_t)F_DONE, nq);
         HIPCHK(hipGetLastError());
     }
-    if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
+    if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
     if (!c->published) HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
     return CGV_OK;
 }
@@ -1055,7 +1056,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         c->rewrote = true;
         hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
         if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, c->out_idx, c->out_score, s))) return rc;
-        if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
+        if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
         memcpy(&me, &c->h_flags[F_MAXERR], 4);
@@ -1066,7 +1067,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
                                c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
             if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nfb, k, c->out_idx, c->out_score, s))) return rc;
-            if (h->profiling) HIPCHK(hipEventRecord(c->ev[3], s));
+            if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
             HIPCHK(hipStreamSynchronize(s));
         }
     }
@@ -1074,7 +1075,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     if (h->profiling) {
         float ms = 0.0f;
         if (c->timed_coarse && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) coarse_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) total_ms = ms;
+        if (h->profiling > 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) total_ms = ms;
     }
     // the last kernel reset the flag words - unless the exact scan ran afterwards (its kernels use them too)
     c->flags_clean = c->published && !c->rewrote;
@@ -1898,8 +1899,14 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
                        uint32_t k, uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
     if (nq == 0 || k == 0) return CGV_OK;
     if (!idx_dev || !score_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
-    if ((uint64_t)g * k > 4096) return fail(CGV_ERR_INVALID_ARG, "g*k exceeds 4096");
+    if (g > 64) return fail(CGV_ERR_INVALID_ARG, "more than 64 partial lists per query");
     HIPCHK(hipSetDevice(device_id));
+    if ((uint64_t)g * k > 4096) {  // beyond the LDS merge: G-way wave merge (any k)
+        hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)idx_dev,
+                           (uint64_t)k * 8, (const char*)score_dev, (uint64_t)k * 4, g, nq, k, out_idx_dev, out_score_dev);
+        HIPCHK(hipGetLastError());
+        return CGV_OK;
+    }
     const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream,
                        (const char*)idx_dev, (uint64_t)k * 8, (const char*)score_dev, (uint64_t)k * 4, g, nq, k,
@@ -1926,10 +1933,16 @@ int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uin
                          uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
     if (nq == 0 || k == 0) return CGV_OK;
     if (!rec_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
-    if ((uint64_t)g * k > 4096) return fail(CGV_ERR_INVALID_ARG, "g*k exceeds 4096");
+    if (g > 64) return fail(CGV_ERR_INVALID_ARG, "more than 64 partial lists per query");
     HIPCHK(hipSetDevice(device_id));
-    const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
     const uint64_t stride = (uint64_t)packed_width(k) * 4;
+    if ((uint64_t)g * k > 4096) {  // beyond the LDS merge: G-way wave merge (any k)
+        hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)rec_dev, stride,
+                           (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k, out_idx_dev, out_score_dev);
+        HIPCHK(hipGetLastError());
+        return CGV_OK;
+    }
+    const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream,
                        (const char*)rec_dev, stride, (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k,
                        out_idx_dev, out_score_dev);
@@ -1974,7 +1987,7 @@ int cgv_get_stats(cgv_index* h, cgv_stats* out) {
 
 int cgv_set_profiling(cgv_index* h, int enabled) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    h->profiling = enabled != 0;
+    h->profiling = enabled < 0 ? 0 : enabled;
     return CGV_OK;
 }
 

@@ -632,6 +632,57 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);
 }
 
+// The same merge without the LDS capacity limit (G * k <= 4096 above): ONE WAVE per query walks the G <= 64 sorted lists
+// like a G-way merge - lane g holds the head of list g, a round is a wave maximum of the ordered scores, then the smallest
+// id among the lanes that hold it, and the winner advances. k dependent rounds: slow (k = 2048: a few ms per batch), but
+// any k up to CGV_MAX_K on any number of shards is served (the LDS merge alone rejected n_shards * k > 4096).
+__global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
+                                                              const char* __restrict__ score_base, uint64_t score_stride,
+                                                              uint32_t G, uint32_t nq, uint32_t k,
+                                                              uint64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const bool mine = (uint32_t)lane < G;
+    const char* ip = idx_base + ((uint64_t)(mine ? lane : 0) * nq + q) * idx_stride;
+    const char* sp = score_base + ((uint64_t)(mine ? lane : 0) * nq + q) * score_stride;
+    uint32_t h = 0;
+    uint64_t id = UINT64_MAX;
+    float sc = -INFINITY;
+    auto load_head = [&]() {
+        id = UINT64_MAX;
+        sc = -INFINITY;
+        if (mine && h < k) {
+            id = *(const uint64_t*)(ip + (uint64_t)h * 8);
+            sc = *(const float*)(sp + (uint64_t)h * 4);
+        }
+    };
+    load_head();
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t ord = (id != UINT64_MAX) ? f2ord(sc + 0.0f) : 0u;  // 0 = exhausted (lists are padded at the tail)
+        const uint32_t m = wave_max_u32(ord);
+        uint64_t oi = UINT64_MAX;
+        float os = -INFINITY;
+        if (m != 0u) {
+            const bool cand = ord == m;
+            const uint32_t hi = ~wave_max_u32(cand ? ~(uint32_t)(id >> 32) : 0u);          // smallest high word
+            const bool cand2 = cand && (uint32_t)(id >> 32) == hi;
+            const uint32_t lo = ~wave_max_u32(cand2 ? ~(uint32_t)id : 0u);                  // then smallest low word
+            const bool win = cand2 && (uint32_t)id == lo;
+            oi = ((uint64_t)hi << 32) | lo;
+            os = ord2f(m);
+            if (win) {
+                ++h;
+                load_head();
+            }
+        }
+        if (lane == 0) {
+            out_idx[(uint64_t)q * k + j] = oi;
+            out_score[(uint64_t)q * k + j] = os;
+        }
+    }
+}
+
 // Per-shard results -> one packed record row per query for the single all-gather of SURVEY.md §8(e):
 // w int32 per query = k u64 ids | k f32 scores | (k odd: one pad word, keeps the next row 8-byte aligned).
 __host__ __device__ inline uint32_t packed_width(uint32_t k) { return 3u * k + (k & 1u); }

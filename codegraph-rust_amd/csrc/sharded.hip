@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -60,6 +61,7 @@ struct Rccl {
     void* lib = nullptr;
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;  // optional: unblocks the other ranks when one fails to post
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GetErrorString; }
@@ -87,6 +89,7 @@ const Rccl* load_rccl(std::string* why = nullptr) {
         if (g_rccl.lib) {
             g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(g_rccl.lib, "ncclCommInitAll");
             g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+            g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(g_rccl.lib, "ncclCommAbort");
             g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
             g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
             if (!g_rccl.ok()) g_rccl_err = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
@@ -116,15 +119,41 @@ struct Buf {
     }
 };
 
-// One worker thread per shard: jobs are posted by the calling thread, which waits for all of them.
+// One worker thread per shard with a FIFO of jobs. A job's completion is awaited through its sequence number, so the
+// calling thread can post the first half of a batch (queries in, search enqueued), return to its caller, and post /
+// await the second half (search done, pack, exchange) later: batches overlap on the devices.
 struct Worker {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<int()> job;
-    bool has_job = false, done = true, quit = false;
-    int rc = CGV_OK;
-    std::string err;
+    struct Job {
+        uint64_t seq;
+        std::function<int()> fn;
+    };
+    std::deque<Job> q;
+    uint64_t next_seq = 1, done_seq = 0;  // jobs complete in order
+    std::deque<std::pair<uint64_t, std::pair<int, std::string>>> failed;  // (seq, (rc, message)) of failed jobs not yet collected
+    bool quit = false;
+    uint64_t post(std::function<int()> fn) {
+        std::lock_guard<std::mutex> lk(mu);
+        const uint64_t id = next_seq++;
+        q.push_back(Job{id, std::move(fn)});
+        cv.notify_all();
+        return id;
+    }
+    // wait until job `id` has run; returns its status (message in *err)
+    int wait(uint64_t id, std::string* err) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done_seq >= id; });
+        for (auto it = failed.begin(); it != failed.end(); ++it)
+            if (it->first == id) {
+                const int rc = it->second.first;
+                if (err) *err = it->second.second;
+                failed.erase(it);
+                return rc;
+            }
+        return CGV_OK;
+    }
 };
 
 struct Shard {
@@ -133,8 +162,14 @@ struct Shard {
     cgv_index* ix = nullptr;
     hipStream_t xs = nullptr;  // H2D of the queries, pack, exchange
     ncclComm_t comm = nullptr;
-    Buf qdev, oidx, osc, rec, gathered, stage;
-    std::chrono::steady_clock::time_point t_search_done;
+    Buf stage;                 // ingest staging
+    struct SlotBufs {          // one set per batch in flight
+        Buf qdev, oidx, osc, rec, gathered;
+        uint64_t ticket = 0;   // the shard's own search ticket (cgv_search_begin_f32_dev)
+        int rc_a = CGV_OK;     // status of the first half (queries in + search enqueued)
+        std::string err_a;
+        std::chrono::steady_clock::time_point t_search_done;
+    } slot[3];
     Worker w;
 };
 
@@ -151,9 +186,20 @@ struct cgv_sharded {
     int exchange = CGV_EXCHANGE_NONE;
     bool distinct = true;
     std::mutex mu;
-    float* pin_q = nullptr;
-    size_t pin_q_bytes = 0;
-    Buf moidx, mosc;  // merged results, on the root device
+    // batches in flight (cgv_sharded_search_begin_f32 / _end): N_SLOTS sets of staging + result buffers
+    struct Slot {
+        bool busy = false;
+        uint32_t gen = 0, nq = 0, k = 0;
+        float* pin_q = nullptr;
+        size_t pin_q_bytes = 0;
+        Buf moidx, mosc;  // merged results, on the root device
+        uint64_t* out_idx = nullptr;
+        float* out_score = nullptr;
+        std::vector<uint64_t> job_a;  // per shard: sequence number of the first-half job
+        std::chrono::steady_clock::time_point t0;
+    } slots[3];
+    std::condition_variable slot_cv;
+    bool rccl_broken = false;  // a rank failed to post a collective: communicators aborted, copy exchange from now on
     uint64_t searches = 0, queries = 0;
     float last_search_ms = 0.0f, last_exchange_ms = 0.0f;
 };
@@ -162,51 +208,59 @@ namespace {
 
 constexpr uint64_t C = CGV_SHARD_CHUNK_ROWS;
 
+constexpr int N_SLOTS = 3;
+
 void worker_main(Shard* s) {
     (void)hipSetDevice(s->device);
     Worker& w = s->w;
     std::unique_lock<std::mutex> lk(w.mu);
     for (;;) {
-        w.cv.wait(lk, [&] { return w.has_job || w.quit; });
-        if (w.quit) return;
-        std::function<int()> job = std::move(w.job);
-        w.has_job = false;
+        w.cv.wait(lk, [&] { return !w.q.empty() || w.quit; });
+        if (w.q.empty()) return;  // quit, nothing pending
+        Worker::Job job = std::move(w.q.front());
+        w.q.pop_front();
         lk.unlock();
-        const int rc = job();
+        const int rc = job.fn();
         const std::string err = rc ? cgv_last_error() : "";
         lk.lock();
-        w.rc = rc;
-        w.err = err;
-        w.done = true;
+        if (rc) w.failed.push_back({job.seq, {rc, err}});
+        w.done_seq = job.seq;
         w.cv.notify_all();
     }
 }
 
 // Post one job per shard (jobs[i] may be empty = nothing to do), wait for all; first failure wins.
 int run_all(cgv_sharded* s, std::vector<std::function<int()>>& jobs) {
-    for (uint32_t g = 0; g < s->G; ++g) {
-        if (!jobs[g]) continue;
-        Worker& w = s->sh[g]->w;
-        std::lock_guard<std::mutex> lk(w.mu);
-        w.job = std::move(jobs[g]);
-        w.has_job = true;
-        w.done = false;
-        w.cv.notify_all();
-    }
+    std::vector<uint64_t> ids(s->G, 0);
+    for (uint32_t g = 0; g < s->G; ++g)
+        if (jobs[g]) ids[g] = s->sh[g]->w.post(std::move(jobs[g]));
     int rc = CGV_OK;
     std::string err;
     for (uint32_t g = 0; g < s->G; ++g) {
-        Worker& w = s->sh[g]->w;
-        std::unique_lock<std::mutex> lk(w.mu);
-        w.cv.wait(lk, [&] { return w.done; });
-        if (w.rc && !rc) {
-            rc = w.rc;
-            err = "shard " + std::to_string(g) + " (device " + std::to_string(s->sh[g]->device) + "): " + w.err;
+        if (!ids[g]) continue;
+        std::string e;
+        const int r = s->sh[g]->w.wait(ids[g], &e);
+        if (r && !rc) {
+            rc = r;
+            err = "shard " + std::to_string(g) + " (device " + std::to_string(s->sh[g]->device) + "): " + e;
         }
-        w.rc = CGV_OK;
     }
     return rc ? fail(rc, err) : CGV_OK;
 }
+
+// The calling thread's current HIP device is restored when a cgv_sharded_* entry point returns.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = -1;
+        }
+    }
+    ~DeviceGuard() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+};
 
 void locate(const cgv_sharded* s, uint64_t id, uint32_t* shard, uint64_t* local) {
     const uint64_t chunk = id / C;
@@ -334,7 +388,7 @@ int cgv_sharded_destroy(cgv_sharded* s) {
         if (sh->w.th.joinable()) {
             {
                 std::lock_guard<std::mutex> lk(sh->w.mu);
-                sh->w.quit = true;
+                sh->w.quit = true;  // (pending jobs still run: the worker leaves once its queue is empty)
                 sh->w.cv.notify_all();
             }
             sh->w.th.join();
@@ -346,15 +400,20 @@ int cgv_sharded_destroy(cgv_sharded* s) {
         if (sh->xs) (void)hipStreamSynchronize(sh->xs);
         if (sh->comm && r) (void)r->CommDestroy(sh->comm);
         if (sh->ix) (void)cgv_destroy(sh->ix);
-        for (Buf* b : {&sh->qdev, &sh->oidx, &sh->osc, &sh->rec, &sh->gathered, &sh->stage}) b->release();
+        sh->stage.release();
+        for (auto& sb : sh->slot)
+            for (Buf* b : {&sb.qdev, &sb.oidx, &sb.osc, &sb.rec, &sb.gathered}) b->release();
         if (sh->xs) (void)hipStreamDestroy(sh->xs);
     }
     if (!s->sh.empty()) {
         (void)hipSetDevice(s->sh[0]->device);
-        s->moidx.release();
-        s->mosc.release();
+        for (auto& sl : s->slots) {
+            sl.moidx.release();
+            sl.mosc.release();
+        }
     }
-    if (s->pin_q) (void)hipHostFree(s->pin_q);
+    for (auto& sl : s->slots)
+        if (sl.pin_q) (void)hipHostFree(sl.pin_q);
     for (Shard* sh : s->sh) delete sh;
     delete s;
     return CGV_OK;
@@ -464,108 +523,245 @@ int cgv_sharded_set_exchange(cgv_sharded* s, int kind) {
     return set_exchange_locked(s, kind);
 }
 
-int cgv_sharded_search_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
-                           float* out_score_host) {
+// ---- search: batches in flight ----------------------------------------------------------------------
+// begin  = slot + buffers, one host pass of the queries into pinned staging, then per shard (its worker thread):
+//          H2D over the shard's own PCIe link + cgv_search_begin_f32_dev (the single-device pipeline, enqueued, no wait);
+// end    = per shard: cgv_search_end (its results exist), pack, the exchange (ncclAllGather posted by EVERY shard,
+//          whatever its own search returned - a collective some rank skips hangs the others; or the copy into the root's
+//          gather buffer) and the stream wait; then ONE join of the workers, the root's merge and the result copy.
+// A caller that keeps two batches in flight (begin i+1 before end i) overlaps batch i's exchange + merge + D2H with
+// batch i+1's search on the devices.
+namespace {
+
+int slot_of_ticket(cgv_sharded* s, uint64_t ticket, cgv_sharded::Slot** out) {
+    const uint64_t si = ticket & 0xff;
+    if (si == 0 || si > (uint64_t)N_SLOTS) return fail(CGV_ERR_INVALID_ARG, "bad ticket");
+    cgv_sharded::Slot* sl = &s->slots[si - 1];
+    if (!sl->busy || sl->gen != (uint32_t)(ticket >> 8)) return fail(CGV_ERR_INVALID_ARG, "stale ticket");
+    *out = sl;
+    return CGV_OK;
+}
+
+// every shard's exchange stream idle (error paths: nothing of this batch may still be reading the staging buffers)
+void drain_streams(cgv_sharded* s) {
+    std::vector<std::function<int()>> jobs(s->G);
+    for (uint32_t g = 0; g < s->G; ++g) {
+        Shard* sh = s->sh[g];
+        jobs[g] = [sh]() -> int {
+            (void)hipStreamSynchronize(sh->xs);
+            return CGV_OK;
+        };
+    }
+    (void)run_all(s, jobs);
+}
+
+// A rank failed to post its part of a collective: the other ranks would wait in it forever. Abort every communicator
+// (unblocks them) and fall back to the copy exchange for the rest of the handle's life.
+void abort_rccl(cgv_sharded* s, const Rccl* r) {
+    s->rccl_broken = true;
+    for (Shard* sh : s->sh) {
+        if (sh->comm && r && r->CommAbort) (void)r->CommAbort(sh->comm);
+        sh->comm = nullptr;
+    }
+    s->exchange = CGV_EXCHANGE_COPY;
+}
+
+}  // namespace
+
+int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k,
+                                 uint64_t* out_idx_host, float* out_score_host, uint64_t* ticket) {
+    if (!ticket) return fail(CGV_ERR_INVALID_ARG, "ticket is NULL");
+    *ticket = 0;
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    if (nq == 0 || k == 0) return CGV_OK;  // surreal_store.rs:62-64
+    if (nq == 0 || k == 0) return CGV_OK;  // surreal_store.rs:62-64; ticket 0 = nothing to wait for
     if (!queries_host || !out_idx_host || !out_score_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
     if (k > CGV_MAX_K) return fail(CGV_ERR_INVALID_ARG, "k exceeds CGV_MAX_K");
-    if ((uint64_t)s->G * k > 4096) return fail(CGV_ERR_INVALID_ARG, "n_shards * k exceeds 4096 (merge capacity)");
-    std::lock_guard<std::mutex> lk(s->mu);
-    const auto t0 = Clock::now();
+    DeviceGuard guard;
+    std::unique_lock<std::mutex> lk(s->mu);
+    int si = -1;
+    for (int i = 0; i < N_SLOTS; ++i)
+        if (!s->slots[i].busy) {
+            si = i;
+            break;
+        }
+    if (si < 0)
+        return fail(CGV_ERR_BUSY, "all " + std::to_string(N_SLOTS) + " batches in flight: call cgv_sharded_search_end first");
+    cgv_sharded::Slot& sl = s->slots[si];
     const uint32_t G = s->G, D = s->D;
     const uint32_t w = cgv_packed_width(k);
     const size_t qbytes = (size_t)nq * D * 4, rec_bytes = (size_t)nq * w * 4;
     Shard* root = s->sh[0];
-    // buffers (only when the batch shape grows)
-    if (s->pin_q_bytes < qbytes) {
-        if (s->pin_q) (void)hipHostFree(s->pin_q);
-        s->pin_q = nullptr;
-        s->pin_q_bytes = 0;
+    if (sl.pin_q_bytes < qbytes) {  // (the slot is idle: nothing reads its staging)
+        if (sl.pin_q) (void)hipHostFree(sl.pin_q);
+        sl.pin_q = nullptr;
+        sl.pin_q_bytes = 0;
         SHIP(hipSetDevice(root->device));
-        SHIP(hipHostMalloc((void**)&s->pin_q, qbytes, hipHostMallocPortable));
-        s->pin_q_bytes = qbytes;
+        SHIP(hipHostMalloc((void**)&sl.pin_q, qbytes, hipHostMallocPortable));
+        sl.pin_q_bytes = qbytes;
     }
     for (Shard* sh : s->sh) {
         SHIP(hipSetDevice(sh->device));
+        Shard::SlotBufs& b = sh->slot[si];
         int rc;
-        if ((rc = sh->qdev.ensure(qbytes))) return rc;
-        if ((rc = sh->oidx.ensure((size_t)nq * k * 8))) return rc;
-        if ((rc = sh->osc.ensure((size_t)nq * k * 4))) return rc;
+        if ((rc = b.qdev.ensure(qbytes))) return rc;
+        if ((rc = b.oidx.ensure((size_t)nq * k * 8))) return rc;
+        if ((rc = b.osc.ensure((size_t)nq * k * 4))) return rc;
         if (G > 1) {
-            if ((rc = sh->rec.ensure(rec_bytes))) return rc;
-            if ((s->exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = sh->gathered.ensure((size_t)G * rec_bytes))) return rc;
+            if ((rc = b.rec.ensure(rec_bytes))) return rc;
+            if ((s->exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = b.gathered.ensure((size_t)G * rec_bytes))) return rc;
         }
     }
-    SHIP(hipSetDevice(root->device));
     if (G > 1) {
+        SHIP(hipSetDevice(root->device));
         int rc;
-        if ((rc = s->moidx.ensure((size_t)nq * k * 8))) return rc;
-        if ((rc = s->mosc.ensure((size_t)nq * k * 4))) return rc;
+        if ((rc = sl.moidx.ensure((size_t)nq * k * 8))) return rc;
+        if ((rc = sl.mosc.ensure((size_t)nq * k * 4))) return rc;
     }
-    memcpy(s->pin_q, queries_host, qbytes);  // one pass; every device then pulls it over its own link
-
-    const int exchange = s->exchange;
-    const Rccl* rccl = exchange == CGV_EXCHANGE_RCCL ? load_rccl() : nullptr;
-    const float* pin_q = s->pin_q;
-    std::vector<std::function<int()>> jobs(G);
+    memcpy(sl.pin_q, queries_host, qbytes);  // one pass; every device then pulls it over its own link
+    sl.busy = true;
+    sl.gen++;
+    sl.nq = nq;
+    sl.k = k;
+    sl.out_idx = out_idx_host;
+    sl.out_score = out_score_host;
+    sl.t0 = Clock::now();
+    sl.job_a.assign(G, 0);
+    const float* pin_q = sl.pin_q;
     for (uint32_t g = 0; g < G; ++g) {
         Shard* sh = s->sh[g];
+        sl.job_a[g] = sh->w.post([=]() -> int {
+            Shard::SlotBufs& b = sh->slot[si];
+            b.ticket = 0;
+            b.rc_a = CGV_OK;
+            auto half = [&]() -> int {
+                SHIP(hipMemcpyAsync(b.qdev.p, pin_q, qbytes, hipMemcpyHostToDevice, sh->xs));
+                return cgv_search_begin_f32_dev(sh->ix, (const float*)b.qdev.p, nq, k, (uint64_t*)b.oidx.p, (float*)b.osc.p,
+                                                &b.ticket);
+            };
+            b.rc_a = half();
+            if (b.rc_a) b.err_a = cgv_last_error();
+            return CGV_OK;  // the status travels with the slot: the second half reports it
+        });
+    }
+    *ticket = ((uint64_t)sl.gen << 8) | (uint64_t)(si + 1);
+    return CGV_OK;
+}
+
+int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
+    if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (ticket == 0) return CGV_OK;
+    DeviceGuard guard;
+    std::unique_lock<std::mutex> lk(s->mu);
+    cgv_sharded::Slot* slp = nullptr;
+    if (int rc = slot_of_ticket(s, ticket, &slp)) return rc;
+    cgv_sharded::Slot& sl = *slp;
+    const int si = (int)(slp - s->slots);
+    const uint32_t G = s->G, nq = sl.nq, k = sl.k;
+    const uint32_t w = cgv_packed_width(k);
+    const size_t rec_bytes = (size_t)nq * w * 4;
+    Shard* root = s->sh[0];
+    const int exchange = s->exchange;
+    std::string why;
+    const Rccl* rccl = exchange == CGV_EXCHANGE_RCCL ? load_rccl(&why) : nullptr;
+    std::vector<std::function<int()>> jobs(G);
+    std::vector<int> xerr(G, 0);  // a rank's collective call failed
+    for (uint32_t g = 0; g < G; ++g) {
+        Shard* sh = s->sh[g];
+        int* xe = &xerr[g];
         jobs[g] = [=]() -> int {
-            SHIP(hipMemcpyAsync(sh->qdev.p, pin_q, qbytes, hipMemcpyHostToDevice, sh->xs));
-            int rc = cgv_search_f32_dev(sh->ix, (const float*)sh->qdev.p, nq, k, (uint64_t*)sh->oidx.p, (float*)sh->osc.p);
-            sh->t_search_done = Clock::now();
-            if (rc || G == 1) return rc;
-            if ((rc = cgv_pack_topk_dev(sh->device, (const uint64_t*)sh->oidx.p, (const float*)sh->osc.p, nq, k,
-                                        (uint32_t*)sh->rec.p, sh->xs)))
-                return rc;
-            if (exchange == CGV_EXCHANGE_RCCL) return CGV_OK;  // the collective is entered below, by ALL shards or none
-            char* dst = (char*)root->gathered.p + (size_t)g * rec_bytes;
-            if (sh->device == root->device)
-                SHIP(hipMemcpyAsync(dst, sh->rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs));
-            else
-                SHIP(hipMemcpyPeerAsync(dst, root->device, sh->rec.p, sh->device, rec_bytes, sh->xs));
-            SHIP(hipStreamSynchronize(sh->xs));
-            return CGV_OK;
+            Shard::SlotBufs& b = sh->slot[si];
+            int rc = b.rc_a;
+            std::string err = b.err_a;
+            if (rc == CGV_OK && b.ticket) {
+                rc = cgv_search_end(sh->ix, b.ticket);
+                if (rc) err = cgv_last_error();
+            }
+            b.t_search_done = Clock::now();
+            if (G > 1) {
+                if (rc == CGV_OK) {
+                    rc = cgv_pack_topk_dev(sh->device, (const uint64_t*)b.oidx.p, (const float*)b.osc.p, nq, k, (uint32_t*)b.rec.p,
+                                           sh->xs);
+                    if (rc) err = cgv_last_error();
+                }
+                if (exchange == CGV_EXCHANGE_RCCL) {
+                    // entered by every shard, also after a failure of its own (the buffers exist; the batch's status
+                    // discards the result): a collective that one rank skips never completes on the others
+                    const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                    if (e != 0) {
+                        *xe = 1;
+                        if (rc == CGV_OK) {
+                            rc = CGV_ERR_HIP;
+                            err = std::string("ncclAllGather: ") + rccl->GetErrorString(e);
+                        }
+                        return fail(rc, err);  // no stream wait: the caller aborts the communicators
+                    }
+                } else if (rc == CGV_OK) {
+                    char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
+                    hipError_t he = sh->device == root->device
+                                        ? hipMemcpyAsync(dst, b.rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs)
+                                        : hipMemcpyPeerAsync(dst, root->device, b.rec.p, sh->device, rec_bytes, sh->xs);
+                    if (he != hipSuccess) {
+                        rc = CGV_ERR_HIP;
+                        err = std::string("exchange copy: ") + hipGetErrorString(he);
+                    }
+                }
+            }
+            const hipError_t se = hipStreamSynchronize(sh->xs);
+            if (se != hipSuccess && rc == CGV_OK) {
+                rc = CGV_ERR_HIP;
+                err = std::string("hipStreamSynchronize: ") + hipGetErrorString(se);
+            }
+            return rc ? fail(rc, err) : CGV_OK;
         };
     }
-    int rc = run_all(s, jobs);
-    if (rc) return rc;
-    if (G > 1 && exchange == CGV_EXCHANGE_RCCL) {
-        // A collective that one rank never enters hangs the others: it is only started once every shard's search
-        // and pack were enqueued without error (a failed shard returned above, before anyone called into RCCL).
-        for (uint32_t g = 0; g < G; ++g) {
-            Shard* sh = s->sh[g];
-            jobs[g] = [=]() -> int {
-                const int e = rccl->AllGather(sh->rec.p, sh->gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
-                if (e != 0) return fail(CGV_ERR_HIP, std::string("ncclAllGather: ") + rccl->GetErrorString(e));
-                SHIP(hipStreamSynchronize(sh->xs));
-                return CGV_OK;
-            };
-        }
-        if ((rc = run_all(s, jobs))) return rc;
+    int rc = run_all(s, jobs);  // the ONE host join of the batch
+    bool any_xerr = false;
+    for (int e : xerr) any_xerr = any_xerr || e;
+    if (any_xerr) {
+        const std::string msg = cgv_last_error();
+        abort_rccl(s, rccl);
+        drain_streams(s);
+        rc = fail(rc ? rc : CGV_ERR_HIP, msg + " (RCCL communicators aborted; the handle continues with the copy exchange)");
     }
-    auto t1 = s->sh[0]->t_search_done;
-    for (Shard* sh : s->sh) t1 = std::max(t1, sh->t_search_done);
-    SHIP(hipSetDevice(root->device));
-    const uint64_t* ri = (const uint64_t*)root->oidx.p;
-    const float* rs = (const float*)root->osc.p;
-    if (G > 1) {
-        if ((rc = cgv_merge_packed_dev(root->device, (const uint32_t*)root->gathered.p, G, nq, k, (uint64_t*)s->moidx.p,
-                                       (float*)s->mosc.p, root->xs)))
-            return rc;
-        ri = (const uint64_t*)s->moidx.p;
-        rs = (const float*)s->mosc.p;
+    auto finish = [&](int code) {
+        sl.busy = false;
+        s->slot_cv.notify_all();
+        return code;
+    };
+    if (rc) return finish(rc);
+    auto t1 = s->sh[0]->slot[si].t_search_done;
+    for (Shard* sh : s->sh) t1 = std::max(t1, sh->slot[si].t_search_done);
+    hipError_t he = hipSetDevice(root->device);
+    const uint64_t* ri = (const uint64_t*)root->slot[si].oidx.p;
+    const float* rs = (const float*)root->slot[si].osc.p;
+    if (he == hipSuccess && G > 1) {
+        rc = cgv_merge_packed_dev(root->device, (const uint32_t*)root->slot[si].gathered.p, G, nq, k, (uint64_t*)sl.moidx.p,
+                                  (float*)sl.mosc.p, root->xs);
+        ri = (const uint64_t*)sl.moidx.p;
+        rs = (const float*)sl.mosc.p;
     }
-    SHIP(hipMemcpyAsync(out_idx_host, ri, (size_t)nq * k * 8, hipMemcpyDeviceToHost, root->xs));
-    SHIP(hipMemcpyAsync(out_score_host, rs, (size_t)nq * k * 4, hipMemcpyDeviceToHost, root->xs));
-    SHIP(hipStreamSynchronize(root->xs));
+    if (rc == CGV_OK && he == hipSuccess) he = hipMemcpyAsync(sl.out_idx, ri, (size_t)nq * k * 8, hipMemcpyDeviceToHost, root->xs);
+    if (rc == CGV_OK && he == hipSuccess) he = hipMemcpyAsync(sl.out_score, rs, (size_t)nq * k * 4, hipMemcpyDeviceToHost, root->xs);
+    const hipError_t se = hipStreamSynchronize(root->xs);  // also on the error paths: nothing stays in flight
+    if (rc == CGV_OK && he == hipSuccess) he = se;
+    if (rc == CGV_OK && he != hipSuccess) rc = fail(CGV_ERR_HIP, std::string("sharded search, result copy: ") + hipGetErrorString(he));
+    if (rc) return finish(rc);
     const auto t2 = Clock::now();
     s->searches++;
     s->queries += nq;
-    s->last_search_ms = std::chrono::duration<float, std::milli>(t2 - t0).count();
+    s->last_search_ms = std::chrono::duration<float, std::milli>(t2 - sl.t0).count();
     s->last_exchange_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
-    return CGV_OK;
+    return finish(CGV_OK);
+}
+
+uint32_t cgv_sharded_max_batches_in_flight(const cgv_sharded* s) { return s ? (uint32_t)N_SLOTS : 0u; }
+
+int cgv_sharded_search_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
+                           float* out_score_host) {
+    uint64_t t = 0;
+    int rc = cgv_sharded_search_begin_f32(s, queries_host, nq, k, out_idx_host, out_score_host, &t);
+    if (rc) return rc;
+    return cgv_sharded_search_end(s, t);
 }
 
 int cgv_sharded_get_stats(cgv_sharded* s, cgv_sharded_stats* out) {
@@ -583,8 +779,9 @@ int cgv_sharded_get_stats(cgv_sharded* s, cgv_sharded_stats* out) {
         cgv_stats st;
         const int rc = cgv_get_stats(sh->ix, &st);
         if (rc) return rc;
-        out->device_bytes += st.device_bytes + sh->qdev.bytes + sh->oidx.bytes + sh->osc.bytes + sh->rec.bytes +
-                             sh->gathered.bytes + sh->stage.bytes;
+        out->device_bytes += st.device_bytes + sh->stage.bytes;
+        for (const auto& sb : sh->slot)
+            out->device_bytes += sb.qdev.bytes + sb.oidx.bytes + sb.osc.bytes + sb.rec.bytes + sb.gathered.bytes;
         out->fallback_queries += st.fallback_queries;
     }
     return CGV_OK;

@@ -269,8 +269,9 @@ typedef struct cgv_stats {
 } cgv_stats;
 int cgv_get_stats(cgv_index* h, cgv_stats* out);
 
-/* Enable (1) / disable (0) HIP-event timing of each search (adds two event records
- * around the dominant kernel on the stream it is launched on). */
+/* HIP-event timing of each search, on the stream its kernels are launched on: 0 = off; 1 = two event records around
+ * the dominant coarse launch (cgv_stats.last_coarse_ms); 2 = also around the whole pipeline (last_total_ms). Each
+ * record is a packet on the stream: level 2 measured ~10 us per batch on short searches. */
 int cgv_set_profiling(cgv_index* h, int enabled);
 
 /* Tuning knob for tests: force the exact full-scan path (1) or auto (0). */
@@ -294,7 +295,8 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
  *             than once, which is how a 1-GPU box exercises the whole path) - and the root merges
  *             n_devices * k records per query with (score desc, id asc). Exact: the global top-k is a
  *             subset of the union of the per-shard top-k.
- * Thread-safety: calls on one cgv_sharded are serialised by the handle. */
+ * Thread-safety: calls on one cgv_sharded are serialised by the handle (a call holds it while it runs; searches split
+ * into begin / end overlap on the devices between the two calls). */
 typedef struct cgv_sharded cgv_sharded;
 #define CGV_SHARD_CHUNK_ROWS 4096u
 #define CGV_EXCHANGE_NONE 0 /* one shard */
@@ -314,9 +316,22 @@ uint64_t cgv_sharded_count(const cgv_sharded* s);
 uint32_t cgv_sharded_n_shards(const cgv_sharded* s);
 /* Borrowed handle of shard i (statistics, profiling switches); do not add to / destroy it. */
 cgv_index* cgv_sharded_shard(cgv_sharded* s, uint32_t i);
-/* cgv_search_f32 over all shards; out arrays HOST [nq][k], ids global. */
+/* cgv_search_f32 over all shards; out arrays HOST [nq][k], ids global. Any k <= CGV_MAX_K on any number of shards
+ * (n_shards * k <= 4096: LDS merge; beyond: a slower G-way wave merge). = begin + end below. */
 int cgv_sharded_search_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k,
                            uint64_t* out_idx_host, float* out_score_host);
+/* The same in two halves, so that batches overlap on the devices (the counterpart of cgv_search_begin_f32_dev /
+ * cgv_search_end for ONE backend object that owns all shards, surreal_store.rs:11-22): begin copies the queries
+ * (the caller's buffer is free again on return), enqueues every shard's search and returns a ticket; end waits for the
+ * shards, runs pack + exchange + merge and fills the HOST out arrays given to begin (one host join per batch). Up to
+ * cgv_sharded_max_batches_in_flight() tickets may be open (CGV_ERR_BUSY beyond); with two in flight the exchange,
+ * merge and result copy of batch i run beside the search of batch i + 1. nq == 0 or k == 0: ticket 0, nothing to end.
+ * On error the out arrays are unspecified. The calling thread's current HIP device is restored before every
+ * cgv_sharded_* call returns. */
+int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k,
+                                 uint64_t* out_idx_host, float* out_score_host, uint64_t* ticket);
+int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket);
+uint32_t cgv_sharded_max_batches_in_flight(const cgv_sharded* s);
 /* Which exchange the handle uses (CGV_EXCHANGE_*); cgv_sharded_set_exchange forces RCCL or COPY
  * (RCCL needs distinct devices). */
 int cgv_sharded_exchange(const cgv_sharded* s);

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (workload table + generators)
 
-KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1, "profiling": 1}
+KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1, "profiling": 2}
 
 
 def main():
@@ -52,7 +52,7 @@ def main():
     qhost = [q.cpu().pin_memory() for q in qpool]
     out_i = torch.empty((batch, k), dtype=torch.int64).pin_memory()
     out_s = torch.empty((batch, k), dtype=torch.float32).pin_memory()
-    ix.set_profiling(True)
+    ix.set_profiling(2)
     vp = C.c_void_p
 
     variants = []
@@ -67,7 +67,7 @@ def main():
     def apply(knobs):
         for key, val in knobs.items():
             if key == "profiling":       # HIP events around the dominant launch / the pipeline (cgv_set_profiling)
-                ix.set_profiling(bool(val))
+                ix.set_profiling(int(val))
                 continue
             assert L.cgv_debug_set_(key.encode(), float(val)) == 0, key
 

@@ -101,6 +101,69 @@ def test_sharded_handle_matches_oracle(oracle, g, dtype):
         sx.close()
 
 
+def test_sharded_batches_in_flight_and_large_k(oracle):
+    """cgv_sharded_search_begin_f32 / _end: three batches in flight on ONE handle return what three serial searches
+    return (and the oracle), a fourth begin is CGV_ERR_BUSY, tickets can be ended in any order; n_shards * k > 4096
+    takes the G-way wave merge and still equals the oracle (it used to be rejected)."""
+    m = pkg()
+    rng = np.random.default_rng(77)
+    n, d, k = 4 * C + 321, 64, 10
+    rows = _unit(rng, n, d)
+    qs = [_unit(rng, nq, d) for nq in (33, 257, 5)]
+    sx = m.ShardedIndex(d, _devices(m, 3), dtype="bf16")
+    try:
+        sx.add(rows)
+        assert sx.max_in_flight == 3
+        pend = [sx.search_begin(q, k) for q in qs]
+        with pytest.raises(m.CgvError) as ei:
+            sx.search_begin(qs[0], k)
+        assert ei.value.code == m.cgvec.CGV_ERR_BUSY
+        for i in (1, 0, 2):                     # out of order
+            idx, sc = pend[i].wait()
+            ri, rs = oracle.batch_top_k(qs[i], rows, k, dtype=1)
+            assert np.array_equal(idx, ri) and np.array_equal(sc, rs), i
+        with pytest.raises(m.CgvError):         # a ticket is good once
+            pend[0].wait()
+        # steady state: begin i + 1 before end i
+        prev = sx.search_begin(qs[0], k)
+        for i in range(1, 6):
+            nxt = sx.search_begin(qs[i % 3], k)
+            idx, sc = prev.wait()
+            ri, rs = oracle.batch_top_k(qs[(i - 1) % 3], rows, k, dtype=1)
+            assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+            prev = nxt
+        prev.wait()
+        # k beyond the LDS merge: 3 shards x 1500 = 4500 records per query
+        kk = 1500
+        idx, sc = sx.search(qs[2], kk)
+        ri, rs = oracle.batch_top_k(qs[2], rows, kk, dtype=1)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    finally:
+        sx.close()
+
+
+def test_merge_wave_kernel_matches_lds_merge(oracle):
+    """cgv_merge_topk_dev beyond g * k = 4096 (G-way wave merge) against the oracle's merge, ties by id and padded
+    tails included."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(5)
+    g, nq, k = 5, 7, 1000
+    sc = np.sort(rng.standard_normal((g, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ids = rng.permutation(g * nq * k).astype(np.uint64).reshape(g, nq, k)
+    sc[1, :, :50] = sc[0, :, :50]                       # equal scores across lists: lower id first
+    for gi in range(g):                                  # each list sorted by (score desc, id asc)
+        for q in range(nq):
+            o = np.lexsort((ids[gi, q], -sc[gi, q]))
+            ids[gi, q], sc[gi, q] = ids[gi, q][o], sc[gi, q][o]
+    ids[3, :, 700:] = np.uint64(2**64 - 1)               # a short list, padded
+    sc[3, :, 700:] = -np.inf
+    oi, os_ = m.merge_topk(torch.from_numpy(ids.view(np.int64)).cuda(), torch.from_numpy(sc).cuda())
+    for q in range(nq):
+        ri, rs = oracle.merge_topk(ids[:, q, :], sc[:, q, :], k)
+        assert np.array_equal(oi[q].cpu().numpy().view(np.uint64), ri) and np.array_equal(os_[q].cpu().numpy(), rs), q
+
+
 def test_sharded_add_is_all_or_nothing(oracle):
     """A NaN row in one shard's part of an insert: CGV_ERR_NONFINITE and NO shard keeps any row of it."""
     m = pkg()
