@@ -8,7 +8,6 @@
 
 #include "../../include/cgvec.h"
 #include "coarse_launch.h"
-#include "kernels_coarse_w4.h"
 
 extern "C" int cgv_set_error_(int code, const char* msg);
 
@@ -32,7 +31,6 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_DUMP>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_SAMPLE>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true>))) return rc;
-    if ((rc = coarse_set_lds((const void*)coarse_w4_kernel<DT, false>))) return rc;
     return CGV_OK;
 }
 
@@ -67,30 +65,6 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
 #undef CGV_ABLK
             return coarse_hip_status("coarse_kernel (ablation)");
         }
-        static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;
-        static const bool w4a = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
-        if (abl4 && w4a && a.kc >= 4) {
-#define CGV_ABLK4(N)                                                           \
-    case N: {                                                                  \
-        auto k2 = coarse_w4_kernel<DT, false, N>;                              \
-        if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                 \
-        break;                                                                 \
-    }
-            switch (abl4) {
-                CGV_ABLK4(1) CGV_ABLK4(3) CGV_ABLK4(5) CGV_ABLK4(9) CGV_ABLK4(11) CGV_ABLK4(17)
-                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE_W4: unknown mask");
-            }
-#undef CGV_ABLK4
-            return coarse_hip_status("coarse_w4_kernel (ablation)");
-        }
-    }
-    // CGV_COARSE=w4 selects the one-wave-per-SIMD variant (kernels_coarse_w4.h; kc >= 4) for A/B timing: same
-    // results, measured equal to the 8-wave kernel on the main launch and slower on hit-heavy launches.
-    static const bool use_w4 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w4");
-    if (use_w4 && a.kc >= 4) {
-        hipLaunchKernelGGL((coarse_w4_kernel<DT, false>), dim3(W), dim3(256), lds, s, a);
-        return coarse_hip_status("coarse_w4_kernel");
     }
     if constexpr (ABLATE) {  // A/B reference: the round-2 epilogue (bf16 build only)
         if ((a.epi & 1u) == 0) {

@@ -142,10 +142,10 @@ def test_fp8_mixed_row_scales_staged(oracle):
     assert st["max_observed_err"] <= st["last_eps"]
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_one_wave_per_simd_variant(oracle, dtype):
-    """CGV_COARSE=w4 (kernels_coarse_w4.h, an opt-in A/B variant read once per process): same candidates, same
-    bit-exact results, no fallback. Runs in a child process because the switch is read at first use."""
+def test_reference_epilogue_variant(oracle):
+    """CGV_EPI=0: the round-2 epilogue of the bf16 coarse kernel (everything at the tile boundary), kept in the build as
+    the A/B reference of the interleaved one - same candidates, same bit-exact results, no fallback. A child process:
+    the switch is read at load time."""
     import os
     import subprocess
     import sys
@@ -160,18 +160,18 @@ rng = np.random.default_rng(21)
 n, d, nq, k = 40_000, 1024, 300, 10
 rows = rng.standard_normal((n, d)).astype(np.float32)
 queries = rng.standard_normal((nq, d)).astype(np.float32)
-ix = m.HipKnnIndex(d, metric="cosine", dtype={dtype!r})
+ix = m.HipKnnIndex(d, metric="cosine", dtype="bf16")
 ix.add(rows)
 idx, sc = ix.search(queries, k)
 st = ix.stats()
-ri, rs = o.batch_top_k(queries, rows, k, metric=0, dtype={ODT[dtype]})
-assert np.array_equal(idx, ri) and np.array_equal(sc, rs), "w4 results differ from the oracle"
+ri, rs = o.batch_top_k(queries, rows, k, metric=0, dtype=1)
+assert np.array_equal(idx, ri) and np.array_equal(sc, rs), "results differ from the oracle"
 assert st["last_path"] == 1 and st["fallback_queries"] == 0, st
-print("W4-OK")
+print("EPI0-OK")
 """
-    env = dict(os.environ, CGV_COARSE="w4")
+    env = dict(os.environ, CGV_EPI="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "W4-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "EPI0-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
