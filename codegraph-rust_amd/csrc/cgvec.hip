@@ -686,7 +686,9 @@ Tunables& tun() {
 // kappa * (rho - 1)); m is the cheapest count whose expected emissions fit the candidate lists (LIST_TARGET per
 // (workgroup, query) list of CAND_CAPS entries, MERGE_TARGET per query). C2: S = 16 k rows, m = 2 (112 k + 888 k
 // rows); the 125 k-row shard of C2 at 8 GPUs: ONE launch.
-constexpr uint32_t SAMPLE_TILES_MAX = 64;  // tau_kernel: 16 block maxima per tile, <= 1024 values per query
+constexpr uint32_t SAMPLE_TILES_MAX = 256;  // tau_kernel takes <= 1024 group maxima per query: 16 per tile up to 64 tiles,
+                                           // 8 up to 128, 4 up to 256 (sample_vals_of)
+uint32_t sample_vals_of(uint32_t sample_tiles) { return sample_tiles <= 64 ? 16u : (sample_tiles <= 128 ? 8u : 4u); }
 constexpr uint32_t LIST_TARGET = 32;
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, uint32_t nsplit_max) {
     const Tunables& t = tun();
@@ -695,10 +697,12 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, 
     if (t.plan_legacy || p.ntiles <= BOOT_TILES) return plan_stages_legacy(n, kprime, nsplit_max);
     const int forced_s = t.sample_tiles, forced_m = t.plan_launches;
     const double hit_us = t.hit_us, launch_us = t.launch_us;
+    // one pass of the chip: one tile per CU, but never more than 1/8 of the corpus (it is scored again by the launches)
     uint32_t S = std::min<uint32_t>(std::max<uint32_t>(n_cu / std::max<uint32_t>(nqt, 1u), 8u), SAMPLE_TILES_MAX);
+    while (S > 64 && S * 8 > p.ntiles) S /= 2;
     if (forced_s > 0) S = std::min<uint32_t>((uint32_t)forced_s, SAMPLE_TILES_MAX);
     // the k'-th largest of 16 S block maxima: keep a few times k' of them
-    while (S < SAMPLE_TILES_MAX && 16u * S < 4u * kprime) S *= 2;
+    while (S < 64 && 16u * S < 4u * kprime) S *= 2;
     S = std::min(S, p.ntiles);
     p.sample_tiles = S;
     p.T1 = 0;
@@ -836,6 +840,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.overflow = c->overflow.as<uint32_t>();
         a.dump = nullptr;
         a.sample_ld = 0;
+        a.sample_vals = 16;
         a.epi = (uint32_t)tun().epi;
         a.n = (uint32_t)h->n;
         a.nq = nq;
@@ -854,12 +859,14 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 
         if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
-            const uint32_t M = p.sample_tiles * 16u;
+            const uint32_t vals = sample_vals_of(p.sample_tiles);
+            const uint32_t M = p.sample_tiles * vals;
             if ((rc = c->dump.ensure((size_t)nq * M * 4))) return rc;
             CoarseArgs sa = a;
             sa.dump = c->dump.as<float>();
             sa.pace = nullptr;
             sa.sample_ld = M;
+            sa.sample_vals = vals;
             sa.j0 = 0;
             sa.cnt = p.sample_tiles;
             sa.nsplit = std::min<uint32_t>(p.sample_tiles, nsplit_max);
@@ -2064,6 +2071,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.rexp_q = c->qrexp.as<int8_t>();
     a.pace = nullptr;
     a.sample_ld = 0;
+    a.sample_vals = 16;
     a.epi = 1;
     if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));

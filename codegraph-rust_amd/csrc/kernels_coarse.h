@@ -99,7 +99,8 @@ struct CoarseArgs {
     const int8_t* rexp_c;   // fp8 only: [n] per-row power-of-two scale exponents of the corpus ...
     const int8_t* rexp_q;   //           [nq] ... and of the queries (kernels_coarse_fp8.h)
     uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
-    uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump` (16 per sampled tile)
+    uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump`
+    uint32_t sample_vals;   // SAMPLE mode: group maxima per (query, tile): 16, 8 or 4 (tile_epilogue)
     uint32_t epi;           // A/B switches (scripts/ab.py): bit 0 clear = round-2 epilogue (bf16 build only); bit 1 = no NT hint
 };
 
@@ -295,10 +296,12 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
     lane = lane_o;
     if (MODE == 2) {
         // SAMPLE: no threshold exists yet. Every lane reduces each of its 32 x 32 blocks to the
-        // maximum of its 16 coarse scores (16 distinct corpus rows); a query collects 16 such maxima per sampled
-        // tile, and the k'-th largest of them all is a valid first threshold: >= k' DISTINCT rows score at least
-        // that much (tau_kernel, kernels_select.h). Layout [q][seq * 16 + wm * 8 + (lane >> 5) * 4 + mb]: one
-        // 16-byte store per lane and N-block.
+        // maximum of its 16 coarse scores (16 distinct corpus rows); the k'-th largest of all the group maxima a query
+        // collects is a valid first threshold: >= k' DISTINCT rows score at least that much (tau_kernel,
+        // kernels_select.h). a.sample_vals values per (query, tile): 16 = one per lane and block (layout
+        // seq * 16 + wm * 8 + (lane >> 5) * 4 + mb: one 16-byte store per lane and N-block); 8 / 4 = the maxima of
+        // block pairs / of all four blocks of the lane (groups of 32 / 64 rows), for samples of up to 128 / 256 tiles
+        // within tau_kernel's 1024 values per query (one query tile: C4 samples with ALL CUs, 256 tiles).
         static_assert(MODE != 2 || MB == 4, "sample layout assumes 4 M-blocks per wave");
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -315,9 +318,17 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
                 }
                 m[mb] = (mm == -INFINITY) ? -INFINITY : mm * invq[nb];
             }
-            if (q < a.nq)
-                *(float4*)(a.dump + (uint64_t)q * a.sample_ld + seq * 16u + (uint32_t)(wm * 8 + (lane >> 5) * 4)) =
-                    make_float4(m[0], m[1], m[2], m[3]);
+            if (q < a.nq) {
+                float* dst = a.dump + (uint64_t)q * a.sample_ld + seq * a.sample_vals;
+                const uint32_t lg = (uint32_t)(wm * 2 + (lane >> 5));  // the lane's row group within the tile: 0..3
+                if (a.sample_vals == 16u) {
+                    *(float4*)(dst + lg * 4u) = make_float4(m[0], m[1], m[2], m[3]);
+                } else if (a.sample_vals == 8u) {
+                    *(float2*)(dst + lg * 2u) = make_float2(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                } else {
+                    dst[lg] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                }
+            }
         }
         return;
     }

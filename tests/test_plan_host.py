@@ -31,7 +31,7 @@ def test_plan_covers_every_tile_once(n, k, nq, shadow):
     L = pkg().cgvec.lib()
     sample, counts = _plan(L, n, k, nq, shadow=shadow)
     ntiles = (n + 255) // 256
-    assert 0 < sample <= 64 and sample <= ntiles          # block maxima of <= 64 tiles -> <= 1024 values per query
+    assert 0 < sample <= 256 and sample <= ntiles         # 16 / 8 / 4 group maxima per tile -> <= 1024 values per query
     assert all(c > 0 for c in counts) and sum(counts) == ntiles
     assert len(counts) <= 8
     # thresholds tighten launch by launch: the rows behind a launch's threshold never shrink relative to its size
@@ -46,6 +46,7 @@ def test_plan_shapes_of_the_baseline_configs():
     assert _plan(L, 1_000_000, 10, 1024) == (64, [448, 3459])   # C2: sample, 112 k rows, the dominant launch
     assert _plan(L, 125_000, 10, 1024) == (64, [489])           # C2's 8-GPU shard: ONE emitting launch
     assert _plan(L, 4096, 10, 64)[0] == 0                        # <= 16 tiles: the dense boot stage covers the corpus
+    assert _plan(L, 1_000_000, 10, 256) == (256, [3907])        # C4, one query tile: the sample uses every CU
 
 
 def test_rccl_loader_failure_is_reported_not_fatal():
