@@ -215,13 +215,16 @@ __device__ __forceinline__ float vmax2(float a, float b) {
     return r;
 }
 
-// maximum of the 16 scores a lane holds of one 32 x 32 block: 10 VALU
+// maximum of the 16 scores a lane holds of one 32 x 32 block: 8 VALU (7 three-input maxima + one two-input)
 __device__ __forceinline__ float block_max(const f32x16_t& v) {
-    const float m0 = vmax3(v[0], v[1], vmax2(v[2], v[3]));
-    const float m1 = vmax3(v[4], v[5], vmax2(v[6], v[7]));
-    const float m2 = vmax3(v[8], v[9], vmax2(v[10], v[11]));
-    const float m3 = vmax3(v[12], v[13], vmax2(v[14], v[15]));
-    return vmax3(m0, m1, vmax2(m2, m3));
+    const float m0 = vmax3(v[0], v[1], v[2]);
+    const float m1 = vmax3(v[3], v[4], v[5]);
+    const float m2 = vmax3(v[6], v[7], v[8]);
+    const float m3 = vmax3(v[9], v[10], v[11]);
+    const float m4 = vmax3(v[12], v[13], v[14]);
+    const float m5 = vmax3(m0, m1, v[15]);
+    const float m6 = vmax3(m2, m3, m4);
+    return vmax2(m5, m6);
 }
 
 // Slow path of one 32 x 32 block (some lane holds a score above its conservative threshold t): lanes with a score
@@ -240,10 +243,9 @@ __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& 
     // The inverse norms of the lane's 16 rows (4 runs of 4 consecutive rows) are fetched up front, 4 x 16 bytes from
     // the LDS ring (a vector GLOBAL load here would need s_waitcnt vmcnt(0), i.e. wait for the next chunk's DMA): they
     // land while the group maxima are tested, so a hit no longer pays an LDS round trip of its own before the list
-    // counter's (round 3; a hit costs two dependent LDS latencies otherwise).
+    // counter's (round 3: -0.4 % on the C2 step, -0.7 % on a hit-heavy single-launch plan, profiles/r03f_ab.txt).
     f32x4_t inv4[4];
-    const bool late_invn = (a.epi & 4u) != 0;  // A/B switch (scripts/ab.py epi bit 2): fetch per hit as in round 2
-    if (a.metric != METRIC_DOT && !late_invn) {
+    if (a.metric != METRIC_DOT) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) inv4[gq] = *(const f32x4_t*)(invn_s + rbase + 8 * gq);
     }
@@ -259,7 +261,7 @@ __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& 
                     const uint32_t rl = rbase + (uint32_t)((r & 3) + 8 * (r >> 2));
                     const uint32_t row = tile * (uint32_t)BM + rl;
                     if (row < a.n) {
-                        const float s = (a.metric == METRIC_DOT) ? av : av * (late_invn ? invn_s[rl] : inv4[gq][r4]) * iq;
+                        const float s = (a.metric == METRIC_DOT) ? av : av * inv4[gq][r4] * iq;
                         if (s > tau) {
                             const uint32_t p = lds_inc_rtn(&cntq[ql]);
                             if (p < CAND_CAPS)
@@ -283,7 +285,7 @@ __device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, 
 }
 
 // Fused top-k' epilogue of one corpus tile (shared by the coarse kernel variants).
-// Fast filter, BRANCH-FREE over all blocks of the wave tile: the maximum of each block's 16 scores (10 VALU) against a
+// Fast filter, BRANCH-FREE over all blocks of the wave tile: the maximum of each block's 16 scores (8 VALU) against a
 // conservative raw-accumulator threshold, the verdicts collected in a per-lane bit mask; one branch for the whole
 // tile, then the slow path of the flagged blocks only. (Round 1 branched per block: 8 - 16 short basic blocks per
 // tile, each a dependent chain with nothing to overlap; measured 43 % of the one-wave-per-SIMD fp8 kernel.)
@@ -397,7 +399,7 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
 
 // Emitting epilogue of the 8-wave bf16 / fp16 kernel with the conservative thresholds thr[mb][nb] PRECOMPUTED (the
 // kernel forms them in the MFMA gaps of the tile's last k-step, under matrix-pipe cover): what is left between the
-// last MFMA of a tile and the first of the next is, per 32 x 32 block, the maximum of the lane's 16 scores (10 VALU),
+// last MFMA of a tile and the first of the next is, per 32 x 32 block, the maximum of the lane's 16 scores (8 VALU),
 // one compare and a scalar OR of the compare mask - ~90 VALU per wave instead of ~200 (r03a clock ablation: the
 // epilogue cost 0.14 of the main launch's 1.17 ms while the matrix pipe sat idle in all 8 waves). Blocks are flagged
 // wave-wide: the slow path runs block_hits for every lane of a flagged block (lanes without a hit fall through its
@@ -438,7 +440,7 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
 // 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
 // EPI, the emitting epilogue: 1 (default) = the conservative thresholds are formed in the MFMA gaps of a tile's last
-// k-step, and each 32 x 32 block's filter (10 VALU maxima + one compare) sits right in front of the zero-C MFMA of the
+// k-step, and each 32 x 32 block's filter (8 VALU maxima + one compare) sits right in front of the zero-C MFMA of the
 // next tile's first k-step that overwrites the block - one wave's filter runs beside its SIMD partner's MFMA instead of
 // all 8 waves filtering while the matrix pipe idles. 0 = the round-2 form (everything at the tile boundary,
 // tile_epilogue), kept in the bf16 build as the A/B reference (scripts/ab.py knob `epi`). Measured r03c, C2 main

@@ -324,6 +324,7 @@ int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, 
     if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (n_devices == 0 || n_devices > 64 || !device_ids) return fail(CGV_ERR_INVALID_ARG, "n_devices must be 1..64 with a device list");
+    DeviceGuard guard;
     const int ndev = cgv_device_count();
     if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
     for (uint32_t g = 0; g < n_devices; ++g)
@@ -384,6 +385,7 @@ int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, 
 
 int cgv_sharded_destroy(cgv_sharded* s) {
     if (!s) return CGV_OK;
+    DeviceGuard guard;
     for (Shard* sh : s->sh) {
         if (sh->w.th.joinable()) {
             {
@@ -421,6 +423,7 @@ int cgv_sharded_destroy(cgv_sharded* s) {
 
 int cgv_sharded_reserve(cgv_sharded* s, uint64_t total_rows) {
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
     for (uint32_t g = 0; g < s->G; ++g) {
         const int rc = cgv_reserve(s->sh[g]->ix, shard_count(s, total_rows, g));
@@ -431,6 +434,7 @@ int cgv_sharded_reserve(cgv_sharded* s, uint64_t total_rows) {
 
 int cgv_sharded_add_f32(cgv_sharded* s, const float* rows_host, uint64_t n) {
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    DeviceGuard guard;
     if (n == 0) return CGV_OK;
     if (!rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     std::lock_guard<std::mutex> lk(s->mu);
@@ -494,6 +498,7 @@ int cgv_sharded_add_f32(cgv_sharded* s, const float* rows_host, uint64_t n) {
 
 int cgv_sharded_update_row_f32(cgv_sharded* s, uint64_t id, const float* row_host) {
     if (!s || !row_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
     if (id >= s->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     uint32_t g;
@@ -504,6 +509,7 @@ int cgv_sharded_update_row_f32(cgv_sharded* s, uint64_t id, const float* row_hos
 
 int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host) {
     if (!s || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
     if (id >= s->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     uint32_t g;
@@ -519,7 +525,12 @@ int cgv_sharded_exchange(const cgv_sharded* s) { return s ? s->exchange : CGV_EX
 
 int cgv_sharded_set_exchange(cgv_sharded* s, int kind) {
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
+    for (const auto& sl : s->slots)  // a batch in flight sized its buffers for the current exchange
+        if (sl.busy) return fail(CGV_ERR_BUSY, "a search is in flight: call cgv_sharded_search_end first");
+    if (kind == CGV_EXCHANGE_RCCL && s->rccl_broken)
+        return fail(CGV_ERR_HIP, "the handle's RCCL communicators were aborted after a failed collective");
     return set_exchange_locked(s, kind);
 }
 
