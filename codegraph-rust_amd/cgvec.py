@@ -345,6 +345,11 @@ class HipKnnIndex:
                                         idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return idx, sc
 
+    def search_host_ptr(self, q_ptr, nq, k, idx_ptr, score_ptr):
+        """cgv_search_f32 on raw HOST pointers (any mix of pinned and pageable buffers): the caller owns the memory."""
+        _check(lib().cgv_search_f32(self._h, C.c_void_p(int(q_ptr)), int(nq), int(k), C.c_void_p(int(idx_ptr)),
+                                    C.c_void_p(int(score_ptr))))
+
     OPS = {"cosine": 0, "dot": 1, "l2": 2, "cosine_seq": 3, "cosine_distance_seq": 4}
 
     def batch_similarity(self, query, op="cosine", limit_rows=0):

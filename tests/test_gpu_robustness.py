@@ -214,3 +214,58 @@ def test_fp8_magnitude_range_is_enforced(oracle):
         assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
     finally:
         ix.close()
+
+
+def test_pinned_host_buffers_are_used_in_place(oracle):
+    """cgv_search_f32 reads pinned query buffers and writes pinned result buffers directly; pageable
+    buffers go through staging. Every mix must give the oracle's answers - including the batches whose queries take
+    the exact-scan fallback (it writes into the caller's pinned arrays too), a non-finite query (error, index intact),
+    an f32 index (exact path only), and a registered (hipHostRegister) numpy buffer."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(91)
+    n, d, nq, k = 30_000, 256, 300, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[5000:5060] = rows[17] * (1 + 1e-4 * rng.standard_normal((60, 1)).astype(np.float32))   # a near-duplicate cluster
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[3] = rows[17]                                   # its query falls back to the exact scan
+    for dtype, odt in (("bf16", 1), ("f32", 0), ("f32s", 0)):
+        ix = m.HipKnnIndex(d, dtype=dtype)
+        try:
+            ix.add(rows)
+            ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+            qp = torch.from_numpy(q).pin_memory()
+            oi = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+            osc = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+            oi_pg = np.empty((nq, k), dtype=np.uint64)
+            os_pg = np.empty((nq, k), dtype=np.float32)
+            combos = [(qp.data_ptr(), oi.data_ptr(), osc.data_ptr(), lambda: (oi.numpy().view(np.uint64), osc.numpy())),
+                      (q.ctypes.data, oi.data_ptr(), osc.data_ptr(), lambda: (oi.numpy().view(np.uint64), osc.numpy())),
+                      (qp.data_ptr(), oi_pg.ctypes.data, os_pg.ctypes.data, lambda: (oi_pg, os_pg)),
+                      (qp.data_ptr(), oi.data_ptr(), os_pg.ctypes.data, lambda: (oi.numpy().view(np.uint64), os_pg))]
+            for qptr, iptr, sptr, get in combos:
+                oi.zero_(); osc.zero_(); oi_pg[:] = 0; os_pg[:] = 0
+                for _ in range(2):                    # twice: the flag words must come back clean for the second batch
+                    ix.search_host_ptr(qptr, nq, k, iptr, sptr)
+                gi, gs = get()
+                assert np.array_equal(gi, ri) and np.array_equal(gs, rs), dtype
+            if dtype == "bf16":
+                assert ix.stats()["fallback_queries"] >= 8     # the cluster's query, every time
+            bad = qp.clone().pin_memory()
+            bad[7, 5] = float("nan")
+            with pytest.raises(m.CgvError) as ei:
+                ix.search_host_ptr(bad.data_ptr(), nq, k, oi.data_ptr(), osc.data_ptr())
+            assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+            ix.search_host_ptr(qp.data_ptr(), nq, k, oi.data_ptr(), osc.data_ptr())     # and the index still answers
+            assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+            # registered pageable memory: the device alias may differ from the host address
+            rt = torch.cuda.cudart()
+            reg = np.ascontiguousarray(q.copy())
+            if hasattr(rt, "cudaHostRegister") and int(rt.cudaHostRegister(reg.ctypes.data, reg.nbytes, 0)) == 0:
+                try:
+                    ix.search_host_ptr(reg.ctypes.data, nq, k, oi.data_ptr(), osc.data_ptr())
+                    assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+                finally:
+                    rt.cudaHostUnregister(reg.ctypes.data)
+        finally:
+            ix.close()
