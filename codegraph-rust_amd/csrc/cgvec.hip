@@ -218,6 +218,7 @@ struct cgv_index {
     std::condition_variable cv;
     int profiling = 0;  // 0 off; 1 = HIP events around the dominant coarse launch; 2 = also around the whole pipeline
     bool force_exact = false;
+    bool wide_range = false;  // a stored row's magnitude is outside [2^-40, 2^40]: searches take the exact scan (kernels_prep.h)
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
     cgv_index() { memset(&st, 0, sizeof(st)); }
@@ -394,6 +395,10 @@ int ingest_finish(cgv_index* h, uint64_t n_new) {
     if (h->h_flags[F_NONFINITE_C] & 2u)
         return fail(CGV_ERR_INVALID_ARG,
                     "fp8 storage: a row's largest magnitude is outside [2^-48, 2^48]; the add was not applied");
+    if (h->h_flags[F_NONFINITE_C] & 4u) {  // sticky: the coarse pass' error bound does not cover such rows
+        h->wide_range = true;
+        HIPCHK(hipMemsetAsync(h->flags + F_NONFINITE_C, 0, 4, s));
+    }
     h->n = n_new;
     memcpy(&h->max_norm_c, h->h_flags + F_COUNT, 4);
     if (h->shadow) {
@@ -809,7 +814,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 
     // f32 + shadow: the coarse scores carry bf16 rounding error (~2e-3), so more candidates are re-scored
     const uint32_t kprime = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
-    const bool mfma = !h->force_exact && (h->dtype != CGV_DTYPE_F32 || h->shadow) && kprime <= CAND_CAPS &&
+    const bool mfma = !h->force_exact && !h->wide_range && (h->dtype != CGV_DTYPE_F32 || h->shadow) && kprime <= CAND_CAPS &&
                       (!h->shadow || k <= 60);
     c->mfma = mfma;
     c->kprime = mfma ? kprime : 0u;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
         e = fp8_row_exponent(amax);
         if (lane == 0) rexp[row0 + row] = (int8_t)e;
     }
-    float ss = 0.0f;
+    float ss = 0.0f, amx = 0.0f;
     int bad = 0;
     if (DT == DT_FP8 && (e < FP8_EXP_MIN || e > FP8_EXP_MAX)) bad = 2;  // magnitude outside the supported range (common.h)
     const uint64_t R = row0 + row;
@@ -110,21 +110,31 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < EPP; ++t) {
             if (!(fabsf(x[t]) <= 3.402823466e38f)) bad |= 1;  // NaN or Inf
+            amx = fmaxf(amx, fabsf(x[t]));
             if (DT == DT_FP8) x[t] = ldexpf(x[t], e);          // exact
             const float xr = Elem<DT>::round_trip(x[t]);
             ss = fmaf(xr, xr, ss);
         }
         *(uint4*)(obase + ((DT == DT_F32) ? (uint64_t)pc * 16 : blocked_piece_off(pc, key))) = pack_piece<DT>(x);
     }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+    }
+    // The MFMA coarse pass and its error bound assume no underflow / overflow in the squared norms and in the products
+    // (DESIGN.md §5.3): a row whose largest magnitude lies outside [2^-40, 2^40] (and is not all zero) is answered by the
+    // exact scan instead - bit 2 of the flag word (corpus: the index leaves the fast path; queries: zero1[row] = 1
+    // sends THAT query through the exact scan, see rescore_body's `overflow`).
+    const bool wide = amx != 0.0f && (amx < 9.094947017729282e-13f || amx > 1.099511627776e12f) && DT != DT_FP8;
     if (lane == 0) {
+        if (wide && zero1) zero1[row0 + row] = 1u;
         const float nr = sqrtf(ss);
         // fp8: the coarse kernel applies the rows' scales inside the MFMA (kernels_coarse_fp8.h), so its accumulators -
         // and therefore these norms - live in the DE-SCALED domain: norm * 2^-e, (1 / norm) * 2^e, both exact
         norm[row0 + row] = (DT == DT_FP8) ? ldexpf(nr, -e) : nr;
         invn[row0 + row] = nr > 0.0f ? ((DT == DT_FP8) ? ldexpf(1.0f / nr, e) : 1.0f / nr) : 0.0f;
     }
-    const uint32_t bits = (__any(bad & 1) ? 1u : 0u) | (__any(bad & 2) ? 2u : 0u);
+    const uint32_t bits = (__any(bad & 1) ? 1u : 0u) | (__any(bad & 2) ? 2u : 0u) | (wide ? 4u : 0u);
     if (bits && lane == 0) atomicOr(nonfinite, bits);
 }
 

@@ -50,7 +50,10 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_METRIC_COSINE_SEQ 2 /* the sequential dot/(sqrt(na)*sqrt(nb)) cosine of SemanticSearch (search.rs:519-533)
                                   and of the symbol resolver (crates/codegraph-mcp/src/indexer.rs:2965-2979) */
 
-/* storage dtype of the corpus in HBM (queries are rounded to the same dtype) */
+/* storage dtype of the corpus in HBM (queries are rounded to the same dtype). Results never depend on magnitudes; speed
+ * can: rows / queries whose largest magnitude is outside [2^-40, 2^40] (embeddings never are) are answered by the exact scan
+ * - such a query alone, such a stored row for the whole index - because the MFMA coarse pass' error bound assumes no
+ * under- / overflow in squared norms and products. */
 #define CGV_DTYPE_F32 0     /* the reference's own Vec<f32> (node.rs:14) */
 #define CGV_DTYPE_BF16 1
 #define CGV_DTYPE_FP16 2
