@@ -264,9 +264,9 @@ def main():
         ev_x0, ev_x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         exchange_ms = []
 
-        def step(i):   # every rank: H2D of the (replicated) batch, shard search, all-gather + merge, D2H
-            q = qhost[i % npool].to(dev, non_blocking=True)
-            li, ls = ix.search(q, k)                  # this rank's shard (ids already global)
+        def step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link, shard search,
+            #                all-gather + merge, D2H
+            li, ls = ix.search_from_pinned(qhost[i % npool], k)   # this rank's shard (ids already global)
             ev_x0.record()
             gi, gs = searcher._exchange(li, ls, k)    # ONE RCCL all-gather of packed records + merge kernel
             ev_x1.record()

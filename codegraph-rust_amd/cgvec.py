@@ -345,6 +345,25 @@ class HipKnnIndex:
                                         idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return idx, sc
 
+    def search_from_pinned(self, q_pinned, k):
+        """Pinned HOST queries (a torch CPU tensor in pinned memory) -> (idx, score) CUDA tensors: the conversion kernel
+        reads the batch over PCIe in place (no separate H2D copy); what a rank of the row-sharded deployment does before
+        the exchange of its partial top-k."""
+        import torch
+        if not (_is_torch(q_pinned) and not q_pinned.is_cuda and q_pinned.is_pinned()):
+            raise CgvError(CGV_ERR_INVALID_ARG, "search_from_pinned takes a pinned CPU tensor")
+        if q_pinned.dim() != 2 or q_pinned.shape[1] != self.dim or q_pinned.dtype != torch.float32 or not q_pinned.is_contiguous():
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query batch {tuple(q_pinned.shape)} {q_pinned.dtype} != [nq, {self.dim}] f32")
+        nq, k = q_pinned.shape[0], int(k)
+        dev = torch.device("cuda", self.device)
+        self.use_torch_stream()
+        idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        if nq and k:
+            _check(lib().cgv_search_f32_dev(self._h, C.c_void_p(q_pinned.data_ptr()), nq, k,
+                                            C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr())))
+        return idx, sc
+
     def search_host_ptr(self, q_ptr, nq, k, idx_ptr, score_ptr):
         """cgv_search_f32 on raw HOST pointers (any mix of pinned and pageable buffers): the caller owns the memory."""
         _check(lib().cgv_search_f32(self._h, C.c_void_p(int(q_ptr)), int(nq), int(k), C.c_void_p(int(idx_ptr)),

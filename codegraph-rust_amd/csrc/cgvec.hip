@@ -1177,7 +1177,7 @@ int order_after_caller(cgv_index* h, SearchCtx* c) {
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 3u; }
+uint32_t cgv_version(void) { return (0u << 16) | 4u; }
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }

@@ -83,7 +83,8 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_MAX_K 2048u
 #define CGV_FAST_MAX_K 228u
 
-/* Library/ABI version (major<<16 | minor). */
+/* Library/ABI version (major<<16 | minor). Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
+ * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. */
 uint32_t cgv_version(void);
 
 /* Thread-local message for the last failing call on this thread ("" if none). */
@@ -141,7 +142,10 @@ int cgv_truncate(cgv_index* h, uint64_t n_rows);
  * Replaces: ParallelVectorOps::parallel_top_k_search (simd_ops.rs:361-383) per query;
  * SurrealVectorBackend::vector_knn (surreal_store.rs:14-20) — the shim reports
  * distance = 1 - score; and the N-independent-searches batch of
- * SemanticSearch::multi_vector_search (search.rs:358-361). */
+ * SemanticSearch::multi_vector_search (search.rs:358-361).
+ * Buffers in pinned memory (hipHostMalloc / hipHostRegister) are used IN PLACE: the conversion kernel reads the
+ * queries over PCIe and the last kernel writes the results (no staging copies); pageable buffers are staged by the
+ * library. On a non-zero status the out arrays are unspecified (they may already have been written). */
 int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k,
                    uint64_t* out_idx_host, float* out_score_host);
 

@@ -258,6 +258,9 @@ def test_pinned_host_buffers_are_used_in_place(oracle):
             assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
             ix.search_host_ptr(qp.data_ptr(), nq, k, oi.data_ptr(), osc.data_ptr())     # and the index still answers
             assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+            # pinned queries in, DEVICE results out (what a rank of the row-sharded deployment does before the exchange)
+            di, ds = ix.search_from_pinned(qp, k)
+            assert np.array_equal(di.cpu().numpy().view(np.uint64), ri) and np.array_equal(ds.cpu().numpy(), rs)
             # registered pageable memory: the device alias may differ from the host address
             rt = torch.cuda.cudart()
             reg = np.ascontiguousarray(q.copy())
