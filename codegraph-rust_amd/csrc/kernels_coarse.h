@@ -240,15 +240,6 @@ __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& 
     // rows): hoisted, they were 16 64-bit additions per tile on the path every block takes
     uint32_t rbase = rl0 + 4u * (uint32_t)(lane >> 5);
     asm volatile("" : "+v"(rbase));
-    // The inverse norms of the lane's 16 rows (4 runs of 4 consecutive rows) are fetched up front, 4 x 16 bytes from
-    // the LDS ring (a vector GLOBAL load here would need s_waitcnt vmcnt(0), i.e. wait for the next chunk's DMA): they
-    // land while the group maxima are tested, so a hit no longer pays an LDS round trip of its own before the list
-    // counter's (round 3: -0.4 % on the C2 step, -0.7 % on a hit-heavy single-launch plan, profiles/r03f_ab.txt).
-    f32x4_t inv4[4];
-    if (a.metric != METRIC_DOT) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) inv4[gq] = *(const f32x4_t*)(invn_s + rbase + 8 * gq);
-    }
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         // the group maximum skips four compares at a time
@@ -261,7 +252,11 @@ __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& 
                     const uint32_t rl = rbase + (uint32_t)((r & 3) + 8 * (r >> 2));
                     const uint32_t row = tile * (uint32_t)BM + rl;
                     if (row < a.n) {
-                        const float s = (a.metric == METRIC_DOT) ? av : av * inv4[gq][r4] * iq;
+                        // inverse norm from LDS: a vector global load here would need
+                        // s_waitcnt vmcnt(0), i.e. wait for the next chunk's DMA. (Fetching all 16 of the lane's inverse
+                        // norms up front - 4 x 16 bytes at the top of this path - measured -0.4 % on the C2 step at the price
+                        // of 16 more VGPRs in the kernel: not kept, profiles/r03f_ab.txt.)
+                        const float s = (a.metric == METRIC_DOT) ? av : av * invn_s[rl] * iq;
                         if (s > tau) {
                             const uint32_t p = lds_inc_rtn(&cntq[ql]);
                             if (p < CAND_CAPS)

@@ -518,6 +518,45 @@ int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host) {
     return cgv_get_row_f32(s->sh[g]->ix, local, out_host);
 }
 
+// cgv_score_ids_f32 over the shards: every (query, id) pair is scored on the shard that owns the row (global id ->
+// shard, local row: locate()), all shards in parallel, one device launch each.
+int cgv_sharded_score_ids_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host,
+                              uint32_t m, float* out_host) {
+    if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || m == 0) return CGV_OK;
+    if (!queries_host || !ids_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    DeviceGuard guard;
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t pairs = (size_t)nq * m;
+    std::vector<std::vector<uint64_t>> local(s->G, std::vector<uint64_t>(pairs, UINT64_MAX));
+    std::vector<uint8_t> owner(pairs, 0xff);
+    std::vector<char> used(s->G, 0);
+    for (size_t i = 0; i < pairs; ++i) {
+        const uint64_t id = ids_host[i];
+        if (id >= s->n) continue;  // UINT64_MAX or beyond the index: scores 0.0 (a missing embedding, search.rs:207-217)
+        uint32_t g;
+        uint64_t l;
+        locate(s, id, &g, &l);
+        local[g][i] = l;
+        owner[i] = (uint8_t)g;
+        used[g] = 1;
+    }
+    std::vector<std::vector<float>> part(s->G);
+    std::vector<std::function<int()>> jobs(s->G);
+    for (uint32_t g = 0; g < s->G; ++g) {
+        if (!used[g]) continue;
+        part[g].assign(pairs, 0.0f);
+        Shard* sh = s->sh[g];
+        const uint64_t* lp = local[g].data();
+        float* op_out = part[g].data();
+        jobs[g] = [=]() -> int { return cgv_score_ids_f32(sh->ix, queries_host, nq, op, lp, m, op_out); };
+    }
+    const int rc = run_all(s, jobs);
+    if (rc) return rc;
+    for (size_t i = 0; i < pairs; ++i) out_host[i] = owner[i] == 0xff ? 0.0f : part[owner[i]][i];
+    return CGV_OK;
+}
+
 uint64_t cgv_sharded_count(const cgv_sharded* s) { return s ? s->n : 0; }
 uint32_t cgv_sharded_n_shards(const cgv_sharded* s) { return s ? s->G : 0; }
 cgv_index* cgv_sharded_shard(cgv_sharded* s, uint32_t i) { return (s && i < s->G) ? s->sh[i]->ix : nullptr; }

@@ -224,8 +224,14 @@ struct SurrealVectorBackend {
 class HipKnnBackend : public SurrealVectorBackend {
    public:
     HipKnnBackend(int dtype, int device) : dtype_(dtype), device_(device) {}
+    // ONE backend object over several GPUs (the seam holds a single Arc<dyn SurrealVectorBackend>, surreal_store.rs:11-22,
+    // 32-34): every embedding column is a cgv_sharded handle (block-cyclic row shards, one exchange per search)
+    HipKnnBackend(int dtype, std::vector<int> devices) : dtype_(dtype), device_(devices.empty() ? 0 : devices[0]), devices_(std::move(devices)) {}
     ~HipKnnBackend() override {
-        for (auto& kv : cols_) cgv_destroy(kv.second.h);
+        for (auto& kv : cols_) {
+            if (kv.second.sh) cgv_sharded_destroy(kv.second.sh);
+            if (kv.second.h) cgv_destroy(kv.second.h);
+        }
     }
     int upsert_nodes(const std::vector<Node>& nodes) override {
         // group appended rows per column so that each column gets one cgv_add_f32
@@ -239,7 +245,7 @@ class HipKnnBackend : public SurrealVectorBackend {
             if (c->dim != n.dim) return fail(CGV_ERR_DIM_MISMATCH, "embedding dimension does not match column " + col);
             auto it = c->row_of.find(n.id);
             if (it != c->row_of.end()) {  // UPSERT of a known id: rewrite the stored row in place
-                if ((rc = cgv_update_row_f32(c->h, it->second, n.embedding))) return rc;
+                if ((rc = c->sh ? cgv_sharded_update_row_f32(c->sh, it->second, n.embedding) : cgv_update_row_f32(c->h, it->second, n.embedding))) return rc;
             } else {
                 fresh[col].push_back(&n);
             }
@@ -262,7 +268,7 @@ class HipKnnBackend : public SurrealVectorBackend {
             }
             // cgv_add_f32 is all-or-nothing (a rejected batch leaves the device index untouched), so on
             // failure only this batch's id entries are dropped and rows / ids stay aligned
-            int rc = cgv_add_f32(c.h, flat.data(), ids.size());
+            int rc = c.sh ? cgv_sharded_add_f32(c.sh, flat.data(), ids.size()) : cgv_add_f32(c.h, flat.data(), ids.size());
             if (rc) {
                 for (auto& id : ids) c.row_of.erase(id);
                 return rc;
@@ -289,14 +295,15 @@ class HipKnnBackend : public SurrealVectorBackend {
         if (dim != c.dim) return fail(CGV_ERR_DIM_MISMATCH, "query dimension " + std::to_string(dim) + " != column " + column_name);
         // a search cannot return more neighbours than the column holds; beyond CGV_MAX_K the request is an
         // error, never a silent truncation (k <= CGV_FAST_MAX_K: MFMA path; larger: exact scan on the device)
-        const size_t k = std::min<size_t>(limit, (size_t)cgv_count(c.h));
+        const size_t k = std::min<size_t>(limit, (size_t)(c.sh ? cgv_sharded_count(c.sh) : cgv_count(c.h)));
         if (k == 0) return CGV_OK;
         if (k > CGV_MAX_K)
             return fail(CGV_ERR_INVALID_ARG, "vector_knn: limit " + std::to_string(limit) + " exceeds CGV_MAX_K (" +
                                                  std::to_string(CGV_MAX_K) + ") neighbours per query");
         std::vector<uint64_t> idx(nq * k);
         std::vector<float> sc(nq * k);
-        int rc = cgv_search_f32(c.h, queries, (uint32_t)nq, (uint32_t)k, idx.data(), sc.data());
+        int rc = c.sh ? cgv_sharded_search_f32(c.sh, queries, (uint32_t)nq, (uint32_t)k, idx.data(), sc.data())
+                      : cgv_search_f32(c.h, queries, (uint32_t)nq, (uint32_t)k, idx.data(), sc.data());
         if (rc) return rc;
         for (size_t q = 0; q < nq; ++q)
             for (size_t j = 0; j < k; ++j) {
@@ -328,7 +335,8 @@ class HipKnnBackend : public SurrealVectorBackend {
                 }
         std::vector<float> out(nq * m, 0.0f);
         if (c) {
-            int rc = cgv_score_ids_f32(c->h, queries, (uint32_t)nq, CGV_OP_COSINE_SEQ, rows.data(), (uint32_t)m, out.data());
+            int rc = c->sh ? cgv_sharded_score_ids_f32(c->sh, queries, (uint32_t)nq, CGV_OP_COSINE_SEQ, rows.data(), (uint32_t)m, out.data())
+                           : cgv_score_ids_f32(c->h, queries, (uint32_t)nq, CGV_OP_COSINE_SEQ, rows.data(), (uint32_t)m, out.data());
             if (rc) return rc;
         }
         for (size_t q = 0; q < nq; ++q) scores[q].assign(out.begin() + q * m, out.begin() + q * m + ids[q].size());
@@ -340,7 +348,8 @@ class HipKnnBackend : public SurrealVectorBackend {
             auto it = kv.second.row_of.find(id);
             if (it == kv.second.row_of.end()) continue;
             out.resize(kv.second.dim);
-            int rc = cgv_get_row_f32(kv.second.h, it->second, out.data());
+            int rc = kv.second.sh ? cgv_sharded_get_row_f32(kv.second.sh, it->second, out.data())
+                                  : cgv_get_row_f32(kv.second.h, it->second, out.data());
             if (rc) return rc;
             found = true;
             return CGV_OK;
@@ -350,7 +359,8 @@ class HipKnnBackend : public SurrealVectorBackend {
 
    private:
     struct Column {
-        cgv_index* h = nullptr;
+        cgv_index* h = nullptr;     // one device ...
+        cgv_sharded* sh = nullptr;  // ... or one handle over several
         uint32_t dim = 0;
         std::vector<NodeId> ids;                                  // row -> NodeId
         std::unordered_map<NodeId, uint64_t, NodeIdHash> row_of;  // NodeId -> row
@@ -360,7 +370,8 @@ class HipKnnBackend : public SurrealVectorBackend {
         if (it == cols_.end()) {
             Column c;
             c.dim = dim;
-            int rc = cgv_create(dim, CGV_METRIC_COSINE, dtype_, device_, &c.h);
+            int rc = devices_.empty() ? cgv_create(dim, CGV_METRIC_COSINE, dtype_, device_, &c.h)
+                                      : cgv_sharded_create(dim, CGV_METRIC_COSINE, dtype_, (uint32_t)devices_.size(), devices_.data(), &c.sh);
             if (rc) return rc;
             it = cols_.emplace(name, std::move(c)).first;
         }
@@ -368,6 +379,7 @@ class HipKnnBackend : public SurrealVectorBackend {
         return CGV_OK;
     }
     int dtype_, device_;
+    std::vector<int> devices_;  // non-empty: sharded columns
     std::map<std::string, Column> cols_;
 };
 
@@ -576,6 +588,24 @@ int cgvs_store_create(int dtype, int device_id, uint32_t ef_search, cgvs_store**
         return fail(CGV_ERR_INVALID_ARG, "bad dtype (f32, bf16, fp16, fp8e4m3, f32 + bf16 shadow)");
     cgvs_store* s = new cgvs_store();
     s->backend.reset(new HipKnnBackend(dtype, device_id));
+    s->ef_search = ef_search;
+    *out = s;
+    return CGV_OK;
+}
+
+int cgvs_store_create_sharded(int dtype, uint32_t n_devices, const int* device_ids, uint32_t ef_search, cgvs_store** out) {
+    if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_devices == 0 || n_devices > 64 || !device_ids) return fail(CGV_ERR_INVALID_ARG, "n_devices must be 1..64 with a device list");
+    const int ndev = cgv_device_count();
+    if (ndev == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+    for (uint32_t i = 0; i < n_devices; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(CGV_ERR_INVALID_ARG, "device id out of range");
+    if (dtype != CGV_DTYPE_F32 && dtype != CGV_DTYPE_BF16 && dtype != CGV_DTYPE_FP16 && dtype != CGV_DTYPE_FP8E4M3 &&
+        dtype != CGV_DTYPE_F32_SHADOW)
+        return fail(CGV_ERR_INVALID_ARG, "bad dtype (f32, bf16, fp16, fp8e4m3, f32 + bf16 shadow)");
+    cgvs_store* s = new cgvs_store();
+    s->backend.reset(new HipKnnBackend(dtype, std::vector<int>(device_ids, device_ids + n_devices)));
     s->ef_search = ef_search;
     *out = s;
     return CGV_OK;

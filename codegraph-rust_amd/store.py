@@ -27,6 +27,7 @@ def _lib():
     if not _bound:
         vp, u32 = C.c_void_p, C.c_uint32
         L.cgvs_store_create.argtypes = [C.c_int, C.c_int, u32, C.POINTER(vp)]
+        L.cgvs_store_create_sharded.argtypes = [C.c_int, u32, C.POINTER(C.c_int), u32, C.POINTER(vp)]
         L.cgvs_store_create_mock.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32, u32, C.POINTER(vp)]
         L.cgvs_mock_recorded_columns.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.cgvs_store_destroy.argtypes = [vp]
@@ -106,10 +107,14 @@ def _filters(f):
 class VectorStore:
     """SurrealVectorStore + SemanticSearch mirror. NodeIds are uuid.UUID."""
 
-    def __init__(self, dtype="bf16", device=0, ef_search=100, _mock=None):
+    def __init__(self, dtype="bf16", device=0, ef_search=100, _mock=None, devices=None):
+        """devices = [d0, d1, ...]: ONE store over several GPUs (cgvs_store_create_sharded; a device may repeat)."""
         self._h = C.c_void_p()
         L = _lib()
-        if _mock is not None:
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(L.cgvs_store_create_sharded(cgvec.DTYPES[dtype], len(devices), devs, ef_search, C.byref(self._h)))
+        elif _mock is not None:
             ids = _cstrs([m[0] for m in _mock])
             d = (C.c_float * max(len(_mock), 1))(*[m[1] for m in _mock])
             _check(L.cgvs_store_create_mock(C.cast(ids, C.POINTER(C.c_char_p)), d, len(_mock), ef_search, C.byref(self._h)))

@@ -319,6 +319,9 @@ int cgv_sharded_reserve(cgv_sharded* s, uint64_t total_rows);
 int cgv_sharded_add_f32(cgv_sharded* s, const float* rows_host, uint64_t n);
 int cgv_sharded_update_row_f32(cgv_sharded* s, uint64_t id, const float* row_host);
 int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host);
+/* cgv_score_ids_f32 with GLOBAL row ids: each pair is scored on the shard that owns the row. */
+int cgv_sharded_score_ids_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host,
+                              uint32_t m, float* out_host);
 uint64_t cgv_sharded_count(const cgv_sharded* s);
 uint32_t cgv_sharded_n_shards(const cgv_sharded* s);
 /* Borrowed handle of shard i (statistics, profiling switches); do not add to / destroy it. */

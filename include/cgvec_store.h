@@ -52,6 +52,11 @@ typedef struct cgvs_filters {
 /* SurrealVectorStore::new(Arc<HipKnnBackend>, ef_search) (surreal_store.rs:32-34): a store over
  * the HIP kNN backend; one device index per embedding column, created on first upsert. */
 int cgvs_store_create(int dtype, int device_id, uint32_t ef_search, cgvs_store** out);
+/* The same store over SEVERAL GPUs of the node: the seam holds ONE backend object (Arc<dyn SurrealVectorBackend>), so
+ * that object owns all shards - every embedding column is a cgv_sharded handle (cgvec.h: rows dealt block-cyclically,
+ * per-shard top-k exchanged once per search with RCCL / peer copies, merged on the first device). Everything above the
+ * backend (UPSERT, id map, columns, SemanticSearch surface) is unchanged; a device may be listed more than once. */
+int cgvs_store_create_sharded(int dtype, uint32_t n_devices, const int* device_ids, uint32_t ef_search, cgvs_store** out);
 
 /* The reference's own seam test backend (surreal_store.rs:167-205 MockBackend): vector_knn
  * returns the canned (id, distance) list and records the column it was asked for. No GPU. */

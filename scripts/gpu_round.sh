@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=${1:-round}; VARIANTS=${2:-}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 900 2>&1 | tail -12 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+timeout 1500 python -X faulthandler -m pytest tests -m gpu -v --tb=short -p no:cacheprovider --timeout 900 > $O/pytest_gpu_full.txt 2>&1; tail -15 $O/pytest_gpu_full.txt | cut -c1-200; grep -c PASSED $O/pytest_gpu_full.txt
 for wl in c2 c4 c3shard c5mini c2f32 c2shard8; do
   timeout 400 python bench.py --workload $wl --cpu-seconds 0 2>$O/bench_$wl.err | tail -1 > $O/${wl}_bench.json
   python - <<PY

@@ -272,3 +272,40 @@ def test_rejected_upsert_leaves_store_consistent(oracle):
     assert np.array_equal(st.get_embedding(new_ids[2]), oracle.round_trip(good[2], 1))
     assert st.search_similar(good[2], 1) == [new_ids[2]]
     st.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32s"])
+def test_store_over_several_shards_equals_the_single_device_store(oracle, dtype):
+    """cgvs_store_create_sharded: ONE backend object over several GPUs (the seam holds a single
+    Arc<dyn SurrealVectorBackend>, surreal_store.rs:11-22). Every call of the store surface - upsert in batches,
+    vector_knn, search_similar, search_by_embedding (per-hit re-score through cgv_sharded_score_ids_f32),
+    multi_vector_search, get_embedding, UPSERT of a known id - must return exactly what the one-device store returns
+    (devices i % device_count: a 1-GPU box lists device 0 three times)."""
+    m = pkg()
+    nd = m.device_count()
+    rng = np.random.default_rng(17)
+    n, d = 3 * 4096 + 500, 384                      # rows over several block-cyclic chunks of every shard
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    ids = [uuid.UUID(int=int(rng.integers(1, 2**62)) * 4 + i) for i in range(n)]
+    one = m.store.VectorStore(dtype=dtype)
+    many = m.store.VectorStore(dtype=dtype, devices=[i % nd for i in range(3)])
+    try:
+        for st in (one, many):
+            for lo in range(0, n, 5000):
+                st.store_embeddings(ids[lo: lo + 5000], rows[lo: lo + 5000])
+        qs = rng.standard_normal((5, d)).astype(np.float32)
+        for q in qs:
+            assert many.search_similar(q, 15) == one.search_similar(q, 15)
+            assert many.vector_knn("embedding_384", q, 15) == one.vector_knn("embedding_384", q, 15)
+            assert many.search_by_embedding(q, 7) == one.search_by_embedding(q, 7)
+        assert many.multi_vector_search(qs, m.store.OR_MAX, None, 9) == one.multi_vector_search(qs, m.store.OR_MAX, None, 9)
+        for i in (0, 4095, 4096, 9000, n - 1):
+            assert np.array_equal(many.get_embedding(ids[i]), one.get_embedding(ids[i]))
+        for st in (one, many):                       # UPSERT of a known id: found once, by its new embedding
+            st.store_embeddings([ids[9000]], qs[:1] * np.float32(3.0))
+        assert many.search_similar(qs[0], 5) == one.search_similar(qs[0], 5)
+        assert many.search_similar(qs[0], 5)[0] == ids[9000]
+        assert many.vector_knn("embedding_384", qs[0], 5) == one.vector_knn("embedding_384", qs[0], 5)
+    finally:
+        one.close()
+        many.close()
