@@ -1,3 +1,7 @@
 #!/bin/bash
+# the -m gpu suite, verbose, with the full log kept (gpurun_out/pytest_gpu_full.txt): a crash names its test
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 2>&1 | tail -30
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+cd $R
+timeout 1700 python -X faulthandler -m pytest tests -m gpu -v --tb=short -p no:cacheprovider --timeout 900 ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu_full.txt 2>&1
+echo "rc=$?"; tail -25 gpurun_out/pytest_gpu_full.txt | cut -c1-220; echo "passed: $(grep -c PASSED gpurun_out/pytest_gpu_full.txt)"
