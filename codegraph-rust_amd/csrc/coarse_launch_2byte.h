@@ -31,6 +31,8 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_DUMP>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_SAMPLE>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
     return CGV_OK;
 }
 
@@ -74,10 +76,19 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
             return coarse_hip_status("coarse_kernel (epi 0)");
         }
     }
-    // every corpus tile read by exactly ONE workgroup (a single query tile per XCD group): stream it non-temporally
-    if (a.nqt == 1 && (a.epi & 2u) == 0) {
-        auto kn = coarse_kernel<DT, COARSE_EMIT, 0, 1, true>;
-        hipLaunchKernelGGL(kn, dim3(W), dim3(512), lds, s, a);
+    // every corpus tile read by exactly ONE workgroup (a single query tile per XCD group): stream it non-temporally;
+    // static issue side when a tile has >= 4 K chunks (epi bit 3 = the dynamic form, for A/B)
+    const bool nt = a.nqt == 1 && (a.epi & 2u) == 0, si = a.kc >= 4 && (a.epi & 8u) == 0;
+    if (nt && si) {
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (nt, si)");
+    }
+    if (si) {
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (si)");
+    }
+    if (nt) {
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (nt)");
     }
     hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);

@@ -442,7 +442,12 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // launch: 1.070 -> 1.049 ms (EPI 0 -> 1); thresholds in the gaps alone, with the filter left at the boundary: 1.070.
 // NTA: the corpus (A operand) DMA carries the non-temporal hint - for launches in which every corpus tile is read by
 // exactly one workgroup (one query tile per XCD group: C4).
-template <int DT, int MODE, int ABL = 0, int EPI = 1, bool NTA = false>
+// SI, static issue side (needs KC >= 4): the DMA stream runs exactly three stages ahead of the MFMAs, so WHERE it crosses into
+// the next tile is known per loop iteration (the one with kc + 3 == KC) - no per-stage "stages left?" / "chunk == KC?" scalar
+// tests, no 64-bit chunk offset: the ring position and the chunk offset are two running scalars. Past its last tile the stream
+// simply runs on into the next tile of the visiting order (valid corpus memory) instead of re-reading the last stage. ~8 fewer
+// SALU per stage of ~100 instructions per SIMD - the stage loop sits at the issue limit of ~5 fillers per MFMA gap.
+template <int DT, int MODE, int ABL = 0, int EPI = 1, bool NTA = false, int SI = 0>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -536,7 +541,31 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
 #define CGV_BDMA_A(RS, DST, IMM) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, NTA ? 2 : 0)
+    uint32_t si_slot = 0;                              // SI: ring position in bytes (stage count x STAGE, masked on use)
+    uint32_t si_so = (uint32_t)wave * 2048u;           // SI: chunk offset within the tile + this wave's 2 KiB slab
+    auto issue_switch_tile = [&]() {                   // SI: the issue side enters the next tile of the visiting order
+        lt = next_tile(lt);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff,
+                                                0x00020000);
+        si_so = (uint32_t)wave * 2048u;
+    };
     auto issue_q = [&](int q) {
+        if constexpr (SI != 0) {
+            if (q == 0) {
+                d_dst = smem + (si_slot & (uint32_t)(NSTAGE * STAGE - 1)) + wave * 2048;
+                d_so = si_so;
+                CGV_BDMA_A(rsA, d_dst, 0);
+            } else if (q == 1) {
+                CGV_BDMA_A(rsA, d_dst, 1024);
+            } else if (q == 2) {
+                CGV_BDMA(rsB, d_dst + A_BYTES, 0);
+            } else {
+                CGV_BDMA(rsB, d_dst + A_BYTES, 1024);
+                si_slot += (uint32_t)STAGE;
+                si_so += BLOCK_BYTES;
+            }
+            return;
+        }
         if ((ABL & 2) || ((ABL & 64) && issued >= (uint32_t)NSTAGE)) {
             if (q == 3) ++issued;
             return;
@@ -775,6 +804,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #pragma unroll 1
     for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
         const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+        if (SI != 0 && kc + 3 == KC) issue_switch_tile();  // this iteration issues stage kc + 3 = the next tile's first
         CGV_B_PHASE(sb);
         CGV_A_PHASE(sb);
     }
@@ -808,6 +838,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #pragma unroll 1
         for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
             const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            if (SI != 0 && kc + 3 == KC) issue_switch_tile();
             CGV_B_PHASE(sb);
             CGV_A_PHASE(sb);
         }
