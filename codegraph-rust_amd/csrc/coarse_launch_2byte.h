@@ -33,6 +33,8 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>))) return rc;
     return CGV_OK;
 }
 
@@ -77,8 +79,17 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         }
     }
     // every corpus tile read by exactly ONE workgroup (a single query tile per XCD group): stream it non-temporally;
-    // static issue side when a tile has >= 4 K chunks (epi bit 3 = the dynamic form, for A/B)
+    // static issue side when a tile has >= 4 K chunks (epi bit 3 = the dynamic form, for A/B); with a multiple of 4 chunks
+    // the stage loop unrolled by the ring size, LDS addresses as immediates (epi bit 4 = the rolled form, for A/B)
     const bool nt = a.nqt == 1 && (a.epi & 2u) == 0, si = a.kc >= 4 && (a.epi & 8u) == 0;
+    const bool u4 = si && a.kc % 4 == 0 && (a.epi & 16u) == 0;
+    if (u4) {
+        if (nt)
+            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
+        else
+            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (si, ring-unrolled)");
+    }
     if (nt && si) {
         hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (nt, si)");

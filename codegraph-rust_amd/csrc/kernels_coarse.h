@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 CGV_BDMA(rsB, d_dst + A_BYTES, 0);
             } else {
                 CGV_BDMA(rsB, d_dst + A_BYTES, 1024);
-                si_slot += (uint32_t)STAGE;
+                if (SI == 1) si_slot += (uint32_t)STAGE;   // SI == 2: set by the (unrolled) caller, a constant per iteration
                 si_so += BLOCK_BYTES;
             }
             return;
@@ -761,6 +761,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     issue_side(t_first, 0);
 #pragma unroll 1
     for (int i = 0; i < NSTAGE - 1; ++i) {
+        if (SI == 2) si_slot = (uint32_t)(i * STAGE);
         issue_q(0);
         issue_q(1);
         issue_q(2);
@@ -798,20 +799,46 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // boundary the iteration is B phase (last k-step of the previous tile), its epilogue, zero-C A phase.
     const uint32_t ntl = jhi - jlo;
     uint32_t ct = t_first, s = 1;
+    if (SI == 2) si_slot = (uint32_t)(3 * STAGE);
     issue_q(0);  // stage 3 -> slot 3 (never used so far)
     issue_q(1);
     CGV_A_PHASE_Z(smem);
+    // SI == 2 (KC % 4 == 0): every tile starts in ring slot 0, so the stage loop unrolled by the ring size has its LDS
+    // addresses (fragment reads: lane base + immediate; DMA: wave base + constant) fixed per unrolled iteration
+#define CGV_ITER_AT(SLOT)                                                         \
+    {                                                                             \
+        const char* sbc = smem + (SLOT) * STAGE;                                  \
+        si_slot = (uint32_t)((((SLOT) + 3) & (NSTAGE - 1)) * STAGE);              \
+        CGV_B_PHASE(sbc);                                                         \
+        CGV_A_PHASE(sbc);                                                         \
+    }
+#define CGV_TILE_REST_U4                                                          \
+    {                                                                             \
+        const uint32_t ng = KC >> 2;                                              \
+        if (ng == 1) issue_switch_tile();                                         \
+        CGV_ITER_AT(1) CGV_ITER_AT(2) CGV_ITER_AT(3)                              \
+        _Pragma("unroll 1") for (uint32_t gi = 1; gi < ng; ++gi) {                \
+            CGV_ITER_AT(0)                                                        \
+            if (gi + 1 == ng) issue_switch_tile();                                \
+            CGV_ITER_AT(1) CGV_ITER_AT(2) CGV_ITER_AT(3)                          \
+        }                                                                         \
+    }
+    if constexpr (SI == 2) {
+        CGV_TILE_REST_U4
+    } else {
 #pragma unroll 1
-    for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
-        const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-        if (SI != 0 && kc + 3 == KC) issue_switch_tile();  // this iteration issues stage kc + 3 = the next tile's first
-        CGV_B_PHASE(sb);
-        CGV_A_PHASE(sb);
+        for (uint32_t kc = 1; kc < KC; ++kc, ++s) {  // rest of the first tile
+            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            if (SI != 0 && kc + 3 == KC) issue_switch_tile();  // this iteration issues stage kc + 3 = the next tile's first
+            CGV_B_PHASE(sb);
+            CGV_A_PHASE(sb);
+        }
     }
 #pragma unroll 1
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
-            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+            const char* sb = (SI == 2) ? smem : smem + (s & (NSTAGE - 1)) * STAGE;
+            if (SI == 2) si_slot = (uint32_t)(3 * STAGE);
             if (MODE != 0 || EPI == 0) {
                 CGV_B_PHASE(sb);
             } else {
@@ -835,14 +862,20 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             }
             ++s;
         }
+        if constexpr (SI == 2) {
+            CGV_TILE_REST_U4
+        } else {
 #pragma unroll 1
-        for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
-            const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
-            if (SI != 0 && kc + 3 == KC) issue_switch_tile();
-            CGV_B_PHASE(sb);
-            CGV_A_PHASE(sb);
+            for (uint32_t kc = 1; kc < KC; ++kc, ++s) {
+                const char* sb = smem + (s & (NSTAGE - 1)) * STAGE;
+                if (SI != 0 && kc + 3 == KC) issue_switch_tile();
+                CGV_B_PHASE(sb);
+                CGV_A_PHASE(sb);
+            }
         }
     }
+#undef CGV_TILE_REST_U4
+#undef CGV_ITER_AT
     // tail: second k-step of the last stage, then the last tile's epilogue
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
