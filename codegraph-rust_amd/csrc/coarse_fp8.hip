@@ -29,6 +29,7 @@ int set_lds(const void* kern) {
 int coarse_attrs_fp8() {
     int rc;
     if ((rc = set_lds((const void*)coarse_fp8s_w4_kernel<0>))) return rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_w4_kernel<0, 2>))) return rc;
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_EMIT>))) return rc;
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_DUMP>))) return rc;
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_SAMPLE>))) return rc;
@@ -63,6 +64,10 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
             }
 #undef CGV_ABLK4
             return status("coarse_fp8s_w4_kernel (ablation)");
+        }
+        if (a.kc % 4 == 0 && (a.epi & 8u) == 0) {   // static issue side, ring-unrolled (epi bit 3 = the dynamic form, for A/B)
+            hipLaunchKernelGGL((coarse_fp8s_w4_kernel<0, 2>), dim3(W), dim3(256), lds, s, a);
+            return status("coarse_fp8s_w4_kernel (si)");
         }
         hipLaunchKernelGGL(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
         return status("coarse_fp8s_w4_kernel");

@@ -24,7 +24,10 @@ namespace cgv {
 
 // ABL: timing-only ablation mask (results are WRONG for ABL != 0; CGV_ABLATE_W4): 1 = skip the epilogue,
 // 2 = skip the DMA, 4 = skip the barrier, 8 = read the fragments once (real data) and never again.
-template <int ABL = 0>
+// SI = 2 (kc % 4 == 0): static issue side + loop unrolled by the ring size, as in kernels_coarse.h - the DMA stream's ring slot
+// and the fragment reads' LDS addresses are constants of the unrolled iteration, the chunk offset one running scalar, the tile
+// switch of the stream happens in a known iteration (the last body of a tile); 0 = the dynamic form (any even kc >= 4).
+template <int ABL = 0, int SI = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void coarse_fp8s_w4_kernel(const CoarseArgs a) {
     constexpr bool DUMP = false;
     constexpr int BM = 256, BN = 256, WN = 2, NT = 256;
@@ -93,12 +96,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define CGV_DMA(RS, DST, IMM) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, voff, d_so, IMM, 0)
     // piece Q of the stage: 0..3 = KiB 0..3 of this wave's share of the A block, 4..7 = of the B block
+    uint32_t si_slot = 0;                          // SI: ring slot (bytes) of the stage being issued, set by the caller
+    uint32_t si_so = (uint32_t)wave * 4096u;       // SI: chunk offset within the tile + this wave's 4 KiB slab
+    auto issue_switch_tile = [&]() {               // SI: the issue side enters the next tile of the visiting order
+        lt = next_tile(lt);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)(a.T1 + lt) * KC * BLOCK_BYTES), 0, 0x7fffffff,
+                                                RS_FLAGS);
+        si_so = (uint32_t)wave * 4096u;
+    };
 #define CGV_ISSUE(Q)                                                                                     \
     {                                                                                                    \
         if (!(ABL & 2)) {                                                                                \
             if ((Q) == 0) {                                                                              \
-                d_so = lkc * BLOCK_BYTES + (uint32_t)wave * 4096u;                                       \
-                d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 4096;                            \
+                if (SI != 0) {                                                                           \
+                    d_so = si_so;                                                                        \
+                    d_dst = smem + si_slot + wave * 4096;                                                \
+                } else {                                                                                 \
+                    d_so = lkc * BLOCK_BYTES + (uint32_t)wave * 4096u;                                   \
+                    d_dst = smem + (issued & (NSTAGE - 1)) * STAGE + wave * 4096;                        \
+                }                                                                                        \
             }                                                                                            \
             if ((Q) == 0) CGV_DMA(rsA, d_dst, 0);                                                        \
             if ((Q) == 1) CGV_DMA(rsA, d_dst, 1024);                                                     \
@@ -109,7 +125,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if ((Q) == 6) CGV_DMA(rsB, d_dst + A_BYTES, 2048);                                           \
             if ((Q) == 7) CGV_DMA(rsB, d_dst + A_BYTES, 3072);                                           \
         }                                                                                                \
-        if ((Q) == 7) {                                                                                  \
+        if ((Q) == 7 && SI != 0) si_so += BLOCK_BYTES;                                                   \
+        if ((Q) == 7 && SI == 0) {                                                                       \
             ++issued;                                                                                    \
             /* the stream never ends: past the last stage it re-reads the last one into the free slot */ \
             if (issued < total && ++lkc == KC) {                                                         \
@@ -300,6 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     issue_rexp(next_tile(t_first), 1);
 #pragma unroll 1
     for (int i = 0; i < NSTAGE - 1; ++i) {
+        si_slot = (uint32_t)(i * STAGE);
         CGV_ISSUE(0) CGV_ISSUE(1) CGV_ISSUE(2) CGV_ISSUE(3) CGV_ISSUE(4) CGV_ISSUE(5) CGV_ISSUE(6) CGV_ISSUE(7)
     }
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (and the side data before it) landed
@@ -321,16 +339,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // straight-line tile-boundary block. Body s covers stages 2s-1 and 2s, each phase publishing the next stage.
     // DMA lead: 3 stages.
     uint32_t ct = t_first, s = 1;
+    si_slot = (uint32_t)(3 * STAGE);
     CGV_A_PHASE(CGV_MMAZ, stage_a(0));
+    // SI: body parity P (0: stages in slots 0, 1; 1: slots 2, 3). The B phase computes stage 2s - 1, fills from stage 2s and
+    // issues stage 2s + 2; the A phase computes 2s, fills from 2s + 1, issues 2s + 3. Every tile starts with an even body.
+#define CGV_BODY_AT(P)                                                            \
+    {                                                                             \
+        si_slot = (uint32_t)(((2 * (P) + 2) & (NSTAGE - 1)) * STAGE);             \
+        CGV_B_PHASE(smem + (2 * (P)) * STAGE);                                    \
+        si_slot = (uint32_t)(((2 * (P) + 3) & (NSTAGE - 1)) * STAGE);             \
+        CGV_A_PHASE(CGV_MMA, smem + (2 * (P) + 1) * STAGE);                       \
+    }
+    // the stream crosses into the next tile in the LAST body of a tile (its B phase issues stage KC = the next tile's first)
+#define CGV_TILE_REST_SI                                                          \
+    {                                                                             \
+        const uint32_t ng = UNITS >> 1;                                           \
+        if (ng == 1) issue_switch_tile();                                         \
+        CGV_BODY_AT(1)                                                            \
+        _Pragma("unroll 1") for (uint32_t gi = 1; gi < ng; ++gi) {                \
+            CGV_BODY_AT(0)                                                        \
+            if (gi + 1 == ng) issue_switch_tile();                                \
+            CGV_BODY_AT(1)                                                        \
+        }                                                                         \
+    }
+    if constexpr (SI != 0) {
+        CGV_TILE_REST_SI
+    } else {
 #pragma unroll 1
-    for (uint32_t u = 1; u < UNITS; ++u, ++s) {  // rest of the first tile
-        CGV_B_PHASE(stage_b(s));
-        CGV_A_PHASE(CGV_MMA, stage_a(s));
+        for (uint32_t u = 1; u < UNITS; ++u, ++s) {  // rest of the first tile
+            CGV_B_PHASE(stage_b(s));
+            CGV_A_PHASE(CGV_MMA, stage_a(s));
+        }
     }
 #pragma unroll 1
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
-            CGV_B_PHASE(stage_b(s));
+            si_slot = (uint32_t)(2 * STAGE);
+            if constexpr (SI != 0) {
+                CGV_B_PHASE(smem);
+            } else {
+                CGV_B_PHASE(stage_b(s));
+            }
             if (wave == 0) pace_step(pace, tl + 1, lane);  // keep the split's workgroups within the L2's reach
             const uint32_t nt = next_tile(ct);
             issue_side(nt, tl);                   // the tile that starts here
@@ -346,15 +395,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             ct = nt;
             load_sa(tl);  // issued at the previous boundary: a whole tile of counted waits + barriers ago
-            CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, stage_a(s), 1, 4, CGV_STAGE_SYNC);
+            si_slot = (uint32_t)(3 * STAGE);
+            if constexpr (SI != 0) {
+                CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, smem + STAGE, 1, 4, CGV_STAGE_SYNC);
+            } else {
+                CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, stage_a(s), 1, 4, CGV_STAGE_SYNC);
+            }
             ++s;
         }
+        if constexpr (SI != 0) {
+            CGV_TILE_REST_SI
+        } else {
 #pragma unroll 1
-        for (uint32_t u = 1; u < UNITS; ++u, ++s) {
-            CGV_B_PHASE(stage_b(s));
-            CGV_A_PHASE(CGV_MMA, stage_a(s));
+            for (uint32_t u = 1; u < UNITS; ++u, ++s) {
+                CGV_B_PHASE(stage_b(s));
+                CGV_A_PHASE(CGV_MMA, stage_a(s));
+            }
         }
     }
+#undef CGV_TILE_REST_SI
+#undef CGV_BODY_AT
     // tail: the last k-step of the last tile, then its epilogue
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
