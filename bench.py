@@ -333,6 +333,32 @@ def main():
                  "exchange": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) of packed 12-byte records "
                              "+ merge kernel, timed with events on the stream it runs on"}
 
+    # side measurement: the same SERIAL steps with the query batch already in HBM and the results left in HBM
+    # (cgv_search_f32_dev): what the PCIe hop of the host boundary costs per batch
+    resident = None
+    if world == 1 and args.steps > 0:
+        d_i = torch.empty((batch, k), dtype=torch.int64, device=dev)
+        d_s = torch.empty((batch, k), dtype=torch.float32, device=dev)
+        di_p, ds_p = C.c_void_p(d_i.data_ptr()), C.c_void_p(d_s.data_ptr())
+
+        def rstep(i):
+            m.cgvec._check(L.cgv_search_f32_dev(ix._h, C.c_void_p(qpool[i % npool].data_ptr()), batch, k, di_p, ds_p))
+        for i in range(max(args.warmup, 1)):
+            rstep(i)
+        sync_all()
+        tr = time.perf_counter()
+        for i in range(args.steps):
+            rstep(i)
+        sync_all()
+        dtr = time.perf_counter() - tr
+        rstep(0)
+        step(0)
+        same = bool(torch.equal(d_i.cpu(), out_i) and torch.equal(d_s.cpu(), out_s))
+        resident = {"queries_per_sec": round(batch * args.steps / dtr, 1), "ms_per_step": round(1e3 * dtr / args.steps, 4),
+                    "same_results_as_host_step": same,
+                    "note": "serial batches, queries already in HBM, results left in HBM (cgv_search_f32_dev); "
+                            "`value` above includes the PCIe hop of both"}
+
     # side measurement: device-resident queries and results, `depth` batches in flight (round 1's headline)
     pipelined = None
     if args.pipelined_steps > 0:
@@ -408,6 +434,7 @@ def main():
             "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
             "pipelined": pipelined,
+            "hbm_resident_serial": resident,
             "roofline": roof,
             "multi_gpu": multi,
             "ingest": {"gb_per_s": round(ingest_rows * dim * (4 + ESIZE[dtype]) / max(ingest_s, 1e-9) / 1e9, 1),

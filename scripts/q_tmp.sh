@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3m; rm -rf $O; mkdir -p $O
-cd $R
-timeout 400 python scripts/ab.py --workload c5mini --variants "dyn:epi=9;si:epi=1" --rounds 3 --steps 6 2>$O/ab_c5.err | tee $O/ab_c5mini.txt
-PYTEST_ARGS="--durations=15" bash scripts/gpu_tests.sh | tail -45
+cd $GRAFT_REPO_ROOT
+bash scripts/gpu_final.sh r03
+timeout 900 python bench.py --workload c5shard --cpu-seconds 0 --steps 5 --warmup 2 --pipelined-steps 4 2>gpurun_out/c5shard.err | tail -1 > gpurun_out/profiles_r03/c5shard_bench.json
+cut -c1-400 gpurun_out/profiles_r03/c5shard_bench.json
