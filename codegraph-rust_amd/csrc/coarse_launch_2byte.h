@@ -53,6 +53,21 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     if constexpr (ABLATE) {
         // results are wrong when set: only the launch time means anything
         static const int abl = getenv("CGV_ABLATE") ? atoi(getenv("CGV_ABLATE")) : 0;
+        if (abl && a.kc >= 4 && a.kc % 4 == 0 && (a.epi & 24u) == 0) {   // ... of the default (ring-unrolled) form
+#define CGV_ABLK2(N)                                                           \
+    case N: {                                                                  \
+        auto k2 = coarse_kernel<DT, COARSE_EMIT, N, 1, false, 2>;              \
+        if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
+        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                 \
+        break;                                                                 \
+    }
+            switch (abl) {
+                CGV_ABLK2(1) CGV_ABLK2(4) CGV_ABLK2(5) CGV_ABLK2(65) CGV_ABLK2(197)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: no such mask for the ring-unrolled kernel (1, 4, 5, 65, 197)");
+            }
+#undef CGV_ABLK2
+            return coarse_hip_status("coarse_kernel (ablation, ring-unrolled)");
+        }
         if (abl) {
 #define CGV_ABLK(N)                                                            \
     case N: {                                                                  \

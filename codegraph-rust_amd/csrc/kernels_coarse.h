@@ -551,6 +551,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     };
     auto issue_q = [&](int q) {
         if constexpr (SI != 0) {
+            if ((ABL & 2) || ((ABL & 64) && issued >= (uint32_t)NSTAGE)) {  // timing-only ablations
+                if (q == 3) ++issued;
+                return;
+            }
+            if ((ABL & 64) && q == 3) ++issued;
             if (q == 0) {
                 d_dst = smem + (si_slot & (uint32_t)(NSTAGE * STAGE - 1)) + wave * 2048;
                 d_so = si_so;
