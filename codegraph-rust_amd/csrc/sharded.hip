@@ -200,6 +200,9 @@ struct cgv_sharded {
     } slots[3];
     std::condition_variable slot_cv;
     bool rccl_broken = false;  // a rank failed to post a collective: communicators aborted, copy exchange from now on
+    // a handle over ONE shard normally skips pack / exchange / merge; CGV_SHARDED_FORCE_EXCHANGE=1 (read at create) runs them
+    // anyway - a one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
+    bool force_xch = false;
     uint64_t searches = 0, queries = 0;
     float last_search_ms = 0.0f, last_exchange_ms = 0.0f;
 };
@@ -279,7 +282,7 @@ uint64_t shard_count(const cgv_sharded* s, uint64_t n, uint32_t g) {
 }
 
 int set_exchange_locked(cgv_sharded* s, int kind) {
-    if (s->G <= 1) {
+    if (s->G <= 1 && !s->force_xch) {
         s->exchange = CGV_EXCHANGE_NONE;
         return CGV_OK;
     }
@@ -334,6 +337,7 @@ int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, 
     s->metric = metric;
     s->dtype = dtype;
     s->G = n_devices;
+    if (const char* e = getenv("CGV_SHARDED_FORCE_EXCHANGE")) s->force_xch = atoi(e) != 0;
     for (uint32_t g = 0; g < n_devices; ++g)
         for (uint32_t g2 = 0; g2 < g; ++g2)
             if (device_ids[g] == device_ids[g2]) s->distinct = false;
@@ -656,12 +660,12 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
         if ((rc = b.qdev.ensure(qbytes))) return rc;
         if ((rc = b.oidx.ensure((size_t)nq * k * 8))) return rc;
         if ((rc = b.osc.ensure((size_t)nq * k * 4))) return rc;
-        if (G > 1) {
+        if (G > 1 || s->force_xch) {
             if ((rc = b.rec.ensure(rec_bytes))) return rc;
             if ((s->exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = b.gathered.ensure((size_t)G * rec_bytes))) return rc;
         }
     }
-    if (G > 1) {
+    if (G > 1 || s->force_xch) {
         SHIP(hipSetDevice(root->device));
         int rc;
         if ((rc = sl.moidx.ensure((size_t)nq * k * 8))) return rc;
@@ -711,6 +715,7 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
     const size_t rec_bytes = (size_t)nq * w * 4;
     Shard* root = s->sh[0];
     const int exchange = s->exchange;
+    const bool xch = G > 1 || s->force_xch;
     std::string why;
     const Rccl* rccl = exchange == CGV_EXCHANGE_RCCL ? load_rccl(&why) : nullptr;
     std::vector<std::function<int()>> jobs(G);
@@ -727,7 +732,7 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
                 if (rc) err = cgv_last_error();
             }
             b.t_search_done = Clock::now();
-            if (G > 1) {
+            if (xch) {
                 if (rc == CGV_OK) {
                     rc = cgv_pack_topk_dev(sh->device, (const uint64_t*)b.oidx.p, (const float*)b.osc.p, nq, k, (uint32_t*)b.rec.p,
                                            sh->xs);
@@ -784,7 +789,7 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
     hipError_t he = hipSetDevice(root->device);
     const uint64_t* ri = (const uint64_t*)root->slot[si].oidx.p;
     const float* rs = (const float*)root->slot[si].osc.p;
-    if (he == hipSuccess && G > 1) {
+    if (he == hipSuccess && xch) {
         rc = cgv_merge_packed_dev(root->device, (const uint32_t*)root->slot[si].gathered.p, G, nq, k, (uint64_t*)sl.moidx.p,
                                   (float*)sl.mosc.p, root->xs);
         ri = (const uint64_t*)sl.moidx.p;

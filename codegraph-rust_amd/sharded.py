@@ -25,8 +25,9 @@ class ShardedKnn:
     ids are already GLOBAL (HipKnnIndex.set_index_base(lo)); `merge` maps gathered
     [G,nq,k] tensors to [nq,k] (default: the HIP merge kernel through the C ABI)."""
 
-    def __init__(self, local, rank=None, world=None, group=None, merge=None):
+    def __init__(self, local, rank=None, world=None, group=None, merge=None, force_collective=False):
         self.local = local
+        self.force_collective = force_collective   # world == 1: run pack / all-gather / merge anyway (one-rank RCCL smoke test)
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -53,7 +54,7 @@ class ShardedKnn:
         return _Pending()
 
     def _exchange(self, idx, score, k):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return idx, score
         nq = idx.shape[0]
         # ONE all-gather of nq packed records (k u64 ids + k f32 scores, 12 B per hit) per rank:

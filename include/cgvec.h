@@ -343,7 +343,9 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
 int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket);
 uint32_t cgv_sharded_max_batches_in_flight(const cgv_sharded* s);
 /* Which exchange the handle uses (CGV_EXCHANGE_*); cgv_sharded_set_exchange forces RCCL or COPY
- * (RCCL needs distinct devices). */
+ * (RCCL needs distinct devices). A handle over ONE shard has nothing to exchange (CGV_EXCHANGE_NONE) unless the
+ * environment holds CGV_SHARDED_FORCE_EXCHANGE=1 at cgv_sharded_create: then its batches go through pack -> one-rank
+ * ncclAllGather (or the copy) -> merge as well - how the RCCL branch is executed on a single-GPU box (tests). */
 int cgv_sharded_exchange(const cgv_sharded* s);
 int cgv_sharded_set_exchange(cgv_sharded* s, int kind);
 typedef struct cgv_sharded_stats {

@@ -263,7 +263,7 @@ def _rank_main(rank, world, port, n, d, nq, k, out):
     ix = m.HipKnnIndex(d, dtype="bf16", device=rank)
     ix.add(rows[lo:hi])
     ix.set_index_base(lo)
-    sh = m.ShardedKnn(ix, rank=rank, world=world)      # device pack -> all_gather_into_tensor -> device merge
+    sh = m.ShardedKnn(ix, rank=rank, world=world, force_collective=True)   # device pack -> all_gather_into_tensor -> device merge
     qd = torch.from_numpy(q).cuda()
     idx, sc = sh.search(qd, k)
     p1 = sh.search_begin(qd, k)
@@ -277,6 +277,56 @@ def _rank_main(rank, world, port, n, d, nq, k, out):
     ix.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collective_executes(tmp_path, oracle):
+    """The same rank program with world_size 1 (any box with one GPU): RCCL is loaded, a communicator is created and
+    the packed records go through a real all_gather_into_tensor + the device merge - the degenerate case of the 2-rank
+    test below, so that the RCCL branch of ShardedKnn is executed code on the single-GPU test box too."""
+    import torch.multiprocessing as mp
+    n, d, nq, k = 20_000, 128, 100, 10
+    out = str(tmp_path / "r1")
+    mp.spawn(_rank_main, args=(1, _free_port(), n, d, nq, k, out), nprocs=1, join=True)
+    rng = np.random.default_rng(99)
+    rows = _unit(rng, n, d)
+    rows[11] = rows[n - 2]
+    q = _unit(rng, nq, d)
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+    assert np.array_equal(np.load(f"{out}.0.idx.npy"), ri)
+    assert np.array_equal(np.load(f"{out}.0.sc.npy"), rs)
+
+
+def test_one_shard_handle_runs_the_in_library_rccl_exchange(oracle, monkeypatch):
+    """cgv_sharded over ONE device with CGV_SHARDED_FORCE_EXCHANGE=1: ncclCommInitAll over one device, then every batch
+    goes pack -> ncclAllGather (one rank) -> merge -> host, i.e. the RCCL branch of sharded.hip runs on a single-GPU box
+    (without the switch a one-shard handle skips the exchange). Results = the oracle's; serial and two batches in flight."""
+    m = pkg()
+    monkeypatch.setenv("CGV_SHARDED_FORCE_EXCHANGE", "1")
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 3 * C + 77, 96, 130, 10
+    rows = _unit(rng, n, d)
+    q = _unit(rng, nq, d)
+    sx = m.ShardedIndex(d, [0], dtype="bf16")
+    try:
+        assert sx.exchange == "rccl"
+        sx.add(rows)
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+        for _ in range(2):
+            idx, sc = sx.search(q, k)
+            assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        p1 = sx.search_begin(q, k)
+        p2 = sx.search_begin(q[::-1].copy(), k)
+        i1, s1 = p1.wait()
+        i2, s2 = p2.wait()
+        assert np.array_equal(i1, ri) and np.array_equal(s1, rs)
+        assert np.array_equal(i2, ri[::-1]) and np.array_equal(s2, rs[::-1])
+        st = sx.stats()
+        assert st["exchange"] == "rccl" and st["last_exchange_ms"] > 0.0
+        sx.set_exchange("copy")
+        idx, sc = sx.search(q, k)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    finally:
+        sx.close()
 
 
 @pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 GPUs")
