@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--sharded-handle", type=int, default=0,
                     help="G > 0: drive ONE cgv_sharded handle over G shards (devices i %% device_count) with two batches in "
                          "flight (cgv_sharded_search_begin_f32 / _end) instead of the single index; N = 1 only")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group over RCCL, pinned-batch shard search, all-gather + merge, "
+                         "multi_gpu block) with whatever world size the launcher gave - with ONE rank it is the dry run of the "
+                         "multi-GPU bench on a single-GPU box (start it under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="print this rank's RANK/WORLD_SIZE and exit before touching a GPU (CPU test of the self-spawn)")
     args = ap.parse_args()
@@ -201,7 +205,7 @@ def main():
                           "master": os.environ.get("MASTER_ADDR")}), flush=True)
         return
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -245,7 +249,7 @@ def main():
     qhost = [q.cpu().pin_memory() for q in qpool]           # the caller's query batches: pinned host memory
     out_i = torch.empty((batch, k), dtype=torch.int64).pin_memory()
     out_s = torch.empty((batch, k), dtype=torch.float32).pin_memory()
-    searcher = m.ShardedKnn(ix, rank=rank, world=world) if world > 1 else ix
+    searcher = m.ShardedKnn(ix, rank=rank, world=world, force_collective=args.force_dist) if dist is not None else ix
     ix.set_profiling(True)
 
     def sync_all():
@@ -254,8 +258,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
-        L, C = m.cgvec.lib(), m.cgvec.C
+    L, C = m.cgvec.lib(), m.cgvec.C
+    if dist is None:
         oi_p, os_p = C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr())
 
         def step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
@@ -268,10 +272,9 @@ def main():
             #                all-gather + merge, D2H
             li, ls = ix.search_from_pinned(qhost[i % npool], k)   # this rank's shard (ids already global)
             ev_x0.record()
-            gi, gs = searcher._exchange(li, ls, k)    # ONE RCCL all-gather of packed records + merge kernel
+            # ONE RCCL all-gather of packed records + merge kernel, which writes the pinned host result arrays in place
+            searcher._exchange(li, ls, k, out=(out_i, out_s))
             ev_x1.record()
-            out_i.copy_(gi, non_blocking=True)
-            out_s.copy_(gs, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             exchange_ms.append(ev_x0.elapsed_time(ev_x1))
 
@@ -336,7 +339,7 @@ def main():
     # side measurement: the same SERIAL steps with the query batch already in HBM and the results left in HBM
     # (cgv_search_f32_dev): what the PCIe hop of the host boundary costs per batch
     resident = None
-    if world == 1 and args.steps > 0:
+    if dist is None and args.steps > 0:
         d_i = torch.empty((batch, k), dtype=torch.int64, device=dev)
         d_s = torch.empty((batch, k), dtype=torch.float32, device=dev)
         di_p, ds_p = C.c_void_p(d_i.data_ptr()), C.c_void_p(d_s.data_ptr())

@@ -586,12 +586,20 @@ def pack_topk(idx, score):
     return rec
 
 
-def merge_packed(gathered, k):
-    """[g, nq, packed_width(k)] int32 (the all-gather output) -> merged ([nq, k] int64 ids, f32 scores)."""
+def merge_packed(gathered, k, out=None):
+    """[g, nq, packed_width(k)] int32 (the all-gather output) -> merged ([nq, k] int64 ids, f32 scores).
+    out = (ids, scores): contiguous [nq, k] int64 / float32 tensors to fill - CUDA tensors, or PINNED CPU tensors,
+    which the merge kernel writes in place (valid once the stream has been synchronised)."""
     import torch
     g, nq, _ = gathered.shape
-    oi = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
-    os_ = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    if out is not None:
+        oi, os_ = out
+        for t, dt in ((oi, torch.int64), (os_, torch.float32)):
+            if tuple(t.shape) != (nq, k) or t.dtype != dt or not t.is_contiguous() or not (t.is_cuda or t.is_pinned()):
+                raise CgvError(CGV_ERR_INVALID_ARG, "merge_packed: out tensors must be contiguous [nq, k] int64 / float32, CUDA or pinned")
+    else:
+        oi = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+        os_ = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
     stream = torch.cuda.current_stream(gathered.device).cuda_stream
     _check(lib().cgv_merge_packed_dev(gathered.device.index or 0, C.c_void_p(gathered.data_ptr()), g, nq, k,
                                       C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(stream)))

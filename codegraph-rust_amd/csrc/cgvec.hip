@@ -1947,6 +1947,9 @@ int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uin
     if (!rec_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
     if (g > 64) return fail(CGV_ERR_INVALID_ARG, "more than 64 partial lists per query");
     HIPCHK(hipSetDevice(device_id));
+    // pinned HOST result arrays are written in place by the merge kernel (no D2H copies for the caller to enqueue)
+    if (void* al = device_alias(out_idx_dev)) out_idx_dev = (uint64_t*)al;
+    if (void* al = device_alias(out_score_dev)) out_score_dev = (float*)al;
     const uint64_t stride = (uint64_t)packed_width(k) * 4;
     if ((uint64_t)g * k > 4096) {  // beyond the LDS merge: G-way wave merge (any k)
         hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)rec_dev, stride,

@@ -53,7 +53,9 @@ class ShardedKnn:
                 return outer._exchange(*pending.wait(), k)
         return _Pending()
 
-    def _exchange(self, idx, score, k):
+    def _exchange(self, idx, score, k, out=None):
+        """out = (ids, scores): optional result tensors of the device path (CUDA, or pinned CPU tensors the merge kernel
+        fills in place - the caller synchronises the stream before reading them)."""
         if self.world == 1 and not self.force_collective:
             return idx, score
         nq = idx.shape[0]
@@ -66,7 +68,7 @@ class ShardedKnn:
             if self._gathered is None or tuple(self._gathered.shape) != key or self._gathered.device != rec.device:
                 self._gathered = torch.empty(key, dtype=torch.int32, device=rec.device)   # reused across batches
             dist.all_gather_into_tensor(self._gathered, rec, group=self.group)
-            return merge_packed(self._gathered, k)
+            return merge_packed(self._gathered, k, out=out)
         rec = torch.cat([idx.contiguous().view(torch.int32).reshape(nq, 2 * k),
                          score.contiguous().view(torch.int32).reshape(nq, k)], dim=1).contiguous()
         gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=rec.device)

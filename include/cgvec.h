@@ -238,7 +238,9 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
 /* The same exchange with ONE packed buffer per rank (what sharded.py all-gathers): cgv_pack_topk_dev
  * writes, per query, cgv_packed_width(k) = 3k (+1 if k is odd) int32 words: k u64 ids | k f32 scores;
  * cgv_merge_packed_dev merges g such buffers laid out [g][nq][width] (the all-gather output) with
- * (score desc, id asc). Saves the concatenate / slice copies around the collective. */
+ * (score desc, id asc). Saves the concatenate / slice copies around the collective. The out arrays of
+ * cgv_merge_packed_dev may also be pinned HOST memory (hipHostMalloc / hipHostRegister): the kernel then writes the
+ * merged results there directly. */
 uint32_t cgv_packed_width(uint32_t k);
 int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t nq, uint32_t k,
                       uint32_t* out_rec_dev, void* stream);

@@ -573,6 +573,15 @@ def test_packed_exchange_kernels(oracle, k):
         ri, rs = oracle.merge_topk(idx[:, q, :], sc[:, q, :], k)
         assert np.array_equal(oi[q].cpu().numpy().view(np.uint64), ri) and np.array_equal(os_[q].cpu().numpy(), rs)
     assert torch.equal(oi, oi2) and torch.equal(os_, os2)
+    # pinned HOST result arrays: the merge kernel writes them in place (what a rank of the sharded bench hands over)
+    hi = torch.full((nq, k), -1, dtype=torch.int64).pin_memory()
+    hs = torch.full((nq, k), float("nan"), dtype=torch.float32).pin_memory()
+    ri2, rs2 = m.cgvec.merge_packed(torch.stack(recs).contiguous(), k, out=(hi, hs))
+    torch.cuda.synchronize()
+    assert ri2 is hi and rs2 is hs
+    assert torch.equal(hi, oi.cpu()) and torch.equal(hs, os_.cpu())
+    with pytest.raises(m.CgvError):
+        m.cgvec.merge_packed(torch.stack(recs).contiguous(), k, out=(torch.empty((nq, k), dtype=torch.int64), hs))   # pageable
 
 
 def test_randomised_shapes_differential(oracle):
