@@ -62,8 +62,8 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         break;                                                                 \
     }
             switch (abl) {
-                CGV_ABLK2(1) CGV_ABLK2(4) CGV_ABLK2(5) CGV_ABLK2(65) CGV_ABLK2(197)
-                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: no such mask for the ring-unrolled kernel (1, 4, 5, 65, 197)");
+                CGV_ABLK2(1) CGV_ABLK2(4) CGV_ABLK2(5) CGV_ABLK2(65) CGV_ABLK2(197) CGV_ABLK2(256) CGV_ABLK2(512) CGV_ABLK2(768)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: no such mask for the ring-unrolled kernel (1, 4, 5, 65, 197, 256, 512, 768)");
             }
 #undef CGV_ABLK2
             return coarse_hip_status("coarse_kernel (ablation, ring-unrolled)");
@@ -98,6 +98,12 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     // the stage loop unrolled by the ring size, LDS addresses as immediates (epi bit 4 = the rolled form, for A/B)
     const bool nt = a.nqt == 1 && (a.epi & 2u) == 0, si = a.kc >= 4 && (a.epi & 8u) == 0;
     const bool u4 = si && a.kc % 4 == 0 && (a.epi & 16u) == 0;
+    if (u4 && (a.epi & 32u) != 0 && !nt) {   // A/B reference: the ring-unrolled loop with the fragment reads in the barrier's gap
+        auto kp = coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 3>;
+        if (int rc = coarse_set_lds((const void*)kp)) return rc;
+        hipLaunchKernelGGL(kp, dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (reads in the barrier gap)");
+    }
     if (u4) {
         if (nt)
             hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);

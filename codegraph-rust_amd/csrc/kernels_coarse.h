@@ -434,6 +434,8 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
 // 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
+// 256 / 512 / 768 = the stage's counted wait is vmcnt(4) / (6) / (2) instead of (8): results stay correct, the DMA lead shrinks
+// by 1 / 0.5 / 1.5 stages (how much of the 3-stage lead does the kernel need? r03i: two stages are enough).
 // EPI, the emitting epilogue: 1 (default) = the conservative thresholds are formed in the MFMA gaps of a tile's last
 // k-step, and each 32 x 32 block's filter (8 VALU maxima + one compare) sits right in front of the zero-C MFMA of the
 // next tile's first k-step that overwrites the block - one wave's filter runs beside its SIMD partner's MFMA instead of
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 CGV_BDMA(rsB, d_dst + A_BYTES, 0);
             } else {
                 CGV_BDMA(rsB, d_dst + A_BYTES, 1024);
-                if (SI == 1) si_slot += (uint32_t)STAGE;   // SI == 2: set by the (unrolled) caller, a constant per iteration
+                if (SI == 1) si_slot += (uint32_t)STAGE;   // SI >= 2: set by the (unrolled) caller, a constant per iteration
                 si_so += BLOCK_BYTES;
             }
             return;
@@ -649,6 +651,17 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_LDA(FA, 0, BASE, KK) CGV_LDA(FA, 1, BASE, KK) CGV_LDA(FA, 2, BASE, KK) CGV_LDA(FA, 3, BASE, KK) \
         CGV_LDB(FB, 0, BASE, KK) CGV_LDB(FB, 1, BASE, KK)                                        \
     }
+#define CGV_LOAD_FRAGS_A(FA, BASE, KK) \
+    { CGV_LDA(FA, 0, BASE, KK) CGV_LDA(FA, 1, BASE, KK) CGV_LDA(FA, 2, BASE, KK) CGV_LDA(FA, 3, BASE, KK) }
+#define CGV_LOAD_FRAGS_B(FB, BASE, KK) \
+    { CGV_LDB(FB, 0, BASE, KK) CGV_LDB(FB, 1, BASE, KK) }
+    // Where the fragment reads of a NEW stage go relative to the stage barrier (B phase). LG = 0: right behind it, in the gap
+    // of the barrier (rounds 1-3). LG = 12 (every form but the A/B reference SI == 3): nothing but the barrier in gap 0 -
+    // both waves of a SIMD wake up together, and the first thing each does is put its next MFMA into the idle matrix pipe;
+    // the 4 A reads follow in gap 1, the 2 B reads in gap 2 (5 MFMAs to land). Measured (r03j, C2 main launch, one process):
+    // 1.0001 -> 0.9866 ms; reads one / two gaps later in one piece 0.9889 / 0.9881; C3 shard 4.731 -> 4.661. SI == 3 = the
+    // ring-unrolled loop with LG = 0 (A/B reference).
+    constexpr int LG = (SI == 3) ? 0 : 12;
 #define CGV_MMA(MBI, NBI, FA, FB) acc[MBI][NBI] = Mfma<DT>::mma(FA[MBI], FB[NBI], acc[MBI][NBI]);
     // first k-step of a tile: C operand = 0 (an inline constant in the MFMA encoding) instead of clearing 128
     // accumulator registers per tile. These run in their own straight-line block at every tile boundary (never as
@@ -676,9 +689,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                   \
     {                                                                                                            \
         /* serpentine block order: consecutive MFMAs share one operand block (0.5 % on the C2 main launch) */    \
-        MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LOAD_FRAGS(NA, NB_, NBASE, NKK))                       \
-        MMA(0, 1, FA, FB) CGV_GAP(0, 1, FA[1], CGV_NOP_ACTION)                                                   \
-        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], CGV_NOP_ACTION)                                                   \
+        MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; if (!(LG != 0 && (NKK) == 0)) CGV_LOAD_FRAGS(NA, NB_, NBASE, NKK)) \
+        MMA(0, 1, FA, FB) CGV_GAP(0, 1, FA[1], if (LG == 1 && (NKK) == 0) CGV_LOAD_FRAGS(NA, NB_, NBASE, NKK);   \
+                                               if (LG == 12 && (NKK) == 0) CGV_LOAD_FRAGS_A(NA, NBASE, NKK))     \
+        MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], if (LG == 2 && (NKK) == 0) CGV_LOAD_FRAGS(NA, NB_, NBASE, NKK);   \
+                                               if (LG == 12 && (NKK) == 0) CGV_LOAD_FRAGS_B(NB_, NBASE, NKK))    \
         MMA(1, 0, FA, FB) CGV_GAP(1, 0, FA[2], issue_q(Q0))                                                      \
         MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_NOP_ACTION)                                                   \
         MMA(2, 1, FA, FB) CGV_GAP(2, 1, FA[3], issue_q(Q0 + 1))                                                  \
@@ -713,8 +728,13 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         thr[MBI][NBI] = ta[NBI] * mul_;                                                               \
         asm volatile("" : "+v"(thr[MBI][NBI]));                                                       \
     }
-#define CGV_STAGE_SYNC                                                      \
-    if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
+#define CGV_STAGE_SYNC                                                                          \
+    if (!(ABL & 16)) {                                                                          \
+        if ((ABL & 768) == 256) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  /* lead - 1 stage (timing probe) */ \
+        else if ((ABL & 768) == 512) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           \
+        else if ((ABL & 768) == 768) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                   \
+    }                                                                                           \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
     // Stage s holds k-steps (s,0) [fragments fa0/fb0] and (s,1) [fa1/fb1]. Iteration s runs the B phase =
     // k-step (s-1,1) with the stage barrier behind its first MFMA, then the A phase = k-step (s,0). DMA lead:
@@ -724,7 +744,9 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #define CGV_A_PHASE_Z(SB_) CGV_KSTEP(CGV_MMAZ, fa0, fb0, fa1, fb1, SB_, 1, 2, CGV_NOP_ACTION)
 #define CGV_B_PHASE(SB_) CGV_KSTEP(CGV_MMA, fa1, fb1, fa0, fb0, SB_, 0, 0, CGV_STAGE_SYNC)
 #define CGV_B_PHASE_LAST(SB_, SEQ)                                                                                  \
-    CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; CGV_LOAD_FRAGS(fa0, fb0, SB_, 0), CGV_THR_LOAD(SEQ),        \
+    CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa0, CGV_STAGE_SYNC; if (LG == 0) CGV_LOAD_FRAGS(fa0, fb0, SB_, 0),              \
+                if (LG == 1) CGV_LOAD_FRAGS(fa0, fb0, SB_, 0); if (LG == 12) CGV_LOAD_FRAGS_A(fa0, SB_, 0); CGV_THR_LOAD(SEQ), \
+                if (LG == 2) CGV_LOAD_FRAGS(fa0, fb0, SB_, 0); if (LG == 12) CGV_LOAD_FRAGS_B(fb0, SB_, 0);         \
                 CGV_THR(0, 0, mn4.x, mx4.x) CGV_THR(0, 1, mn4.x, mx4.x), issue_q(0); CGV_THR(1, 0, mn4.y, mx4.y),   \
                 CGV_THR(1, 1, mn4.y, mx4.y) CGV_THR(2, 0, mn4.z, mx4.z), issue_q(1); CGV_THR(2, 1, mn4.z, mx4.z),   \
                 CGV_THR(3, 0, mn4.w, mx4.w), CGV_THR(3, 1, mn4.w, mx4.w))
@@ -766,7 +788,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     issue_side(t_first, 0);
 #pragma unroll 1
     for (int i = 0; i < NSTAGE - 1; ++i) {
-        if (SI == 2) si_slot = (uint32_t)(i * STAGE);
+        if (SI >= 2) si_slot = (uint32_t)(i * STAGE);
         issue_q(0);
         issue_q(1);
         issue_q(2);
@@ -804,11 +826,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // boundary the iteration is B phase (last k-step of the previous tile), its epilogue, zero-C A phase.
     const uint32_t ntl = jhi - jlo;
     uint32_t ct = t_first, s = 1;
-    if (SI == 2) si_slot = (uint32_t)(3 * STAGE);
+    if (SI >= 2) si_slot = (uint32_t)(3 * STAGE);
     issue_q(0);  // stage 3 -> slot 3 (never used so far)
     issue_q(1);
     CGV_A_PHASE_Z(smem);
-    // SI == 2 (KC % 4 == 0): every tile starts in ring slot 0, so the stage loop unrolled by the ring size has its LDS
+    // SI >= 2 (KC % 4 == 0): every tile starts in ring slot 0, so the stage loop unrolled by the ring size has its LDS
     // addresses (fragment reads: lane base + immediate; DMA: wave base + constant) fixed per unrolled iteration
 #define CGV_ITER_AT(SLOT)                                                         \
     {                                                                             \
@@ -828,7 +850,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             CGV_ITER_AT(1) CGV_ITER_AT(2) CGV_ITER_AT(3)                          \
         }                                                                         \
     }
-    if constexpr (SI == 2) {
+    if constexpr (SI >= 2) {
         CGV_TILE_REST_U4
     } else {
 #pragma unroll 1
@@ -842,8 +864,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #pragma unroll 1
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
-            const char* sb = (SI == 2) ? smem : smem + (s & (NSTAGE - 1)) * STAGE;
-            if (SI == 2) si_slot = (uint32_t)(3 * STAGE);
+            const char* sb = (SI >= 2) ? smem : smem + (s & (NSTAGE - 1)) * STAGE;
+            if (SI >= 2) si_slot = (uint32_t)(3 * STAGE);
             if (MODE != 0 || EPI == 0) {
                 CGV_B_PHASE(sb);
             } else {
@@ -867,7 +889,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             }
             ++s;
         }
-        if constexpr (SI == 2) {
+        if constexpr (SI >= 2) {
             CGV_TILE_REST_U4
         } else {
 #pragma unroll 1
