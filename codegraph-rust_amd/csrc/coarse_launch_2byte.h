@@ -98,11 +98,13 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     // the stage loop unrolled by the ring size, LDS addresses as immediates (epi bit 4 = the rolled form, for A/B)
     const bool nt = a.nqt == 1 && (a.epi & 2u) == 0, si = a.kc >= 4 && (a.epi & 8u) == 0;
     const bool u4 = si && a.kc % 4 == 0 && (a.epi & 16u) == 0;
-    if (u4 && (a.epi & 32u) != 0 && !nt) {   // A/B reference: the ring-unrolled loop with the fragment reads in the barrier's gap
-        auto kp = coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 3>;
-        if (int rc = coarse_set_lds((const void*)kp)) return rc;
-        hipLaunchKernelGGL(kp, dim3(W), dim3(512), lds, s, a);
-        return coarse_hip_status("coarse_kernel (reads in the barrier gap)");
+    if constexpr (ABLATE) {   // A/B reference (bf16 build only): the ring-unrolled loop with the fragment reads in the barrier's gap
+        if (u4 && (a.epi & 32u) != 0 && !nt) {
+            auto kp = coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 3>;
+            if (int rc = coarse_set_lds((const void*)kp)) return rc;
+            hipLaunchKernelGGL(kp, dim3(W), dim3(512), lds, s, a);
+            return coarse_hip_status("coarse_kernel (reads in the barrier gap)");
+        }
     }
     if (u4) {
         if (nt)

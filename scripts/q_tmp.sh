@@ -1,8 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3z; rm -rf $O; mkdir -p $O
-cd $R
-timeout 300 python scripts/ab.py --workload c5mini --variants "gap0:epi=33;late:epi=1" --rounds 3 --steps 6 2>$O/ab_c5.err | tee $O/ab_c5mini.txt
-timeout 300 python scripts/ab.py --workload c2 --variants "gap0:epi=33;late:epi=1" --rounds 4 --steps 12 2>$O/ab_c2.err | tee $O/ab_c2.txt
-timeout 300 python scripts/ab.py --workload c4 --variants "gap0:epi=33;late:epi=1" --rounds 4 --steps 12 2>$O/ab_c4.err | tee $O/ab_c4.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_guarantee.py tests/test_gpu_robustness.py tests/test_gpu_configs.py -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -k "not c5_full" 2>&1 | tail -6 | tee $O/pytest.txt
+cd $GRAFT_REPO_ROOT
+PYTEST_ARGS="--durations=8" bash scripts/gpu_tests.sh | tail -30
+bash scripts/gpu_final.sh r03
+timeout 900 python bench.py --workload c5shard --cpu-seconds 0 --steps 5 --warmup 2 --pipelined-steps 4 2>gpurun_out/c5shard.err | tail -1 > gpurun_out/profiles_r03/c5shard_bench.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --force-dist --cpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/profiles_r03/c2_force_dist_bench.json
