@@ -1,7 +1,13 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-PYTEST_ARGS="--durations=8" bash scripts/gpu_tests.sh | tail -30
-bash scripts/gpu_final.sh r03
-timeout 900 python bench.py --workload c5shard --cpu-seconds 0 --steps 5 --warmup 2 --pipelined-steps 4 2>gpurun_out/c5shard.err | tail -1 > gpurun_out/profiles_r03/c5shard_bench.json
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --force-dist --cpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/profiles_r03/c2_force_dist_bench.json
+export LIBC_FATAL_STDERR_=1
+for i in 1 2 3; do
+  echo "== plain run $i"
+  timeout 300 python -X faulthandler -m pytest tests/test_gpu_robustness.py tests/test_gpu_sharded.py -m gpu -q -x --tb=short -p no:cacheprovider --timeout 200 -k "pinned_host or id_map or sharded_handle_matches" 2>&1 | tail -12
+done
+export MALLOC_CHECK_=3
+for i in 1 2; do
+  echo "== MALLOC_CHECK_ run $i"
+  timeout 300 python -X faulthandler -m pytest tests/test_gpu_robustness.py tests/test_gpu_sharded.py -m gpu -q -x --tb=short -p no:cacheprovider --timeout 200 -k "pinned_host or id_map or sharded_handle_matches" 2>&1 | tail -12
+done

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# a glibc abort message (heap corruption, ...) goes to stderr instead of /dev/tty: together with --capture=sys (pytest.ini:
+# native stderr is not swallowed) a crash inside the HIP runtime or the library leaves its last words in the log
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -2,12 +2,15 @@
 k beyond the MFMA path's range, the begin/end pool cannot self-deadlock, per-hit scoring in one launch."""
 import ctypes as C
 
+import mmap
+
 import numpy as np
 import pytest
 
 from _util import pkg
 
 pytestmark = pytest.mark.gpu
+_REGISTERED = []   # anonymous mappings handed to hipHostRegister: kept for the session
 
 
 def _unit(rng, n, d):
@@ -261,14 +264,21 @@ def test_pinned_host_buffers_are_used_in_place(oracle):
             # pinned queries in, DEVICE results out (what a rank of the row-sharded deployment does before the exchange)
             di, ds = ix.search_from_pinned(qp, k)
             assert np.array_equal(di.cpu().numpy().view(np.uint64), ri) and np.array_equal(ds.cpu().numpy(), rs)
-            # registered pageable memory: the device alias may differ from the host address
+            # registered pageable memory: the device alias may differ from the host address. The buffer is an anonymous
+            # page-aligned mapping of its own (not a piece of the malloc heap, whose pages it would pin together with
+            # whatever else lives on them) and stays mapped for the rest of the session (_REGISTERED): its address range is
+            # never handed to another allocation while the HIP runtime may still remember it
             rt = torch.cuda.cudart()
-            reg = np.ascontiguousarray(q.copy())
-            if hasattr(rt, "cudaHostRegister") and int(rt.cudaHostRegister(reg.ctypes.data, reg.nbytes, 0)) == 0:
+            mm = mmap.mmap(-1, (q.nbytes + 4095) // 4096 * 4096)
+            _REGISTERED.append(mm)
+            reg = np.frombuffer(mm, dtype=np.float32, count=q.size).reshape(q.shape)
+            reg[:] = q
+            if hasattr(rt, "cudaHostRegister") and int(rt.cudaHostRegister(reg.ctypes.data, len(mm), 0)) == 0:
                 try:
                     ix.search_host_ptr(reg.ctypes.data, nq, k, oi.data_ptr(), osc.data_ptr())
                     assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
                 finally:
-                    rt.cudaHostUnregister(reg.ctypes.data)
+                    torch.cuda.synchronize()
+                    assert int(rt.cudaHostUnregister(reg.ctypes.data)) == 0
         finally:
             ix.close()
