@@ -53,10 +53,8 @@ class ShardedStats(C.Structure):
 def build_library(force=False):
     """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))
-    else:
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    jobs = "-j%d" % max(1, min(9, os.cpu_count() or 1))   # one object per translation unit: they build in parallel
+    subprocess.check_call(["make", "-C", src_dir, "-s", jobs] + (["-B"] if force else []))
     return LIB_PATH
 
 
