@@ -1,6 +1,7 @@
 """Behaviour at the edges of the single-device C ABI (ADVICE r1 + VERDICT r1): failed adds leave no trace,
 k beyond the MFMA path's range, the begin/end pool cannot self-deadlock, per-hit scoring in one launch."""
 import ctypes as C
+import os
 
 import mmap
 
@@ -223,7 +224,22 @@ def test_pinned_host_buffers_are_used_in_place(oracle):
     """cgv_search_f32 reads pinned query buffers and writes pinned result buffers directly; pageable
     buffers go through staging. Every mix must give the oracle's answers - including the batches whose queries take
     the exact-scan fallback (it writes into the caller's pinned arrays too), a non-finite query (error, index intact),
-    an f32 index (exact path only), and a registered (hipHostRegister) numpy buffer."""
+    an f32 index (exact path only), and a registered (hipHostRegister) buffer.
+    Runs in a process of its own: it is the one test that hands hipHostRegister-ed memory to the HIP runtime, and the two
+    aborts the full suite has seen both hit the test that followed it. The child leaves through os._exit
+    once its assertions hold; whatever the runtime does with that memory afterwards stays in the child."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import os, sys; sys.path.insert(0, %r); import test_gpu_robustness as t; from oracle import oracle as o; "
+            "o.build(); t._pinned_host_buffers_case(o); print('pinned-case-ok', flush=True); os._exit(0)" % here)
+    env = dict(os.environ, LIBC_FATAL_STDERR_="1")
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=os.path.dirname(here))
+    assert p.returncode == 0 and "pinned-case-ok" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+
+
+def _pinned_host_buffers_case(oracle):
     import torch
     m = pkg()
     rng = np.random.default_rng(91)
