@@ -15,8 +15,11 @@ A "step" is SURVEY.md §8(d)'s unit: ONE batched search of 1024 queries against 
 corpus resident in HBM, queries starting in (pinned) HOST memory and the B*k results ending in
 host memory — H2D of the queries and D2H of the results are inside the step; steps are strictly
 serial (one batch at a time). `value` = batch * K / wall time of the K timed steps (max over
-ranks); `median_qps` is the same from the median step. The device-resident, two-batches-in-flight
-rate of round 1 is reported beside it as `pipelined_qps`, never as `value`.
+ranks); `median_qps` is the same from the median step. Beside it, never as `value`: `hbm_resident_serial`
+(the same serial steps with the batch already in HBM and the results left there: what the PCIe hop
+costs) and `pipelined_qps` (device-resident, two batches in flight: round 1's headline).
+`--force-dist` (under `torch.distributed.run --nproc-per-node 1`) runs the N > 1 code path with one rank:
+the dry run of the multi-GPU bench on a single-GPU box.
 Other workloads (--workload): c4, c3shard, c5shard, c5mini, c2shard8, small, c2f32 — parity /
 sizing cases of BASELINE.json, not the headline line.
 
