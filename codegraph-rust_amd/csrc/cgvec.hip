@@ -120,7 +120,8 @@ float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, i
     const double n_inst = (double)((ld_coarse + k_inst - 1) / k_inst);
     const double mfma = n_inst * (double)(k_inst + 1) * 2.0;
     const double scale = (double)ld_coarse / 64.0 + 12.0;
-    const double ref = metric == CGV_METRIC_COSINE_SEQ ? 2.0 * ld_exact + 4.0 : (double)ld_exact / 4.0 + 10.0;
+    const bool sequential = metric == CGV_METRIC_COSINE_SEQ || metric == CGV_METRIC_COSINE_SCALAR;  // one accumulator per sum
+    const double ref = sequential ? 2.0 * ld_exact + 4.0 : (double)ld_exact / 4.0 + 10.0;
     return (float)((mfma + scale + ref) * u * 1.0001);
 }
 
@@ -530,7 +531,9 @@ void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint
 int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
                  float* out_score, hipStream_t s, int op = -1, bool local_ids = false) {
     const IdMap idmap = local_ids ? IdMap{0, 0, 1, 0, 0} : h->idmap;
-    if (op < 0) op = (h->metric == CGV_METRIC_DOT) ? OP_DOT : (h->metric == CGV_METRIC_COSINE_SEQ ? OP_COSINE_SEQ : OP_COSINE);
+    if (op < 0)
+        op = (h->metric == CGV_METRIC_DOT) ? OP_DOT
+             : (h->metric == CGV_METRIC_COSINE_SEQ ? OP_COSINE_SEQ : (h->metric == CGV_METRIC_COSINE_SCALAR ? OP_COSINE_SCALAR : OP_COSINE));
     const uint64_t n = h->n;
     const uint32_t K = next_pow2(std::max<uint32_t>(k, 2));
     uint64_t qg = std::max<uint64_t>(1, (512ull << 20) / (n * 4));
@@ -1243,7 +1246,8 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (!out) return fail(CGV_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (dim == 0 || dim > 8192) return fail(CGV_ERR_INVALID_ARG, "dim must be in 1..=8192");
-    if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT && metric != CGV_METRIC_COSINE_SEQ)
+    if (metric != CGV_METRIC_COSINE && metric != CGV_METRIC_DOT && metric != CGV_METRIC_COSINE_SEQ &&
+        metric != CGV_METRIC_COSINE_SCALAR)
         return fail(CGV_ERR_INVALID_ARG, "bad metric");
     const bool shadow = dtype == CGV_DTYPE_F32_SHADOW;
     if (shadow) dtype = CGV_DTYPE_F32;  // rows, exact paths and get_row are the f32 index; + a bf16 copy for the coarse pass
@@ -1771,7 +1775,7 @@ static int prep_single_query(cgv_index* h, SearchCtx* c, const float* query_host
 
 int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint64_t limit_rows, float* out_host) {
     if (!h || !query_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
+    if (op < 0 || op > OP_COSINE_SCALAR || op == OP_NEG_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
     if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
     std::unique_lock<std::mutex> lk(h->mu);
@@ -1797,14 +1801,18 @@ int cgv_batch_similarity_f32(cgv_index* h, const float* query_host, int op, uint
     return CGV_OK;
 }
 
-int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host, uint32_t m,
-                      float* out_host) {
+// Shared body of cgv_score_ids_f32 (dense [nq][m] ids, qsel_host == NULL) and cgv_score_pairs_f32_ (pair list).
+static int score_pairs(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint32_t* qsel_host,
+                       const uint64_t* ids_host, uint64_t npairs, uint32_t m, float* out_host) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    if (nq == 0 || m == 0) return CGV_OK;
+    if (nq == 0 || npairs == 0) return CGV_OK;
     if (!queries_host || !ids_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
-    if (op < 0 || op > OP_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
+    if (op < 0 || op > OP_COSINE_SCALAR || op == OP_NEG_COSINE_DISTANCE_SEQ) return fail(CGV_ERR_INVALID_ARG, "unknown op");
     if (h->dtype == CGV_DTYPE_FP8E4M3 && (op == OP_DOT || op == OP_L2))
         return fail(CGV_ERR_INVALID_ARG, "fp8 storage is per-row scaled: only the (scale-invariant) cosine ops");
+    if (qsel_host)
+        for (uint64_t i = 0; i < npairs; ++i)
+            if (qsel_host[i] >= nq) return fail(CGV_ERR_INVALID_ARG, "pair list: query index out of range");
     std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     SearchCtx* c = acquire_ctx(h, lk);
@@ -1813,24 +1821,26 @@ int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int 
     const uint64_t n = h->n;
     auto body = [&]() -> int {
         int r;
-        const size_t qb = (size_t)nq * h->D * 4, ib = (size_t)nq * m * 8, ob = (size_t)nq * m * 4;
+        const size_t qb = (size_t)nq * h->D * 4, ib = (size_t)npairs * 8, ob = (size_t)npairs * 4, sb = qsel_host ? (size_t)npairs * 4 : 0;
         if ((r = c->qstage.ensure(qb))) return r;
         if ((r = c->outidx.ensure(ib))) return r;
         if ((r = c->outscore.ensure(ob))) return r;
+        if (sb && (r = c->qlist.ensure(sb))) return r;
         if ((r = order_after_caller(h, c))) return r;
         lk.unlock();
         HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, qb, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->outidx.p, ids_host, ib, hipMemcpyHostToDevice, s));
-        const uint64_t pairs = (uint64_t)nq * m;
-        const dim3 grid((unsigned)((pairs + 31) / 32)), blk(256);
+        if (sb) HIPCHK(hipMemcpyAsync(c->qlist.p, qsel_host, sb, hipMemcpyHostToDevice, s));
+        const dim3 grid((unsigned)((npairs + 31) / 32)), blk(256);
         const float* qd = c->qstage.as<float>();
         const uint64_t* idd = c->outidx.as<uint64_t>();
+        const uint32_t* qs = sb ? c->qlist.as<uint32_t>() : nullptr;
         float* od = c->outscore.as<float>();
         switch (h->dtype) {
-            case CGV_DTYPE_F32: hipLaunchKernelGGL(score_ids_kernel<DT_F32>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
-            case CGV_DTYPE_BF16: hipLaunchKernelGGL(score_ids_kernel<DT_BF16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
-            case CGV_DTYPE_FP16: hipLaunchKernelGGL(score_ids_kernel<DT_FP16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
-            default: hipLaunchKernelGGL(score_ids_kernel<DT_FP8>, grid, blk, 0, s, (const char*)h->rows, qd, idd, nq, m, n, h->D, h->ld, op, od); break;
+            case CGV_DTYPE_F32: hipLaunchKernelGGL(score_ids_kernel<DT_F32>, grid, blk, 0, s, (const char*)h->rows, qd, idd, qs, npairs, m, n, h->D, h->ld, op, od); break;
+            case CGV_DTYPE_BF16: hipLaunchKernelGGL(score_ids_kernel<DT_BF16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, qs, npairs, m, n, h->D, h->ld, op, od); break;
+            case CGV_DTYPE_FP16: hipLaunchKernelGGL(score_ids_kernel<DT_FP16>, grid, blk, 0, s, (const char*)h->rows, qd, idd, qs, npairs, m, n, h->D, h->ld, op, od); break;
+            default: hipLaunchKernelGGL(score_ids_kernel<DT_FP8>, grid, blk, 0, s, (const char*)h->rows, qd, idd, qs, npairs, m, n, h->D, h->ld, op, od); break;
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out_host, od, ob, hipMemcpyDeviceToHost, s));
@@ -1842,6 +1852,19 @@ int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int 
     if (rc) (void)hipStreamSynchronize(s);
     release_ctx(h, c);
     return rc;
+}
+
+int cgv_score_ids_f32(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host, uint32_t m,
+                      float* out_host) {
+    if (m == 0) return h ? CGV_OK : fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    return score_pairs(h, queries_host, nq, op, nullptr, ids_host, (uint64_t)nq * m, m, out_host);
+}
+
+// internal (sharded.hip): the pairs (query qsel[p], row ids[p]) of one shard, p < npairs; out[p] = the score.
+int cgv_score_pairs_f32_(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint32_t* qsel_host,
+                         const uint64_t* ids_host, uint64_t npairs, float* out_host) {
+    if (npairs && !qsel_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
+    return score_pairs(h, queries_host, nq, op, qsel_host, ids_host, npairs, 1u, out_host);
 }
 
 int cgv_truncate(cgv_index* h, uint64_t n_rows) {

@@ -6,7 +6,7 @@
 namespace cgv {
 
 constexpr int DT_F32 = 0, DT_BF16 = 1, DT_FP16 = 2, DT_FP8 = 3;
-constexpr int METRIC_COSINE = 0, METRIC_DOT = 1, METRIC_COSINE_SEQ = 2;
+constexpr int METRIC_COSINE = 0, METRIC_DOT = 1, METRIC_COSINE_SEQ = 2, METRIC_COSINE_SCALAR = 3;
 
 // ---- sortable keys: larger key == better (score desc, row asc) -----------------
 __host__ __device__ inline uint32_t f2ord(float f) {
@@ -247,6 +247,24 @@ __device__ inline float group8_hsum(float v) {
     return z;
 }
 
+// SIMDVectorOps::cosine_similarity_scalar (simd_ops.rs:257-278): ONE sequential accumulator per sum, separate multiply and
+// add (no FMA), sqrt of the PRODUCT of the squared norms, 0.0 when that is zero. It is what adaptive_cosine_similarity
+// (:281-295) runs for len < 32 on an AVX2 host - and for EVERY length on a host without AVX2 + FMA and on every
+// non-x86_64 host (`#[cfg(not(target_arch = "x86_64"))]`, :291-294; SURVEY.md §4: the authors build on aarch64, where this
+// is the only path that ever runs). CGV_METRIC_COSINE_SCALAR / CGV_OP_COSINE_SCALAR select it for every length.
+template <class RQ, class RC>
+__device__ inline float exact_cosine_scalar(const RQ& q, const RC& c, uint32_t D) {
+    float dp = 0.0f, na = 0.0f, nb = 0.0f;
+    for (uint32_t i = 0; i < D; ++i) {
+        const float x = q.at(i), y = c.at(i);
+        dp = dp + x * y;
+        na = na + x * x;
+        nb = nb + y * y;
+    }
+    const float np = sqrtf(na * nb);
+    return (np == 0.0f) ? 0.0f : dp / np;
+}
+
 template <class RQ, class RC>
 __device__ inline float exact_cosine_group8(const RQ& q, const RC& c, uint32_t D, int l) {
     float result = 0.0f;
@@ -279,15 +297,7 @@ __device__ inline float exact_cosine_group8(const RQ& q, const RC& c, uint32_t D
             result = (np == 0.0f) ? 0.0f : fd / np;
         }
     } else if (l == 0) {  // cosine_similarity_scalar, simd_ops.rs:257-278
-        float dp = 0.0f, na = 0.0f, nb = 0.0f;
-        for (uint32_t i = 0; i < D; ++i) {
-            float x = q.at(i), y = c.at(i);
-            dp = dp + x * y;
-            na = na + x * x;
-            nb = nb + y * y;
-        }
-        float np = sqrtf(na * nb);
-        result = (np == 0.0f) ? 0.0f : dp / np;
+        result = exact_cosine_scalar(q, c, D);
     }
     return result;
 }
@@ -354,11 +364,13 @@ __device__ inline float exact_cosine_seq(const RQ& q, const RC& c, uint32_t D, b
 template <class RQ, class RC>
 __device__ inline float exact_score_group8(int metric, const RQ& q, const RC& c, uint32_t D, int l) {
     if (metric == METRIC_COSINE_SEQ) return l == 0 ? exact_cosine_seq(q, c, D, false) : 0.0f;
+    if (metric == METRIC_COSINE_SCALAR) return l == 0 ? exact_cosine_scalar(q, c, D) : 0.0f;
     return metric == METRIC_DOT ? exact_dot_group8(q, c, D, l) : exact_cosine_group8(q, c, D, l);
 }
 
 constexpr int OP_COSINE = 0, OP_DOT = 1, OP_L2 = 2, OP_COSINE_SEQ = 3, OP_COSINE_DISTANCE_SEQ = 4,
-              OP_NEG_COSINE_DISTANCE_SEQ = 5;  // 5: -(distance), so that "larger is better" orders by distance asc
+              OP_NEG_COSINE_DISTANCE_SEQ = 5,  // 5 (internal): -(distance), so that "larger is better" orders by distance asc
+              OP_COSINE_SCALAR = 6;            // cosine_similarity_scalar for every length (a host without AVX2 / not x86_64)
 
 template <class RQ, class RC>
 __device__ inline float exact_op_group8(int op, const RQ& q, const RC& c, uint32_t D, int l) {
@@ -368,6 +380,7 @@ __device__ inline float exact_op_group8(int op, const RQ& q, const RC& c, uint32
         case OP_COSINE_SEQ: return l == 0 ? exact_cosine_seq(q, c, D, false) : 0.0f;
         case OP_COSINE_DISTANCE_SEQ: return l == 0 ? exact_cosine_seq(q, c, D, true) : 0.0f;
         case OP_NEG_COSINE_DISTANCE_SEQ: return l == 0 ? -exact_cosine_seq(q, c, D, true) : 0.0f;
+        case OP_COSINE_SCALAR: return l == 0 ? exact_cosine_scalar(q, c, D) : 0.0f;
         default: return exact_cosine_group8(q, c, D, l);
     }
 }

@@ -37,14 +37,17 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
 // the row is the stored value upcast to f32 (what get_embedding returns). ids[q][j] == UINT64_MAX or
 // beyond the index -> 0.0 (a missing embedding scores 0.0, search.rs:207-217). 8 lanes per pair.
 template <int DT>
+// qsel == NULL: the dense [nq][m] form (pair p belongs to query p / m); else a PAIR LIST: pair p = (query qsel[p], ids[p]) -
+// what one shard of a cgv_sharded handle scores (only the pairs whose rows it owns, sharded.hip).
 __global__ __launch_bounds__(256) void score_ids_kernel(const char* __restrict__ rows, const float* __restrict__ queries,
-                                                        const uint64_t* __restrict__ ids, uint32_t nq, uint32_t m,
+                                                        const uint64_t* __restrict__ ids, const uint32_t* __restrict__ qsel,
+                                                        uint64_t npairs, uint32_t m,
                                                         uint64_t n, uint32_t D, uint32_t ld, int op,
                                                         float* __restrict__ out) {
     const int l = threadIdx.x & 7;
     const uint64_t pair = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-    if (pair >= (uint64_t)nq * m) return;
-    const uint32_t q = (uint32_t)(pair / m);
+    if (pair >= npairs) return;
+    const uint32_t q = qsel ? qsel[pair] : (uint32_t)(pair / m);
     const uint64_t id = ids[pair];
     float s = 0.0f;
     if (id < n) {  // uniform within the 8-lane group

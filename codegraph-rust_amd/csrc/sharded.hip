@@ -281,6 +281,18 @@ uint64_t shard_count(const cgv_sharded* s, uint64_t n, uint32_t g) {
     return cnt;
 }
 
+// Writers and readers of the shards (add, update_row, get_row, reserve, score_ids) run the shard's single-device API on the
+// CALLING thread while holding s->mu. A batch begun with cgv_sharded_search_begin_f32 holds a search context of every shard on
+// its WORKER thread until cgv_sharded_search_end - which needs s->mu: the shard call would wait for that context forever and
+// nobody could release it. Same answer as the single-device handle: CGV_ERR_BUSY while a batch is in flight.
+int busy_if_in_flight(const cgv_sharded* s, const char* what) {
+    for (const auto& sl : s->slots)
+        if (sl.busy)
+            return fail(CGV_ERR_BUSY, std::string(what) + ": a batch begun with cgv_sharded_search_begin_f32 is in flight - call "
+                                      "cgv_sharded_search_end first");
+    return CGV_OK;
+}
+
 int set_exchange_locked(cgv_sharded* s, int kind) {
     if (s->G <= 1 && !s->force_xch) {
         s->exchange = CGV_EXCHANGE_NONE;
@@ -429,6 +441,7 @@ int cgv_sharded_reserve(cgv_sharded* s, uint64_t total_rows) {
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
+    if (int brc = busy_if_in_flight(s, "cgv_sharded_reserve")) return brc;
     for (uint32_t g = 0; g < s->G; ++g) {
         const int rc = cgv_reserve(s->sh[g]->ix, shard_count(s, total_rows, g));
         if (rc) return rc;
@@ -442,6 +455,7 @@ int cgv_sharded_add_f32(cgv_sharded* s, const float* rows_host, uint64_t n) {
     if (n == 0) return CGV_OK;
     if (!rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     std::lock_guard<std::mutex> lk(s->mu);
+    if (int brc = busy_if_in_flight(s, "cgv_sharded_add_f32")) return brc;
     // pieces of [n0, n0 + n) per shard, in global (= local) order
     struct Piece {
         const float* src;
@@ -504,6 +518,7 @@ int cgv_sharded_update_row_f32(cgv_sharded* s, uint64_t id, const float* row_hos
     if (!s || !row_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
+    if (int brc = busy_if_in_flight(s, "cgv_sharded_update_row_f32")) return brc;
     if (id >= s->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     uint32_t g;
     uint64_t local;
@@ -515,6 +530,7 @@ int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host) {
     if (!s || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
+    if (int brc = busy_if_in_flight(s, "cgv_sharded_get_row_f32")) return brc;
     if (id >= s->n) return fail(CGV_ERR_OUT_OF_RANGE, "row id out of range");
     uint32_t g;
     uint64_t local;

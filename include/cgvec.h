@@ -49,6 +49,11 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_METRIC_DOT 1    /* SIMDVectorOps::dot_product_avx2, simd_ops.rs:149-183 */
 #define CGV_METRIC_COSINE_SEQ 2 /* the sequential dot/(sqrt(na)*sqrt(nb)) cosine of SemanticSearch (search.rs:519-533)
                                   and of the symbol resolver (crates/codegraph-mcp/src/indexer.rs:2965-2979) */
+#define CGV_METRIC_COSINE_SCALAR 3 /* SIMDVectorOps::cosine_similarity_scalar (simd_ops.rs:257-278) for EVERY length: what
+                                  adaptive_cosine_similarity (:281-295) computes on a host WITHOUT AVX2 + FMA and on every
+                                  non-x86_64 host (aarch64: `#[cfg(not(target_arch = "x86_64"))]`, :291-294). Pick it when the
+                                  results must be bit-equal to a reference that runs on such a host; CGV_METRIC_COSINE is
+                                  bit-equal to the reference on an AVX2 host (scalar formula below 32 elements only). */
 
 /* storage dtype of the corpus in HBM (queries are rounded to the same dtype). Results never depend on magnitudes; speed
  * can: rows / queries whose largest magnitude is outside [2^-40, 2^40] (embeddings never are) are answered by the exact scan
@@ -200,6 +205,8 @@ int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host);
 #define CGV_OP_L2 2                  /* SIMDVectorOps::l2_distance_avx2, simd_ops.rs:105-143 */
 #define CGV_OP_COSINE_SEQ 3          /* cosine_similarity, search.rs:519-533 (sequential sums, no FMA) */
 #define CGV_OP_COSINE_DISTANCE_SEQ 4 /* cosine_distance, optimization.rs:404-418 / gpu.rs:324-338 */
+#define CGV_OP_COSINE_SCALAR 6       /* cosine_similarity_scalar, simd_ops.rs:257-278, for every length (see
+                                        CGV_METRIC_COSINE_SCALAR; 5 is reserved) */
 
 /* One query (HOST, f32[dim]) against the first limit_rows stored rows (0 = all), out_host[i] =
  * op(query, row i). Replaces ParallelVectorOps::parallel_batch_similarity (simd_ops.rs:347-358),

@@ -47,6 +47,7 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#include <parallel/algorithm>
 #endif
 
 extern "C" {
@@ -202,32 +203,49 @@ static inline bool pair_before(const Pair& x, const Pair& y) {
     return x.i < y.i;
 }
 
-static void parallel_sort_pairs(std::vector<Pair>& v, int threads) {
-    size_t n = v.size();
+// Full parallel sort (not a k-select), every phase threaded - the shape of rayon's par_sort_unstable_by, which the
+// reference calls on all N (score, index) pairs (simd_ops.rs:376-380). libstdc++'s parallel mode (MCSTL: parallel
+// multiway mergesort, OpenMP) does the splitting, the chunk sorts AND the merges on all threads. pair_before is a strict
+// total order (index breaks score ties), so any correct sort yields the same sequence.
+static void parallel_sort_pairs(Pair* v, size_t n, int threads) {
     if (threads <= 1 || n < 4096) {
-        std::sort(v.begin(), v.end(), pair_before);
+        std::sort(v, v + n, pair_before);
         return;
     }
-    // full parallel sort (not a k-select): chunk sorts + pairwise merges, the
-    // same O(N log N / P) shape as rayon's par_sort_unstable_by.
-    int T = 1;
-    while (T * 2 <= threads) T *= 2;
-    std::vector<size_t> bnd(T + 1);
-    for (int t = 0; t <= T; ++t) bnd[t] = n * (size_t)t / (size_t)T;
-#pragma omp parallel for num_threads(T) schedule(static, 1)
-    for (int t = 0; t < T; ++t) std::sort(v.begin() + bnd[t], v.begin() + bnd[t + 1], pair_before);
-    for (int w = 1; w < T; w *= 2) {
-        int nm = T / (2 * w);
-#pragma omp parallel for num_threads(nm > 0 ? nm : 1) schedule(static, 1)
-        for (int m = 0; m < nm; ++m) {
-            size_t lo = bnd[2 * w * m], mid = bnd[2 * w * m + w], hi = bnd[2 * w * m + 2 * w];
-            std::inplace_merge(v.begin() + lo, v.begin() + mid, v.begin() + hi, pair_before);
-        }
-    }
+#ifdef _OPENMP
+    __gnu_parallel::sort(v, v + n, pair_before, __gnu_parallel::multiway_mergesort_tag(threads));
+#else
+    std::sort(v, v + n, pair_before);
+#endif
 }
 
 float cgo_search_cosine(const float* a, const float* b, size_t len);
 
+// The (score, index) buffer of the calling thread, kept between calls: the reference allocates a fresh Vec per query
+// (`collect()`, simd_ops.rs:366-374), which its allocator serves from a recycled block; re-faulting 16 MB of fresh
+// pages per query (what a new std::vector does here) is not part of the algorithm being timed. Pages are first touched
+// by the thread that fills them (same static schedule as the scoring loop).
+static thread_local Pair* tl_pairs = nullptr;
+static thread_local size_t tl_pairs_cap = 0;
+static thread_local double tl_score_ms = 0.0, tl_sort_ms = 0.0;
+
+static double now_ms() {
+#ifdef _OPENMP
+    return omp_get_wtime() * 1e3;
+#else
+    return 0.0;
+#endif
+}
+
+// timing of the calling thread's last cgo_parallel_top_k: scoring pass / sort (milliseconds)
+void cgo_last_timing(double* score_ms, double* sort_ms) {
+    if (score_ms) *score_ms = tl_score_ms;
+    if (sort_ms) *sort_ms = tl_sort_ms;
+}
+
+// metric: 0 = adaptive cosine (an AVX2 host: simd_ops.rs:281-290), 1 = dot product, 2 = search.rs' sequential cosine,
+// 3 = cosine_similarity_scalar for every length (adaptive_cosine_similarity on a host without AVX2 + FMA or not
+// x86_64 at all, simd_ops.rs:291-294)
 int cgo_parallel_top_k(const float* query, const float* const* rows, uint64_t n, uint64_t dim,
                        uint64_t k, int metric, int threads, uint64_t* out_idx, float* out_score) {
     if (threads <= 0) {
@@ -237,19 +255,32 @@ int cgo_parallel_top_k(const float* query, const float* const* rows, uint64_t n,
         threads = 1;
 #endif
     }
-    std::vector<Pair> sims(n);
+    if (tl_pairs_cap < n) {
+        // raw storage: nothing touches the pages on this thread; the scoring loop below writes every element
+        free(tl_pairs);
+        tl_pairs = (Pair*)malloc(sizeof(Pair) * (size_t)n);
+        tl_pairs_cap = tl_pairs ? (size_t)n : 0;
+        if (!tl_pairs) return -2;
+    }
+    Pair* sims = tl_pairs;
     int has_nan = 0;
+    const double t0 = now_ms();
 #pragma omp parallel for num_threads(threads) schedule(static) reduction(| : has_nan)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         float s = metric == 1   ? cgo_dot_avx2(query, rows[i], dim)
                   : metric == 2 ? cgo_search_cosine(query, rows[i], dim)  // search.rs:519-533 == indexer.rs:2965-2979
+                  : metric == 3 ? cgo_cosine_scalar(query, rows[i], dim)  // simd_ops.rs:257-278 for every length
                                 : cgo_cosine_adaptive(query, rows[i], dim);
         if (s != s) has_nan |= 1;
         sims[i].s = s;
         sims[i].i = (uint64_t)i;
     }
+    const double t1 = now_ms();
+    tl_score_ms = t1 - t0;
+    tl_sort_ms = 0.0;
     if (has_nan) return -1;  // reference panics (simd_ops.rs:379)
-    parallel_sort_pairs(sims, threads);
+    parallel_sort_pairs(sims, (size_t)n, threads);
+    tl_sort_ms = now_ms() - t1;
     uint64_t m = k < n ? k : n;
     for (uint64_t j = 0; j < m; ++j) {
         out_idx[j] = sims[j].i;
@@ -281,9 +312,13 @@ void* cgo_rowset_create(const float* flat, uint64_t n, uint64_t dim) {
     RowSet* rs = new RowSet();
     rs->dim = dim;
     rs->rows.resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
+    // every row is its own heap block (the reference's Vec<f32> per embedding), allocated AND first written by the thread
+    // that scans it in cgo_parallel_top_k (same static schedule): on a multi-socket host the rows are then spread over
+    // the NUMA nodes like the threads, instead of all sitting on the node of the one thread that loaded them
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
         rs->rows[i] = (float*)malloc(sizeof(float) * (dim ? dim : 1));
-        memcpy(rs->rows[i], flat + i * dim, sizeof(float) * dim);
+        memcpy(rs->rows[i], flat + (uint64_t)i * dim, sizeof(float) * dim);
     }
     return rs;
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 F32, BF16, FP16, FP8 = 0, 1, 2, 3
-COSINE, DOT, COSINE_SEQ = 0, 1, 2
+COSINE, DOT, COSINE_SEQ, COSINE_SCALAR = 0, 1, 2, 3   # COSINE_SCALAR: simd_ops.rs:257-278 for every length (non-AVX2 host)
 
 
 def build(force=False):
@@ -52,6 +52,8 @@ def lib():
         L.cgo_rowset_destroy.argtypes = [C.c_void_p]
         L.cgo_rowset_top_k.restype = C.c_int
         L.cgo_rowset_top_k.argtypes = [C.c_void_p, fp, C.c_uint64, C.c_int, C.c_int, u64p, fp]
+        L.cgo_last_timing.restype = None
+        L.cgo_last_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cgo_prefetch_k.restype = C.c_uint64
         L.cgo_prefetch_k.argtypes = [C.c_uint64]
         L.cgo_normalize_scores.restype = None
@@ -181,6 +183,20 @@ class RowSet:
 
     def __del__(self):
         self.close()
+
+
+def last_timing():
+    """(score_ms, sort_ms) of the calling thread's last parallel_top_k / RowSet.top_k."""
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    lib().cgo_last_timing(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def numa_nodes():
+    try:
+        return max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]))
+    except OSError:
+        return 1
 
 
 def prefetch_k(limit):

@@ -14,6 +14,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # an abort / fault inside native code leaves the C-level stack of the raising thread in the log (tests/c_client/abort_bt.c)
+    import faulthandler
+    if not faulthandler.is_enabled():
+        faulthandler.enable()
+    from _util import install_abort_bt
+    install_abort_bt()
 
 
 @pytest.fixture(scope="session")

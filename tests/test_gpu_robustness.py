@@ -225,9 +225,13 @@ def test_pinned_host_buffers_are_used_in_place(oracle):
     buffers go through staging. Every mix must give the oracle's answers - including the batches whose queries take
     the exact-scan fallback (it writes into the caller's pinned arrays too), a non-finite query (error, index intact),
     an f32 index (exact path only), and a registered (hipHostRegister) buffer.
-    Runs in a process of its own: it is the one test that hands hipHostRegister-ed memory to the HIP runtime, and the two
-    aborts the full suite has seen both hit the test that followed it. The child leaves through os._exit
-    once its assertions hold; whatever the runtime does with that memory afterwards stays in the child."""
+    Runs IN THE SUITE'S PROCESS (round 3 moved it into a child after two unexplained aborts of the full suite in the test
+    that followed it; DESIGN.md §9.5 has what the hunt for them found). tests/conftest.py hooks tests/c_client/abort_bt.c into
+    the process, so a recurrence leaves the native stack of the raising thread in the log. CGV_PINNED_CHILD=1 restores the
+    isolated form (a child that leaves through os._exit)."""
+    if not os.environ.get("CGV_PINNED_CHILD"):
+        _pinned_host_buffers_case(oracle)
+        return
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
