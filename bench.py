@@ -55,8 +55,14 @@ WORKLOADS = {
     "c2": (1_000_000, 768, "bf16", "cosine", 1024, 10),
     "c4": (1_000_000, 1536, "fp16", "dot", 256, 10),
     "c3shard": (1_250_000, 768, "bf16", "cosine", 4096, 10),   # one GPU's share of C3 (10M rows / 8)
+    # C3 whole: 10M x 768 bf16 (15.4 GB: fits ONE MI355X 18 times over), batch 4096, 8 row shards - `--sharded-handle 8` on a
+    # 1-GPU box (device 0 listed 8 times), `--gpus 8` on a node
+    "c3": (10_000_000, 768, "bf16", "cosine", 4096, 10),
     "small": (100_000, 768, "bf16", "cosine", 1024, 10),
     "c2shard8": (125_000, 768, "bf16", "cosine", 1024, 10),    # one rank's share of C2 at 8 GPUs (fixed-cost probe)
+    # C2 with HALF the batch: two of these in flight (`pipelined`) are the proxy for running one cgv_search_f32 batch as two
+    # 512-query halves on two contexts (VERDICT r3 'Next' 2b) - DESIGN.md §9 has what it measured
+    "c2half": (1_000_000, 768, "bf16", "cosine", 512, 10),
     # C5 = 500M x 768 fp8 over 8 GPUs, batch 8192: one GPU's share is 62.5M rows = 48 GB of codes
     "c5shard": (62_500_000, 768, "fp8", "cosine", 8192, 10),
     "c5mini": (4_000_000, 768, "fp8", "cosine", 8192, 10),   # same kernel shape, 1/16 of the shard
@@ -152,6 +158,22 @@ def bench_sharded_handle(args, m, dev):
     prev.wait()
     piped = time.perf_counter() - t0
     st = sx.stats()
+    # parity of the merged answer, in the same line: sampled queries through the EXACT device scan of every shard + the same
+    # exchange and merge (ids global across the block-cyclic map) must equal the fast path's answer bit for bit
+    check = None
+    if args.check_queries > 0:
+        nc = min(args.check_queries, batch)
+        fi, fs = sx.search(qhost[0][:nc], k)
+        fb_before = sx.stats()["fallback_queries"]
+        sx.set_force_exact(True)
+        ei, es = sx.search(qhost[0][:nc], k)
+        sx.set_force_exact(False)
+        hits = sum(len(set(ei[q].tolist()) & set(fi[q].tolist())) for q in range(nc))
+        check = {"anchor": "device-exact-scan of every shard + the same merge", "queries": nc,
+                 "recall_at_10": hits / (nc * k),
+                 "ordered_match_rate": float(np.mean([np.array_equal(ei[q], fi[q]) for q in range(nc)])),
+                 "score_bit_exact_rate": float(np.mean([np.array_equal(es[q], fs[q]) for q in range(nc)])),
+                 "fallback_queries_fast_path": int(fb_before)}
     print(json.dumps({
         "metric": "queries_per_sec", "value": round(batch * args.steps / serial, 1), "unit": "queries/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * serial / args.steps, 4),
@@ -164,6 +186,8 @@ def bench_sharded_handle(args, m, dev):
         "two_in_flight": {"queries_per_sec": round(batch * args.steps / piped, 1), "ms_per_batch": round(1e3 * piped / args.steps, 4),
                           "note": "cgv_sharded_search_begin_f32 of batch i + 1 before cgv_sharded_search_end of batch i"},
         "last_exchange_ms": round(float(np.median(xms)), 4), "fallback_queries": int(st["fallback_queries"]),
+        "shard_rows": sx.shard_counts(), "check": check,
+        "recall_at_10": check["recall_at_10"] if check else None,
         "roofline": None, "cpu_baseline": None}), flush=True)
     sx.close()
 
@@ -171,14 +195,20 @@ def bench_sharded_handle(args, m, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 200 for millisecond-scale steps, fewer for the big workloads - VERDICT r3: a 20-step "
+                         "timed region was 28 ms of a 20 s run)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; 3 for the big workloads)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--pipelined-steps", type=int, default=20,
                     help="extra device-resident batches kept `--depth` in flight (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight of the pipelined side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=128)
+    ap.add_argument("--check-queries", type=int, default=32,
+                    help="N > 1 (or --force-dist): queries of one merged batch that rank 0 checks against the CPU oracle over the "
+                         "WHOLE corpus (recall / order / score bits in the same JSON line); corpora too big for the CPU leg are "
+                         "checked against the exact device scan of every shard + merge instead (0 = off)")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed searches before the W warm-up steps until this much wall time has passed: the part clocks "
                          "up over tens of milliseconds of load (a 20-step bench started cold measured 3-5 %% slower launches "
@@ -193,6 +223,11 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="print this rank's RANK/WORLD_SIZE and exit before touching a GPU (CPU test of the self-spawn)")
     args = ap.parse_args()
+    big = args.workload in ("c5shard", "c5mini", "c3", "c3shard")       # steps of 6 - 300 ms
+    if args.steps is None:
+        args.steps = {"c5shard": 5, "c3": 20}.get(args.workload, 50 if big else 200)
+    if args.warmup is None:
+        args.warmup = 3 if big else 10
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_under_launcher(args.gpus))
@@ -225,16 +260,37 @@ def main():
     ix = m.HipKnnIndex(dim, metric=metric, dtype=dtype, device=local_rank)
     ix.reserve(hi - lo)
     ix.set_index_base(lo)
-    want_cpu = (world == 1 and rank == 0 and args.cpu_seconds > 0)
+    want_cpu = (world == 1 and dist is None and rank == 0 and args.cpu_seconds > 0)
+    # N > 1 (or the one-rank dry run): rank 0 checks ONE merged batch against the oracle over the WHOLE corpus, so it keeps
+    # the storage values of every chunk, not only its shard's (VERDICT r3 'Next' #4: the first SCALE line must carry parity)
+    want_check = (dist is not None and rank == 0 and args.check_queries > 0)
     host_chunks = []
     if n_total > 4_000_000:
         want_cpu = False   # the f32 upcast of the corpus would not fit the CPU leg's time/memory bound
+    oracle_fits = n_total <= 4_000_000
     nchunks = (n_total + CHUNK - 1) // CHUNK
     ingest_s, ingest_rows = 0.0, 0
     for c in range(nchunks):
         c_lo, c_hi = c * CHUNK, min(n_total, (c + 1) * CHUNK)
         a, b = max(lo, c_lo), min(hi, c_hi)
         if a >= b:
+            if want_check and oracle_fits:   # a chunk of another rank's shard: rank 0 only needs its values on the host
+                host_chunks.append(storage_values(gen_chunk(c, c_hi - c_lo, dim, dev), dtype).cpu().numpy())
+            continue
+        if want_check and oracle_fits and (a > c_lo or b < c_hi):   # the parts of a straddling chunk that are not mine
+            xf = gen_chunk(c, c_hi - c_lo, dim, dev)
+            if a > c_lo:
+                host_chunks.append(storage_values(xf[: a - c_lo], dtype).cpu().numpy())
+            x = xf[a - c_lo: b - c_lo]
+            torch.cuda.synchronize()
+            ti = time.perf_counter()
+            ix.add(x)
+            ingest_s += time.perf_counter() - ti
+            ingest_rows += b - a
+            host_chunks.append(storage_values(x, dtype).cpu().numpy())
+            if b < c_hi:
+                host_chunks.append(storage_values(xf[b - c_lo:], dtype).cpu().numpy())
+            del x, xf
             continue
         x = gen_chunk(c, c_hi - c_lo, dim, dev)[a - c_lo: b - c_lo]
         torch.cuda.synchronize()
@@ -242,7 +298,7 @@ def main():
         ix.add(x)                      # device f32 rows -> storage dtype + norms + block bounds (synchronous)
         ingest_s += time.perf_counter() - ti
         ingest_rows += b - a
-        if want_cpu:
+        if want_cpu or (want_check and oracle_fits):
             host_chunks.append(storage_values(x, dtype).cpu().numpy())   # rounded-then-upcast values
         del x
     gq = torch.Generator(device=dev).manual_seed(SEED_QUERY)
@@ -268,18 +324,15 @@ def main():
         def step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
             m.cgvec._check(L.cgv_search_f32(ix._h, C.c_void_p(qhost[i % npool].data_ptr()), batch, k, oi_p, os_p))
     else:
-        ev_x0, ev_x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         exchange_ms = []
+        searcher.time_exchange = True
 
-        def step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link, shard search,
-            #                all-gather + merge, D2H
-            li, ls = ix.search_from_pinned(qhost[i % npool], k)   # this rank's shard (ids already global)
-            ev_x0.record()
-            # ONE RCCL all-gather of packed records + merge kernel, which writes the pinned host result arrays in place
-            searcher._exchange(li, ls, k, out=(out_i, out_s))
-            ev_x1.record()
-            torch.cuda.current_stream().synchronize()
-            exchange_ms.append(ev_x0.elapsed_time(ev_x1))
+        def step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link by the shard search,
+            #                its top-k packed on the library's stream, ONE RCCL all-gather of the packed records + the merge
+            #                kernel (writes the pinned host result arrays in place) enqueued behind an event - no host join
+            #                between the search and the collective, ONE synchronisation per batch (ShardedKnn.step_packed)
+            searcher.step_packed(qhost[i % npool], k, out=(out_i, out_s), device=dev)
+            exchange_ms.append(searcher.last_exchange_ms)
 
     if args.settle_ms > 0:   # steady-state clocks before anything is measured (setup, like the index build)
         ts = time.perf_counter()
@@ -336,8 +389,10 @@ def main():
                  "per_rank_shard_rows": [int(r[3]) for r in allr],
                  "per_rank_device": [int(r[4]) for r in allr],
                  "exchange_ms": round(max(r[2] for r in allr), 4),
-                 "exchange": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) of packed 12-byte records "
-                             "+ merge kernel, timed with events on the stream it runs on"}
+                 "redo_batches": searcher.redo_batches,
+                 "exchange": "records packed on the search's stream, torch.distributed all_gather_into_tensor (backend nccl = "
+                             "RCCL) + merge kernel enqueued behind an event (no host join), timed with events on the stream "
+                             "they run on"}
 
     # side measurement: the same SERIAL steps with the query batch already in HBM and the results left in HBM
     # (cgv_search_f32_dev): what the PCIe hop of the host boundary costs per batch
@@ -452,45 +507,103 @@ def main():
                          "max_observed_coarse_err": st["max_observed_err"]},
         }
 
+    def oracle_leg(o, rs, qh, gi, gs, budget_s, max_q):
+        """Time the CPU port on single-query searches (the reference's shape) and compare every answer with the device's."""
+        omet = o.COSINE if metric == "cosine" else o.DOT
+        cores = o.max_threads()
+        for _ in range(3):                    # warm-up: thread pool, the reusable (score, index) buffer's pages
+            rs.top_k(qh[0], k, omet, cores)
+        t0 = time.perf_counter()
+        nqc, hits, ordered, exact_scores, sc_ms, so_ms = 0, 0, 0, 0, 0.0, 0.0
+        while nqc < max_q and (nqc < 4 or time.perf_counter() - t0 < budget_s):
+            ri, rsc = rs.top_k(qh[nqc], k, omet, cores)
+            a, b = o.last_timing()
+            sc_ms += a
+            so_ms += b
+            hits += len(set(ri.tolist()) & set(gi[nqc].tolist()))
+            ordered += int(np.array_equal(ri, gi[nqc]))
+            exact_scores += int(np.array_equal(rsc, gs[nqc]))
+            nqc += 1
+        cpu_t = time.perf_counter() - t0
+        return {"n": nqc, "seconds": cpu_t, "cores": cores, "recall": hits / (nqc * k), "ordered": ordered / nqc,
+                "exact": exact_scores / nqc, "score_ms": sc_ms / nqc, "sort_ms": so_ms / nqc}
+
     if want_cpu:
         from oracle import oracle as o   # CPU baseline + recall checker only
         rows_host = np.concatenate(host_chunks)
         del host_chunks
         rs = o.RowSet(rows_host)
         del rows_host
-        cores = o.max_threads()
         qh = storage_values(qpool[0][:args.cpu_max_queries], dtype).cpu().numpy()
         if dtype == "fp8":   # the torch expression of the storage format must be the oracle's
             assert np.array_equal(qh, o.round_trip(qpool[0][:args.cpu_max_queries].cpu().numpy(), o.FP8, fp8_codes=True))
         gi, gs = ix.search(qpool[0], k)
         gi = gi.cpu().numpy().view(np.uint64)
         gs = gs.cpu().numpy()
-        omet = o.COSINE if metric == "cosine" else o.DOT
-        rs.top_k(qh[0], k, omet, cores)   # warm-up
-        t0 = time.perf_counter()
-        nqc, hits, ordered, exact_scores = 0, 0, 0, 0
-        while nqc < args.cpu_max_queries and (nqc < 4 or time.perf_counter() - t0 < args.cpu_seconds):
-            ri, rsc = rs.top_k(qh[nqc], k, omet, cores)
-            hits += len(set(ri.tolist()) & set(gi[nqc].tolist()))
-            ordered += int(np.array_equal(ri, gi[nqc]))
-            exact_scores += int(np.array_equal(rsc, gs[nqc]))
-            nqc += 1
-        cpu_t = time.perf_counter() - t0
+        leg = oracle_leg(o, rs, qh, gi, gs, args.cpu_seconds, args.cpu_max_queries)
         rs.close()
-        result["cpu_baseline"] = {"value": round(nqc / cpu_t, 3), "unit": "queries/s", "cores": cores,
-                                  "kind": "port",
+        nqc, cpu_t = leg["n"], leg["seconds"]
+        result["cpu_baseline"] = {"value": round(nqc / cpu_t, 3), "unit": "queries/s", "cores": leg["cores"],
+                                  "kind": "port", "numa_nodes": o.numa_nodes(),
+                                  "score_ms": round(leg["score_ms"], 2), "sort_ms": round(leg["sort_ms"], 2),
                                   "sample": f"{nqc} single-query searches over the same {n_total} x {dim} corpus "
-                                            f"(f32 upcast of the {dtype} values, rows separately allocated), "
-                                            f"{cpu_t:.1f} s wall; C++ port of parallel_top_k_search: threaded AVX2 "
-                                            f"scoring + threaded sort whose last merge levels are single-threaded "
-                                            f"(rayon's par_sort_unstable_by is not) - a slight under-estimate"}
-        result["recall_at_10"] = hits / (nqc * k)
-        result["ordered_match_rate"] = ordered / nqc
-        result["score_bit_exact_rate"] = exact_scores / nqc
+                                            f"(f32 upcast of the {dtype} values, rows separately allocated and first touched "
+                                            f"by the threads that scan them), {cpu_t:.1f} s wall; C++ port of "
+                                            f"parallel_top_k_search: threaded AVX2 scoring (score_ms) + a fully parallel sort "
+                                            f"of all (score, index) pairs (sort_ms; libstdc++ parallel multiway mergesort "
+                                            f"standing in for rayon's par_sort_unstable_by), pair buffer reused across queries"}
+        result["recall_at_10"] = leg["recall"]
+        result["ordered_match_rate"] = leg["ordered"]
+        result["score_bit_exact_rate"] = leg["exact"]
         result["recall_sample"] = f"{nqc} of the {batch} queries of one batch"
         result["speedup_vs_cpu_baseline"] = round(result["value"] / (nqc / cpu_t), 1)
     elif rank == 0:
         result["cpu_baseline"] = None
+
+    # N > 1 (and the one-rank dry run): the MERGED result of one batch is checked in the same line (VERDICT r3 'Next' #4)
+    if dist is not None and args.check_queries > 0:
+        ncheck = min(args.check_queries, batch)
+        step(0)                                           # out_i / out_s: merged results of batch 0 (pinned host arrays)
+        gi = out_i.numpy().view(np.uint64)[:ncheck].copy()
+        gs = out_s.numpy()[:ncheck].copy()
+        if oracle_fits:
+            if rank == 0:
+                from oracle import oracle as o   # checker only
+                rows_host = np.concatenate(host_chunks)
+                del host_chunks
+                assert rows_host.shape[0] == n_total
+                rs = o.RowSet(rows_host)
+                del rows_host
+                qh = storage_values(qpool[0][:ncheck], dtype).cpu().numpy()
+                leg = oracle_leg(o, rs, qh, gi, gs, 1e9, ncheck)
+                rs.close()
+                result["recall_at_10"] = leg["recall"]
+                result["ordered_match_rate"] = leg["ordered"]
+                result["score_bit_exact_rate"] = leg["exact"]
+                result["recall_sample"] = (f"{leg['n']} queries of one MERGED batch (all {world} rank(s)' shards, exchange + merge "
+                                           f"included) against the CPU oracle over the whole {n_total}-row corpus")
+                result["check"] = {"anchor": "cpu-oracle", "queries": leg["n"], "oracle_score_ms": round(leg["score_ms"], 2),
+                                   "oracle_sort_ms": round(leg["sort_ms"], 2), "redo_batches": searcher.redo_batches}
+        else:
+            # too big for the CPU leg: every rank answers the same queries by its EXACT device scan (the proven-correct
+            # fallback path, held against the oracle by the -m gpu tests), the partial results are merged through the same
+            # exchange, and the fast path's merged answer must equal that, bit for bit
+            ix.set_force_exact(True)
+            qs = qhost[0][:ncheck].clone().pin_memory()
+            li, ls = ix.search_from_pinned(qs, k)
+            ei, es = searcher._exchange(li, ls, k)
+            ix.set_force_exact(False)
+            torch.cuda.synchronize()
+            if rank == 0:
+                ei = ei.cpu().numpy().view(np.uint64)
+                es = es.cpu().numpy()
+                hits = sum(len(set(ei[q].tolist()) & set(gi[q].tolist())) for q in range(ncheck))
+                result["recall_at_10"] = hits / (ncheck * k)
+                result["ordered_match_rate"] = float(np.mean([np.array_equal(ei[q], gi[q]) for q in range(ncheck)]))
+                result["score_bit_exact_rate"] = float(np.mean([np.array_equal(es[q], gs[q]) for q in range(ncheck)]))
+                result["recall_sample"] = (f"{ncheck} queries of one MERGED batch against the exact device scan of every shard "
+                                           f"+ the same merge (the {n_total}-row corpus is beyond the CPU leg)")
+                result["check"] = {"anchor": "device-exact-scan", "queries": ncheck, "redo_batches": searcher.redo_batches}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

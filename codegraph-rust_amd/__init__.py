@@ -6,7 +6,8 @@ The directory name is not a Python identifier: load it with
 `importlib.import_module("codegraph-rust_amd")`.
 """
 from . import cgvec  # noqa: F401
-from .cgvec import CgvError, HipKnnIndex, PendingSearch, ShardedIndex, build_library, device_count, merge_topk, write_mmap  # noqa: F401
+from .cgvec import (CgvError, HipKnnIndex, PendingSearch, ShardedIndex, build_library, device_count, merge_packed, merge_topk,  # noqa: F401
+                    pack_topk, write_mmap)
 from .sharded import ShardedKnn, shard_range  # noqa: F401
 from . import store  # noqa: F401
 from .i8scan import Int8ScanIndex, quantize_u4, quantize_u8  # noqa: F401

@@ -12,8 +12,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcgvec_hip.so")
+ABLATE_LIB_PATH = os.path.join(_HERE, "lib", "libcgvec_hip_ablate.so")   # `make ABLATE=1`: + ablations, A/B knobs, traces
+if os.environ.get("CGV_LIB_PATH"):      # measurement scripts load the ablate flavour instead of the production library
+    LIB_PATH = os.path.abspath(os.environ["CGV_LIB_PATH"])
 
-METRICS = {"cosine": 0, "dot": 1, "cosine_seq": 2}
+METRICS = {"cosine": 0, "dot": 1, "cosine_seq": 2, "cosine_scalar": 3}
 DTYPES = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3, "f32s": 4}
 
 CGV_OK = 0
@@ -50,12 +53,13 @@ class ShardedStats(C.Structure):
     ]
 
 
-def build_library(force=False):
-    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+def build_library(force=False, ablate=False):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU). ablate=True: the measurement flavour
+    (libcgvec_hip_ablate.so, csrc/Makefile) beside the production library."""
     src_dir = os.path.join(_HERE, "csrc")
     jobs = "-j%d" % max(1, min(9, os.cpu_count() or 1))   # one object per translation unit: they build in parallel
-    subprocess.check_call(["make", "-C", src_dir, "-s", jobs] + (["-B"] if force else []))
-    return LIB_PATH
+    subprocess.check_call(["make", "-C", src_dir, "-s", jobs] + (["ABLATE=1"] if ablate else []) + (["-B"] if force else []))
+    return ABLATE_LIB_PATH if ablate else LIB_PATH
 
 
 _lib = None
@@ -100,10 +104,18 @@ def lib():
     L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
     L.cgv_normalize_rows_f32.argtypes = [i32, vp, u64, u32]
     L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.cgv_host_device_alias.argtypes = [i32, vp, C.c_size_t]
+    L.cgv_host_device_alias.restype = vp
     L.cgv_packed_width.argtypes = [u32]
     L.cgv_packed_width.restype = u32
     L.cgv_pack_topk_dev.argtypes = [i32, vp, vp, u32, u32, vp, vp]
     L.cgv_merge_packed_dev.argtypes = [i32, vp, u32, u32, u32, vp, vp, vp]
+    L.cgv_merge_packed_flag_dev.argtypes = [i32, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.cgv_merge_packed_flag_dev.restype = i32
+    L.cgv_search_packed_begin_f32_dev.argtypes = [vp, vp, u32, u32, vp, vp, C.POINTER(u64)]
+    L.cgv_search_packed_begin_f32_dev.restype = i32
+    L.cgv_search_packed_end.argtypes = [vp, u64, C.POINTER(i32)]
+    L.cgv_search_packed_end.restype = i32
     L.cgv_set_stream.argtypes = [vp, vp]
     L.cgv_use_own_stream.argtypes = [vp]
     L.cgv_synchronize.argtypes = [vp]
@@ -358,16 +370,57 @@ class HipKnnIndex:
         idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
         sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
         if nq and k:
-            _check(lib().cgv_search_f32_dev(self._h, C.c_void_p(q_pinned.data_ptr()), nq, k,
+            # the address the DEVICE reads the pinned batch at (equal to the host address for hipHostMalloc memory, possibly
+            # different for hipHostRegister-ed memory): resolved by the library over the whole range
+            alias = lib().cgv_host_device_alias(self.device, C.c_void_p(q_pinned.data_ptr()), nq * self.dim * 4)
+            if not alias:
+                raise CgvError(CGV_ERR_INVALID_ARG, "search_from_pinned: the batch is not (wholly) pinned / registered host memory")
+            _check(lib().cgv_search_f32_dev(self._h, C.c_void_p(alias), nq, k,
                                             C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr())))
         return idx, sc
+
+    def device_alias(self, t):
+        """Device-visible address of a pinned CPU tensor's storage (cgv_host_device_alias), or the data pointer of a CUDA tensor."""
+        if t.is_cuda:
+            return t.data_ptr()
+        alias = lib().cgv_host_device_alias(self.device, C.c_void_p(t.data_ptr()), t.numel() * t.element_size())
+        if not alias:
+            raise CgvError(CGV_ERR_INVALID_ARG, "the tensor is not (wholly) pinned / registered host memory")
+        return alias
+
+    def search_packed_begin(self, queries, k, rec):
+        """One rank's share of a batch without a host join before the exchange (cgv_search_packed_begin_f32_dev): the shard
+        search is enqueued, its top-k are packed into `rec` (CUDA int32 [nq, packed_width(k)]) on the library's stream, and
+        torch's CURRENT stream is made to wait for them - enqueue the all-gather + merge_packed(..., redo=flag) next and
+        synchronise once. `queries`: CUDA tensor or pinned CPU tensor [nq, dim] f32. Returns the ticket for
+        search_packed_end()."""
+        import torch
+        nq, k = queries.shape[0], int(k)
+        if queries.dim() != 2 or queries.shape[1] != self.dim or queries.dtype != torch.float32 or not queries.is_contiguous():
+            raise CgvError(CGV_ERR_DIM_MISMATCH, f"query batch {tuple(queries.shape)} {queries.dtype} != [nq, {self.dim}] f32")
+        if not rec.is_cuda or rec.dtype != torch.int32 or rec.numel() != nq * packed_width(k) or not rec.is_contiguous():
+            raise CgvError(CGV_ERR_INVALID_ARG, "rec must be a contiguous CUDA int32 tensor of nq * packed_width(k) words")
+        self.use_torch_stream()   # the search orders after what torch queued so far (the producer of a CUDA batch)
+        stream = torch.cuda.current_stream(rec.device).cuda_stream
+        t = C.c_uint64(0)
+        if nq and k:
+            _check(lib().cgv_search_packed_begin_f32_dev(self._h, C.c_void_p(self.device_alias(queries)), nq, k,
+                                                         C.c_void_p(rec.data_ptr()), C.c_void_p(stream), C.byref(t)))
+        return t.value
+
+    def search_packed_end(self, ticket):
+        """Second half: the search's status (a NaN query fails here); True when provisional records were replaced by final
+        ones (the exact scan ran) - the caller repeats the exchange then."""
+        r = C.c_int(0)
+        _check(lib().cgv_search_packed_end(self._h, C.c_uint64(int(ticket)), C.byref(r)))
+        return bool(r.value)
 
     def search_host_ptr(self, q_ptr, nq, k, idx_ptr, score_ptr):
         """cgv_search_f32 on raw HOST pointers (any mix of pinned and pageable buffers): the caller owns the memory."""
         _check(lib().cgv_search_f32(self._h, C.c_void_p(int(q_ptr)), int(nq), int(k), C.c_void_p(int(idx_ptr)),
                                     C.c_void_p(int(score_ptr))))
 
-    OPS = {"cosine": 0, "dot": 1, "l2": 2, "cosine_seq": 3, "cosine_distance_seq": 4}
+    OPS = {"cosine": 0, "dot": 1, "l2": 2, "cosine_seq": 3, "cosine_distance_seq": 4, "cosine_scalar": 6}
 
     def batch_similarity(self, query, op="cosine", limit_rows=0):
         """parallel_batch_similarity / compute_distances_cpu: op(query, row i) for the first rows."""
@@ -479,6 +532,16 @@ class ShardedIndex:
         L = lib()
         return [int(L.cgv_count(C.c_void_p(L.cgv_sharded_shard(self._h, i)))) for i in range(self.n_shards)]
 
+    def set_force_exact(self, flag):
+        """Every shard answers by its exact full scan (cgv_set_force_exact on the shard handles): the anchor of the
+        full-size checks - the fast path's merged answer must equal the merged exact scans, bit for bit."""
+        L = lib()
+        for i in range(self.n_shards):
+            _check(L.cgv_set_force_exact(C.c_void_p(L.cgv_sharded_shard(self._h, i)), 1 if flag else 0))
+
+    def shard_handle(self, i):
+        return C.c_void_p(lib().cgv_sharded_shard(self._h, i))
+
     def shard_stats(self, i):
         s = Stats()
         _check(lib().cgv_get_stats(C.c_void_p(lib().cgv_sharded_shard(self._h, i)), C.byref(s)))
@@ -584,10 +647,12 @@ def pack_topk(idx, score):
     return rec
 
 
-def merge_packed(gathered, k, out=None):
+def merge_packed(gathered, k, out=None, redo=None):
     """[g, nq, packed_width(k)] int32 (the all-gather output) -> merged ([nq, k] int64 ids, f32 scores).
     out = (ids, scores): contiguous [nq, k] int64 / float32 tensors to fill - CUDA tensors, or PINNED CPU tensors,
-    which the merge kernel writes in place (valid once the stream has been synchronised)."""
+    which the merge kernel writes in place (valid once the stream has been synchronised).
+    redo: a one-element int32 tensor (CUDA or pinned CPU, zeroed by the caller) the kernel sets to 1 when any rank's list of
+    any query is PROVISIONAL (cgv_search_packed_begin_f32_dev) - the exchange of the batch must then be repeated."""
     import torch
     g, nq, _ = gathered.shape
     if out is not None:
@@ -599,6 +664,7 @@ def merge_packed(gathered, k, out=None):
         oi = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
         os_ = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
     stream = torch.cuda.current_stream(gathered.device).cuda_stream
-    _check(lib().cgv_merge_packed_dev(gathered.device.index or 0, C.c_void_p(gathered.data_ptr()), g, nq, k,
-                                      C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), C.c_void_p(stream)))
+    _check(lib().cgv_merge_packed_flag_dev(gathered.device.index or 0, C.c_void_p(gathered.data_ptr()), g, nq, k,
+                                           C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()),
+                                           C.c_void_p(redo.data_ptr() if redo is not None else None), C.c_void_p(stream)))
     return oi, os_

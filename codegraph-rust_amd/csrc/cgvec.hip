@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -95,6 +96,10 @@ enum Flag { F_NONFINITE_C = 0, F_NONFINITE_Q, F_FB_COUNT, F_MAXERR, F_NAN, F_COM
 // a search context's flag words are followed by the coarse kernels' pacing words (kernels_coarse.h: Pace), one
 // per workgroup, cleared together with the flags at the start of every search
 constexpr uint32_t PACE_WORDS = 1024;
+// ... and by the rendezvous words of the fused sample + emit launch (kernels_coarse.h: BootSync), 4 per query tile; zero at
+// the start of every search: cleared with the flags, and again by publish_flags_kernel behind a search that used them
+constexpr uint32_t BOOT_WORDS = 4 * 64;
+constexpr uint32_t CTX_FLAG_WORDS = F_COUNT + PACE_WORDS + BOOT_WORDS;
 
 constexpr int BM = 256, BN = 256;  // coarse tile (corpus rows x queries)
 
@@ -128,8 +133,10 @@ float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, i
 // Query tiles per XCD (kernels_coarse.h block_to_work): the largest power of two that keeps their rows
 // (256 x ld x esize bytes each) within ~1.5 MiB of the XCD's 4 MiB L2, and divides nqt. CGV_QGROUP overrides.
 uint32_t query_group(uint32_t nqt, uint32_t ld, int dtype) {
+#ifdef CGV_ABLATE_BUILD
     static const int forced = getenv("CGV_QGROUP") ? atoi(getenv("CGV_QGROUP")) : -1;
     if (forced >= 0) return (uint32_t)forced;
+#endif
     const size_t tile = (size_t)256 * ld * esize_of(dtype);
     uint32_t g = 1;
     while (g * 2 <= nqt && nqt % (g * 2) == 0 && (size_t)(g * 2) * tile <= (3u << 19)) g *= 2;
@@ -150,6 +157,8 @@ uint32_t kprime_of(uint32_t k) {
 struct SearchCtx {
     hipStream_t stream = nullptr;  // owned, non-blocking
     hipEvent_t dep = nullptr;      // ordering after the caller's stream (ingest, query producer)
+    hipEvent_t done = nullptr;     // cgv_search_packed_begin_f32_dev: the consumer stream waits for the packed records on it
+    uint32_t* rec_out = nullptr;   // ... the caller's record buffer of the batch in flight (NULL: not a packed search)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
@@ -166,6 +175,7 @@ struct SearchCtx {
     uint64_t* out_idx = nullptr;
     float* out_score = nullptr;
     bool mfma = false, timed_coarse = false;
+    bool boot_used = false;  // the search in flight used the fused sample + emit launch (its rendezvous words need clearing)
     bool rewrote = false;  // search_finish ran the exact scan and rewrote (some of) the outputs after its first sync
     uint64_t coarse_rows = 0;
     float eps = 0.0f;
@@ -664,17 +674,32 @@ double env_double(const char* name, double dflt) {
     return v ? atof(v) : dflt;
 }
 
-// Planner knobs: defaults, overridden by the environment at load time and by cgv_debug_set_() at run time (in-process
-// A/B measurements: scripts/ab.py).
+// Planner / host knobs. The production library runs on the defaults below, full stop; the measurement flavour
+// (`make ABLATE=1`, CGV_ABLATE_BUILD) also reads them from the environment at load time and lets cgv_debug_set_() change
+// them at run time (in-process A/B: scripts/ab.py).
+#ifdef CGV_ABLATE_BUILD
+#define CGV_ENV_INT(NAME, DFLT) (getenv(NAME) ? atoi(getenv(NAME)) : (DFLT))
+#define CGV_ENV_DBL(NAME, DFLT) env_double(NAME, DFLT)
+#else
+#define CGV_ENV_INT(NAME, DFLT) (DFLT)
+#define CGV_ENV_DBL(NAME, DFLT) (DFLT)
+#endif
 struct Tunables {
+#ifdef CGV_ABLATE_BUILD
     int plan_legacy = getenv("CGV_PLAN") && !strcmp(getenv("CGV_PLAN"), "legacy");
-    int sample_tiles = getenv("CGV_SAMPLE_TILES") ? atoi(getenv("CGV_SAMPLE_TILES")) : 0;    // 0 = automatic
-    int plan_launches = getenv("CGV_PLAN_LAUNCHES") ? atoi(getenv("CGV_PLAN_LAUNCHES")) : 0;  // 0 = cost model
-    double hit_us = env_double("CGV_PLAN_HIT_US", 1.7);
-    double launch_us = env_double("CGV_PLAN_LAUNCH_US", 40.0);
-    int zero_copy = getenv("CGV_ZERO_COPY") ? atoi(getenv("CGV_ZERO_COPY")) : 3;  // pinned host buffers in place: 1 queries, 2 results
-    int epi = getenv("CGV_EPI") ? atoi(getenv("CGV_EPI")) : 1;   // emitting epilogue variant of the bf16 coarse kernel (A/B)
-    int pace = getenv("CGV_NO_PACE") ? 0 : 1;                                      // soft lockstep of the coarse workgroups (Pace)
+    int pace = getenv("CGV_NO_PACE") ? 0 : 1;                 // soft lockstep of the coarse workgroups (Pace)
+#else
+    int plan_legacy = 0;
+    int pace = 1;
+#endif
+    int sample_tiles = CGV_ENV_INT("CGV_SAMPLE_TILES", 0);    // 0 = automatic
+    int plan_launches = CGV_ENV_INT("CGV_PLAN_LAUNCHES", 0);  // 0 = cost model
+    double hit_us = CGV_ENV_DBL("CGV_PLAN_HIT_US", 1.7);
+    double launch_us = CGV_ENV_DBL("CGV_PLAN_LAUNCH_US", 40.0);
+    int zero_copy = CGV_ENV_INT("CGV_ZERO_COPY", 3);          // pinned host buffers in place: 1 queries, 2 results
+    int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
+    int sub_batch = CGV_ENV_INT("CGV_SUB_BATCH", -1);         // cgv_search_f32 as two half batches on two contexts: -1 auto, 0 off, 1 on
+    int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", -1);     // sample + tau + first emitting launch as ONE launch: -1 auto, 0 off, 1 on
 };
 Tunables& tun() {
     static Tunables t;
@@ -750,6 +775,19 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, 
     return p;
 }
 
+// Searches in flight per DEVICE, over every handle of this process (a cgv_sharded handle keeps several cgv_index on one
+// device): the fused sample + emit launch (COARSE_EMIT_BOOT) holds its workgroups at a rendezvous and wants the device to
+// itself, so only a search that finds the device idle takes that form (search_enqueue); the others use the three-launch form,
+// which never waits. (Best effort - another process is invisible here; the rendezvous is bounded for that reason.)
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_dev_inflight[MAX_DEVICES];
+void dev_inflight_add(const cgv_index* h, int d) {
+    if (h->device >= 0 && h->device < MAX_DEVICES) g_dev_inflight[h->device].fetch_add(d, std::memory_order_relaxed);
+}
+int dev_inflight(const cgv_index* h) {
+    return (h->device >= 0 && h->device < MAX_DEVICES) ? g_dev_inflight[h->device].load(std::memory_order_relaxed) : 2;
+}
+
 template <int DT>
 void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, BootMap bmap, hipStream_t s) {
     const uint32_t nrb = (n_boot + 63) / 64, nqb = (nq + 63) / 64;
@@ -777,8 +815,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     c->coarse_rows = 0;
     c->kprime = 0;
     c->published = false;
+    c->boot_used = false;
     // flag + pacing words: zero after a search that ran to completion (its last kernel resets them), else cleared here
-    if (!c->flags_clean) HIPCHK(hipMemsetAsync(c->flags, 0, (F_COUNT + PACE_WORDS) * 4, s));
+    if (!c->flags_clean) HIPCHK(hipMemsetAsync(c->flags, 0, CTX_FLAG_WORDS * 4, s));
     c->flags_clean = false;
     if (h->n == 0) {
         uint64_t tot = (uint64_t)nq * k;
@@ -865,7 +904,23 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         const uint32_t* pace_words = (Wmax <= PACE_WORDS && tun().pace) ? c->flags + F_COUNT : nullptr;
         a.pace = const_cast<uint32_t*>(pace_words);
 
-        if (p.sample_tiles > 0) {
+        // Fused form (round 4): the first emitting launch takes its own first threshold from the first tile of every
+        // workgroup (COARSE_EMIT_BOOT, kernels_coarse.h) - no sample launch, no tau_kernel, the sample tiles scored once. It
+        // holds workgroups at a rendezvous, so it is taken only when this search found the device idle (dev_inflight).
+        const uint32_t nsplit0 = p.counts.empty() ? 0u : std::min<uint32_t>(p.counts[0], nsplit_max);
+        const uint32_t fvals = sample_vals_of(std::max<uint32_t>(nsplit0, 1u));
+        const bool can_fuse = p.sample_tiles > 0 && nsplit0 > 0 && (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) && a.kc >= 4 &&
+                              a.kc % 4 == 0 && nqt > 1 && nqt * 4u <= BOOT_WORDS && nsplit0 * fvals >= 4u * kprime &&
+                              nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 2 * nsplit0;  // (every workgroup walks >= 2 tiles)
+        const int fs = tun().fuse_sample;
+        const bool fuse = can_fuse && (fs > 0 || (fs < 0 && dev_inflight(h) == 1));
+        c->boot_used = fuse;
+        a.tau_out = c->tau.as<float>();
+        a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
+        a.kprime = kprime;
+        if (fuse) {
+            if ((rc = c->dump.ensure((size_t)nq * nsplit0 * fvals * 4))) return rc;
+        } else if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
             const uint32_t vals = sample_vals_of(p.sample_tiles);
             const uint32_t M = p.sample_tiles * vals;
@@ -915,7 +970,16 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             a.pace = (cnt / a.nsplit >= 128u || tun().pace > 1) ? const_cast<uint32_t*>(pace_words) : nullptr;
             const bool dominant = (st + 1 == p.counts.size());
             if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
-            if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s))) return rc;
+            if (st == 0 && fuse) {
+                CoarseArgs fa = a;
+                fa.dump = c->dump.as<float>();
+                fa.sample_vals = fvals;
+                fa.sample_ld = nsplit0 * fvals;
+                fa.pace = nullptr;
+                if ((rc = launch_coarse(cdt, COARSE_EMIT_BOOT, fa, nqt * fa.nsplit, s))) return rc;
+            } else if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s))) {
+                return rc;
+            }
             if (h->profiling && dominant) {
                 HIPCHK(hipEventRecord(c->ev[2], s));
                 c->timed_coarse = true;
@@ -962,7 +1026,11 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.stat_maxeps = c->flags + F_MAXEPS;
         c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
         c->published = true;     // publish_flags_kernel behind the last kernel, below
+#ifdef CGV_ABLATE_BUILD
         static const bool tracing = getenv("CGV_TRACE") != nullptr;  // diagnostics: phase stamps of the final kernel
+#else
+        constexpr bool tracing = false;
+#endif
         r.trace = nullptr;
         if (tracing) {
             if ((rc = c->trace.ensure((size_t)nq * 64))) return rc;
@@ -1010,7 +1078,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         }
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
-                           (uint32_t)F_DONE, nq);
+                           (uint32_t)F_DONE, nq, c->boot_used ? c->flags + F_COUNT + PACE_WORDS : (uint32_t*)nullptr,
+                           c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u);
         HIPCHK(hipGetLastError());
     }
     if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1024,14 +1093,28 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 // Wait for a stream: poll for up to CGV_SPIN_US microseconds (default 3000; 0 = never) before blocking. A
 // batch takes ~1.5 ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it.
 // Device-visible alias of a pinned / registered HOST pointer, or NULL (pageable memory, device memory, unknown).
-void* device_alias(const void* p) {
+// The WHOLE range [p, p + bytes) must be pinned / registered and map to one contiguous device range: a buffer that is only
+// partly registered, or that starts inside a pinned allocation and runs past its end, is staged like pageable memory
+// instead of letting a kernel fault on its tail.
+void* device_alias(const void* p, size_t bytes) {
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    return (at.type == hipMemoryTypeHost) ? at.devicePointer : nullptr;
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    if (bytes > 1) {
+        hipPointerAttribute_t last;
+        memset(&last, 0, sizeof(last));
+        if (hipPointerGetAttributes(&last, (const char*)p + (bytes - 1)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (last.type != hipMemoryTypeHost || (const char*)last.devicePointer != (const char*)at.devicePointer + (bytes - 1))
+            return nullptr;
+    }
+    return at.devicePointer;
 }
 
 int wait_stream(hipStream_t s) {
@@ -1137,6 +1220,7 @@ SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk, bool spli
     got->split = split;
     got->owner = me;
     got->gen++;
+    dev_inflight_add(h, +1);
     return got;
 }
 
@@ -1145,6 +1229,7 @@ void release_ctx(cgv_index* h, SearchCtx* c) {
         std::lock_guard<std::mutex> lk(h->mu);
         c->busy = false;
     }
+    dev_inflight_add(h, -1);
     h->cv.notify_all();
 }
 
@@ -1187,9 +1272,7 @@ int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""
 
 const char* cgv_last_error(void) { return g_err.c_str(); }
 
-// internal (tests, scripts): the launch plan of a search over n rows with nq queries and k results on a device with
-// n_cu compute units. out[0] = tiles of the sample launch (0: dense boot stage), out[1] = number of emitting
-// launches m, out[2 .. 2+m) = tiles per launch. Returns the number of words written (0 if cap is too small).
+#ifdef CGV_ABLATE_BUILD   // measurement flavour only (make ABLATE=1)
 // internal (scripts): diagnostics of the last search on context `ctx` (CGV_TRACE=1): host timeline of cgv_search_f32
 // in microseconds since entry {order, H2D enqueued, pipeline enqueued, D2H enqueued, stream done} and the final
 // kernel's per-query phase stamps (100 MHz ticks: start, keys gathered, top-k' extracted, rows staged, scored, sorted, end)
@@ -1217,10 +1300,16 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "zero_copy")) t.zero_copy = (int)v;
     else if (!strcmp(key, "pace")) t.pace = (int)v;
     else if (!strcmp(key, "epi")) t.epi = (int)v;
+    else if (!strcmp(key, "sub_batch")) t.sub_batch = (int)v;
+    else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else return -1;
     return 0;
 }
+#endif  // CGV_ABLATE_BUILD
 
+// internal (tests, scripts): the launch plan of a search over n rows with nq queries and k results on a device with
+// n_cu compute units. out[0] = tiles of the sample launch (0: dense boot stage), out[1] = number of emitting
+// launches m, out[2 .. 2+m) = tiles per launch. Returns the number of words written (0 if cap is too small).
 uint32_t cgv_debug_plan_(uint64_t n, uint32_t k, uint32_t nq, uint32_t n_cu, int shadow, uint32_t* out, uint32_t cap) {
     const uint32_t kprime = shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
     const uint32_t nqt = (nq + BN - 1) / BN;
@@ -1282,11 +1371,12 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     for (SearchCtx& c : h->ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
-        if (e == hipSuccess) e = hipMalloc((void**)&c.flags, (F_COUNT + PACE_WORDS) * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_flags_dev, c.h_flags, 0);
-        if (e == hipSuccess) e = hipMemset(c.flags, 0, (F_COUNT + PACE_WORDS) * 4);
+        if (e == hipSuccess) e = hipMemset(c.flags, 0, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) c.flags_clean = true;
     }
     if (e == hipSuccess) e = hipMemset(h->flags, 0, F_COUNT * 4);
@@ -1322,6 +1412,7 @@ int cgv_destroy(cgv_index* h) {
         if (c.flags) (void)hipFree(c.flags);
         if (c.h_flags) (void)hipHostFree(c.h_flags);
         if (c.dep) (void)hipEventDestroy(c.dep);
+        if (c.done) (void)hipEventDestroy(c.done);
         for (int i = 0; i < 4; ++i)
             if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1625,6 +1716,7 @@ int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq
     if (rc) {
         (void)hipStreamSynchronize(c->stream);
         c->busy = false;
+        dev_inflight_add(h, -1);
         lk.unlock();
         h->cv.notify_all();
         return rc;
@@ -1652,6 +1744,89 @@ int cgv_search_end(cgv_index* h, uint64_t ticket) {
 
 uint32_t cgv_max_batches_in_flight(const cgv_index* h) { return h ? (uint32_t)N_CTX : 0u; }
 
+// ---- join-free exchange (one process per GPU) -------------------------------------------------------
+// Round 3 joined the host on the shard search, THEN launched pack / all-gather / merge onto an idle GPU (0.09-0.14 ms per
+// batch at C2, profiles/r03_c2_force_dist_bench.json). Here the records are packed on the search's own stream right behind
+// its last kernel and the consumer stream is made to wait for them with an event: the caller enqueues the collective and
+// the merge while the coarse kernel is still running and synchronises once. Queries the device could not prove travel as
+// PROVISIONAL records (pack_topk_kernel); cgv_search_packed_end re-runs them through the exact scan and re-packs.
+static void launch_pack(const uint64_t* idx, const float* score, uint32_t nq, uint32_t k, uint32_t* rec, const uint32_t* prov,
+                        uint32_t prov_all, hipStream_t s) {
+    const uint64_t total = (uint64_t)nq * packed_width(k);
+    hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)std::min<uint64_t>(1024, (total + 255) / 256)), dim3(256), 0, s, idx, score,
+                       nq, k, rec, prov, prov_all);
+}
+
+int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint32_t* rec_out_dev,
+                                    void* consumer_stream, uint64_t* ticket) {
+    if (!ticket) return fail(CGV_ERR_INVALID_ARG, "ticket is NULL");
+    *ticket = 0;
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || k == 0) return CGV_OK;
+    int rc = check_search_args(h, queries_dev, k, rec_out_dev, rec_out_dev);
+    if (rc) return rc;
+    std::unique_lock<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    SearchCtx* c = acquire_ctx(h, lk, /*split=*/true);
+    if (!c)
+        return fail(CGV_ERR_BUSY, "this thread already holds all " + std::to_string(N_CTX) +
+                                      " search contexts of the handle: call cgv_search_packed_end on one of its tickets first");
+    auto body = [&]() -> int {
+        int r;
+        if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
+        if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
+        if ((r = order_after_caller(h, c))) return r;
+        if ((r = search_enqueue(h, c, queries_dev, nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>()))) return r;
+        // exact-scan-only batches (f32 index, forced exact, k beyond the fast path) are produced by search_finish: every
+        // record is provisional. An empty index pads its results at enqueue time: final.
+        const bool all_prov = !c->mfma;
+        launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), nq, k, rec_out_dev,
+                    c->mfma && h->n ? c->fbflag.as<uint32_t>() : nullptr, all_prov ? 1u : 0u, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->done, c->stream));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)consumer_stream, c->done, 0));
+        return CGV_OK;
+    };
+    rc = body();
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        c->busy = false;
+        dev_inflight_add(h, -1);
+        lk.unlock();
+        h->cv.notify_all();
+        return rc;
+    }
+    c->rec_out = rec_out_dev;
+    *ticket = ((uint64_t)c->gen << 8) | (uint64_t)((c - h->ctx) + 1);
+    return CGV_OK;
+}
+
+int cgv_search_packed_end(cgv_index* h, uint64_t ticket, int* repacked) {
+    if (repacked) *repacked = 0;
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (ticket == 0) return CGV_OK;
+    const uint64_t slot = (ticket & 0xff);
+    if (slot == 0 || slot > (uint64_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "bad ticket");
+    SearchCtx* c = &h->ctx[slot - 1];
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!c->busy || c->gen != (uint32_t)(ticket >> 8) || !c->rec_out) return fail(CGV_ERR_INVALID_ARG, "stale ticket");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = search_finish(h, c);
+    if (rc == CGV_OK && c->rewrote) {  // the exact scan replaced (some of) the results: final records now
+        launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), c->nq, c->k, c->rec_out, nullptr, 0u, c->stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(CGV_ERR_HIP, std::string("re-pack: ") + hipGetErrorString(e));
+        if (repacked) *repacked = 1;
+    }
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    c->rec_out = nullptr;
+    release_ctx(h, c);
+    return rc;
+}
+
 int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint64_t* out_idx_dev,
                        float* out_score_dev) {
     uint64_t t = 0;
@@ -1671,7 +1846,11 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     SearchCtx* c = acquire_ctx(h, lk);
     if (!c) return fail(CGV_ERR_BUSY, "this thread holds every search context of the handle (cgv_search_begin without cgv_search_end)");
     hipStream_t s = c->stream;
+#ifdef CGV_ABLATE_BUILD
     static const bool tracing = getenv("CGV_TRACE") != nullptr;
+#else
+    constexpr bool tracing = false;
+#endif
     const auto t_in = std::chrono::steady_clock::now();
     auto stamp = [&](int i) {
         if (tracing) c->host_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
@@ -1682,9 +1861,9 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         // the f32 batch over PCIe while it converts, the last kernel writes ids and scores straight into the caller's
         // arrays - no staging copies, no copy-engine launches on the critical path (r03a: -60 us per C2 step).
         // Pageable buffers go through the context's staging buffers as before.
-        const float* qsrc = (tun().zero_copy & 1) ? (const float*)device_alias(queries_host) : nullptr;
-        uint64_t* oi = (tun().zero_copy & 2) ? (uint64_t*)device_alias(out_idx_host) : nullptr;
-        float* os = oi ? (float*)device_alias(out_score_host) : nullptr;
+        const float* qsrc = (tun().zero_copy & 1) ? (const float*)device_alias(queries_host, (size_t)nq * h->D * 4) : nullptr;
+        uint64_t* oi = (tun().zero_copy & 2) ? (uint64_t*)device_alias(out_idx_host, (size_t)nq * k * 8) : nullptr;
+        float* os = oi ? (float*)device_alias(out_score_host, (size_t)nq * k * 4) : nullptr;
         const bool direct_out = oi && os;
         if (!qsrc && (r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
         if (!direct_out) {
@@ -1952,6 +2131,14 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
 
 uint32_t cgv_packed_width(uint32_t k) { return packed_width(k); }
 
+void* cgv_host_device_alias(int device_id, const void* host_ptr, size_t bytes) {
+    if (!host_ptr || hipSetDevice(device_id) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return device_alias(host_ptr, bytes);
+}
+
 int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t nq, uint32_t k,
                       uint32_t* out_rec_dev, void* stream) {
     if (nq == 0 || k == 0) return CGV_OK;
@@ -1964,28 +2151,35 @@ int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score
     return CGV_OK;
 }
 
-int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
-                         uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
+int cgv_merge_packed_flag_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
+                              uint64_t* out_idx_dev, float* out_score_dev, uint32_t* redo_flag_dev, void* stream) {
     if (nq == 0 || k == 0) return CGV_OK;
     if (!rec_dev || !out_idx_dev || !out_score_dev || g == 0) return fail(CGV_ERR_INVALID_ARG, "bad argument");
     if (g > 64) return fail(CGV_ERR_INVALID_ARG, "more than 64 partial lists per query");
     HIPCHK(hipSetDevice(device_id));
-    // pinned HOST result arrays are written in place by the merge kernel (no D2H copies for the caller to enqueue)
-    if (void* al = device_alias(out_idx_dev)) out_idx_dev = (uint64_t*)al;
-    if (void* al = device_alias(out_score_dev)) out_score_dev = (float*)al;
+    // pinned HOST result arrays (and redo word) are written in place by the merge kernel (no D2H copies for the caller to enqueue)
+    if (void* al = device_alias(out_idx_dev, (size_t)nq * k * 8)) out_idx_dev = (uint64_t*)al;
+    if (void* al = device_alias(out_score_dev, (size_t)nq * k * 4)) out_score_dev = (float*)al;
+    if (redo_flag_dev)
+        if (void* al = device_alias(redo_flag_dev, 4)) redo_flag_dev = (uint32_t*)al;
     const uint64_t stride = (uint64_t)packed_width(k) * 4;
     if ((uint64_t)g * k > 4096) {  // beyond the LDS merge: G-way wave merge (any k)
         hipLaunchKernelGGL(merge_topk_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)rec_dev, stride,
-                           (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k, out_idx_dev, out_score_dev);
+                           (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k, out_idx_dev, out_score_dev, redo_flag_dev);
         HIPCHK(hipGetLastError());
         return CGV_OK;
     }
     const uint32_t P = next_pow2(std::max<uint32_t>(g * k, 2));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), (size_t)P * 16, (hipStream_t)stream,
                        (const char*)rec_dev, stride, (const char*)rec_dev + (uint64_t)k * 8, stride, g, nq, k,
-                       out_idx_dev, out_score_dev);
+                       out_idx_dev, out_score_dev, redo_flag_dev);
     HIPCHK(hipGetLastError());
     return CGV_OK;
+}
+
+int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
+                         uint64_t* out_idx_dev, float* out_score_dev, void* stream) {
+    return cgv_merge_packed_flag_dev(device_id, rec_dev, g, nq, k, out_idx_dev, out_score_dev, nullptr, stream);
 }
 
 int cgv_set_stream(cgv_index* h, void* stream) {
@@ -2104,6 +2298,9 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.sample_ld = 0;
     a.sample_vals = 16;
     a.epi = 1;
+    a.tau_out = nullptr;
+    a.boot_sync = nullptr;
+    a.kprime = 0;
     if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;

@@ -4,6 +4,10 @@
 namespace cgv {
 int coarse_attrs_bf16() { return coarse_attrs_2byte<DT_BF16>(); }
 int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+#ifdef CGV_ABLATE_BUILD   // `make ABLATE=1`: + the timing-only ablations and the A/B reference instantiations
     return launch_coarse_2byte<DT_BF16, true>(mode, a, W, s);
+#else
+    return launch_coarse_2byte<DT_BF16, false>(mode, a, W, s);
+#endif
 }
 }  // namespace cgv

@@ -46,9 +46,15 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
         hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_SAMPLE>, dim3(W), dim3(512), lds, s, a);
         return status("coarse_fp8s_kernel (sample)");
     }
+    if (mode != COARSE_EMIT) return cgv_set_error_(CGV_ERR_INTERNAL, "fp8 coarse kernels: unknown launch mode");
     // one wave per SIMD (even kc >= 4) or the 8-wave kernel (CGV_COARSE=w8, other kc)
+#ifdef CGV_ABLATE_BUILD
     static const bool w8 = getenv("CGV_COARSE") && !strcmp(getenv("CGV_COARSE"), "w8");
+#else
+    constexpr bool w8 = false;
+#endif
     if (!w8 && a.kc >= 4 && (a.kc & 1u) == 0) {
+#ifdef CGV_ABLATE_BUILD
         static const int abl4 = getenv("CGV_ABLATE_W4") ? atoi(getenv("CGV_ABLATE_W4")) : 0;  // timing only
         if (abl4) {
 #define CGV_ABLK4(N)                                                           \
@@ -65,6 +71,7 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
 #undef CGV_ABLK4
             return status("coarse_fp8s_w4_kernel (ablation)");
         }
+#endif
         if (a.kc % 4 == 0 && (a.epi & 8u) == 0) {   // static issue side, ring-unrolled (epi bit 3 = the dynamic form, for A/B)
             hipLaunchKernelGGL((coarse_fp8s_w4_kernel<0, 2>), dim3(W), dim3(256), lds, s, a);
             return status("coarse_fp8s_w4_kernel (si)");

@@ -35,6 +35,7 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>))) return rc;
     return CGV_OK;
 }
 
@@ -49,6 +50,12 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     if (mode == COARSE_SAMPLE) {
         hipLaunchKernelGGL((coarse_kernel<DT, COARSE_SAMPLE>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (sample)");
+    }
+    if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (cgvec.hip: can_fuse)
+        if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.tau_out && a.dump && a.cnt >= 2 * a.nsplit))
+            return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT launched on a shape it does not serve");
+        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (emit + boot)");
     }
     if constexpr (ABLATE) {
         // results are wrong when set: only the launch time means anything

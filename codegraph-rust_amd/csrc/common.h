@@ -409,6 +409,67 @@ __device__ inline uint32_t wave_max_u32(uint32_t x) {
     const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+// The k-th largest of M <= 1024 floats, by ONE WAVE (result uniform; -inf when fewer than k values exist; -inf entries =
+// "no value"). Values only, as 32-bit ordered keys: <= 16 per lane sorted in registers by a bitonic network, then k rounds
+// of wave maximum + pop. Used for the first threshold of a search: d[] holds maxima of DISJOINT groups of
+// corpus rows, so the k'-th largest of them is a score that at least k' distinct rows reach - by tau_kernel (its own
+// launch) and inside the fused sample + emit launch of the coarse kernel (kernels_coarse.h, COARSE_EMIT_BOOT). d is read
+// with plain vector loads: a caller that reads values other workgroups wrote in the same launch acquires first.
+__device__ inline void cmpx_desc32(uint32_t& x, uint32_t& y) {
+    const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
+    x = hi;
+    y = lo;
+}
+__device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k, int lane) {
+    uint32_t r[16];
+    // lane l owns elements 4l..4l+3 of every 256-element slab (16-byte loads, coalesced); M <= 1024
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t e = 256u * j + 4u * (uint32_t)lane;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (e + 3 < M) {
+            v = *(const float4*)(d + e);
+        } else {
+            if (e < M) v.x = d[e];
+            if (e + 1 < M) v.y = d[e + 1];
+            if (e + 2 < M) v.z = d[e + 2];
+        }
+        // NaN never occurs (non-finite inputs are rejected); -inf = "no row": key 0x007fffff, never 0
+        r[4 * j] = f2ord(v.x + 0.0f);
+        r[4 * j + 1] = f2ord(v.y + 0.0f);
+        r[4 * j + 2] = f2ord(v.z + 0.0f);
+        r[4 * j + 3] = f2ord(v.w + 0.0f);
+    }
+    // bitonic sorting network on 16 registers, descending
+#pragma unroll
+    for (int k2 = 2; k2 <= 16; k2 <<= 1)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    if ((i & k2) == 0) cmpx_desc32(r[i], r[ixj]);
+                    else cmpx_desc32(r[ixj], r[i]);
+                }
+            }
+    const uint32_t none = f2ord(-INFINITY);   // "no value" entries never count
+    uint32_t cnt = 0, last = 0;
+    while (cnt < k) {
+        const uint32_t w = wave_max_u32(r[0]);
+        if (w <= none) break;  // fewer than k values
+        const bool own = (r[0] == w);
+        cnt += (uint32_t)__popcll(__ballot(own));  // equal values in several lanes count once each
+        last = w;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) r[i] = r[i + 1];
+            r[15] = 0u;
+        }
+    }
+    return (cnt >= k) ? ord2f(last) : -INFINITY;
+}
+
 // 64-bit max as two 32-bit phases (high word, then low word among the lanes that hold it).
 __device__ inline uint64_t wave_max_u64(uint64_t k) {
     const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;

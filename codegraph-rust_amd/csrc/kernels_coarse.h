@@ -102,6 +102,10 @@ struct CoarseArgs {
     uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump`
     uint32_t sample_vals;   // SAMPLE mode: group maxima per (query, tile): 16, 8 or 4 (tile_epilogue)
     uint32_t epi;           // A/B switches (scripts/ab.py): bit 0 clear = round-2 epilogue (bf16 build only); bit 1 = no NT hint
+    // COARSE_EMIT_BOOT (the fused sample + first emitting launch, BootSync below)
+    float* tau_out;         // [nq] the first thresholds, written by the launch itself
+    uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
+    uint32_t kprime;        // the threshold is the k'-th largest group maximum
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -428,6 +432,57 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
     }
 }
 
+// ---- COARSE_EMIT_BOOT: sample + first threshold + first emitting pass in ONE launch (round 4) ----------
+// Round 3 spent three launches on the first threshold: a sample launch (one tile per workgroup, block maxima only), tau_kernel,
+// then the first emitting launch, which scored the sample tiles AGAIN - 32 + 7 us + two launch boundaries + a second ramp per
+// batch, and 13 % of a 125 k-row shard scored twice. Here every workgroup scores the FIRST tile of its walk, keeps the
+// accumulators in its registers, publishes the tile's group maxima, and meets the other workgroups of its QUERY TILE (they are
+// the only ones whose maxima its queries need: nsplit <= 64 workgroups) at a rendezvous; each then computes the threshold of
+// its share of the tile's 256 queries (kth_largest_wave over the nsplit x 16 maxima), a second rendezvous makes all 256
+// thresholds visible, and the kept accumulators are filtered with them - the walk continues as an ordinary emitting launch.
+// Rendezvous = one monotonic arrival counter per query tile and phase (release fence -> relaxed agent-scope add; ONE wave
+// polls with relaxed loads + s_sleep, the others wait at s_barrier; acquire fence after - MI355X_MICROARCH.md, row
+// barrier-counter; the groups are 16-64 workgroups, not the grid).
+// It needs the group co-resident, which a plain launch cannot promise (another process' kernel, a second batch in flight on
+// the device): every wait is BOUNDED (BOOT_TIMEOUT_TICKS of the 100 MHz wall clock). A workgroup that times out raises the
+// group's `degraded` word - every later wait of the group ends on it - marks its 256 queries `overflow` (the final kernel
+// sends them through the exact scan: correct, slow) and walks on with an infinite threshold. Nothing hangs, nothing is wrong.
+constexpr uint64_t BOOT_TIMEOUT_TICKS = 200000;  // 2 ms
+struct BootSync {
+    uint32_t* arrive_a;   // workgroups whose maxima are published
+    uint32_t* arrive_b;   // workgroups whose thresholds are published
+    uint32_t* degraded;   // != 0: somebody gave up waiting
+};
+__device__ inline BootSync boot_sync_of(const CoarseArgs& a, uint32_t qt) {
+    return BootSync{a.boot_sync + 4u * qt, a.boot_sync + 4u * qt + 1u, a.boot_sync + 4u * qt + 2u};
+}
+// The threshold computation of one workgroup's share of its query tile (boot_block runs it with the accumulators STASHED in
+// global memory: with 128 accumulators live across it the kernel went over 256 VGPRs and the allocator spilled values that the
+// cold hit paths of the WHOLE kernel then reloaded from scratch - behind a vmcnt(0), i.e. behind the DMA in flight).
+__device__ inline void boot_thresholds(const float* dump, float* tau_out, uint32_t sample_ld, uint32_t kprime,
+                                                          uint32_t q0, uint32_t qstep, uint32_t qend, uint32_t nq, int lane) {
+    for (uint32_t q = q0; q < qend && q < nq; q += qstep) {
+        const float t = kth_largest_wave(dump + (uint64_t)q * sample_ld, sample_ld, kprime, lane);
+        if (lane == 0) __hip_atomic_store(tau_out + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ONE lane: arrive (the caller's data was released by a fence + s_waitcnt before) and wait for `need` arrivals.
+// Returns false when the group is degraded (timeout here or elsewhere).
+__device__ inline bool boot_rendezvous(uint32_t* counter, uint32_t* degraded, uint32_t need) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if (__hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (wall_clock64() - t0 > BOOT_TIMEOUT_TICKS) {
+            __hip_atomic_store(degraded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // MODE: COARSE_EMIT / COARSE_DUMP / COARSE_SAMPLE (coarse_launch.h; tile_epilogue).
 // ABL: timing-only ablation mask for scripts/gpu_ablate.sh / gpu_clock.sh (results are WRONG for ABL != 0):
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
@@ -454,6 +509,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
     constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;  // one stage = one 64-byte K chunk of A and B
+    constexpr bool EMIT = (MODE == 0 || MODE == 3);           // 3 = COARSE_EMIT_BOOT: emits like 0 after its first tile
     constexpr int NSTAGE = 4, NINV = 8;                       // stage ring; per-tile side-data ring
     typedef typename Mfma<DT>::frag frag;
 
@@ -478,7 +534,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     for (int nb = 0; nb < NB; ++nb) {
         const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
         const bool valid = q < a.nq;
-        const float tau = valid ? a.tau[q] : INFINITY;
+        const float tau = (MODE == 3) ? INFINITY : (valid ? a.tau[q] : INFINITY);  // MODE 3: no threshold yet (boot_block)
         const float iq = (a.metric == METRIC_DOT) ? 1.0f : (valid ? a.invn_q[q] : 0.0f);
         tauv[nb] = tau;
         invq[nb] = iq;
@@ -780,9 +836,112 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_THR(2, 0, mn4.z, mx4.z) CGV_THR(2, 1, mn4.z, mx4.z) CGV_THR(3, 0, mn4.w, mx4.w) CGV_THR(3, 1, mn4.w, mx4.w) \
     }
 
+    // COARSE_EMIT_BOOT: runs ONCE, at the workgroup's first tile boundary (or in the tail of a one-tile walk), between the
+    // tile's last MFMA and its filters; `tile0` / `inv0` / `stat0` = the first tile and its side data. See BootSync above.
+    __shared__ uint32_t boot_ok_s;
+    auto boot_block = [&](uint32_t tile0, const float* inv0, const float* stat0) __attribute__((always_inline)) {
+        if constexpr (MODE == 3) {
+            const BootSync bs = boot_sync_of(a, qt);
+            // (1) block by block: the block's contribution to the tile's group maxima (tile_epilogue's SAMPLE layout: 16 / 8 / 4
+            // values per (query, tile) at a.dump[q][split * vals ..]), then the block's 16 accumulators go to the STASH - the
+            // first tile's accumulators wait out the rendezvous in GLOBAL memory, not in registers (with 128 accumulators live
+            // across it the kernel went over 256 VGPRs and the allocator spilled values that the cold hit paths of the WHOLE
+            // kernel then reloaded from scratch, behind a vmcnt(0) = behind the DMA in flight). The stash is the workgroup's own
+            // candidate-list region, still empty: nothing is emitted before the first threshold exists. 32 coalesced 16-byte
+            // stores per lane, 32 loads afterwards: ~256 KiB per workgroup through the L2, once per launch.
+            float4* stash = (float4*)(a.cand + (uint64_t)g * BN * CAND_CAPS) + (uint32_t)wave * 2048u + (uint32_t)lane;
+            const uint32_t lg = (uint32_t)(wm * 2 + (lane >> 5));  // the lane's row group within the tile: 0..3
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float m[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    float mm = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t rl = (uint32_t)(wm * WTM + mb * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (uint32_t)(lane >> 5);
+                        const float sc = (a.metric == METRIC_DOT) ? acc[mb][nb][r] : acc[mb][nb][r] * inv0[rl];
+                        if (tile0 * (uint32_t)BM + rl < a.n) mm = fmaxf(mm, sc);
+                    }
+                    m[mb] = (mm == -INFINITY) ? -INFINITY : mm * invq[nb];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        stash[((mb * NB + nb) * 4 + r4) * 64] = make_float4(acc[mb][nb][4 * r4], acc[mb][nb][4 * r4 + 1],
+                                                                             acc[mb][nb][4 * r4 + 2], acc[mb][nb][4 * r4 + 3]);
+                    asm volatile("" ::: "memory");   // block by block, in this order
+                }
+                const uint32_t q = qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
+                if (q < a.nq) {
+                    float* dst = a.dump + (uint64_t)q * a.sample_ld + split * a.sample_vals;
+                    if (a.sample_vals == 16u) {
+                        *(float4*)(dst + lg * 4u) = make_float4(m[0], m[1], m[2], m[3]);
+                    } else if (a.sample_vals == 8u) {
+                        *(float2*)(dst + lg * 2u) = make_float2(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                    } else {
+                        dst[lg] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back is done before the arrival (guide: the pass drops it)
+            __builtin_amdgcn_s_barrier();
+            // rendezvous A: every workgroup of the query tile has published its maxima. ONE lane waits; the verdict reaches the
+            // other waves through LDS (every wave of the workgroup must act on the SAME verdict).
+            if (tid == 0) boot_ok_s = boot_rendezvous(bs.arrive_a, bs.degraded, a.nsplit) ? 1u : 0u;
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool ok_a = boot_ok_s != 0u;
+            // (2) thresholds of this workgroup's share of the query tile: queries split + nsplit * (wave + 8 j), one wave each
+            if (ok_a)
+                boot_thresholds(a.dump, a.tau_out, a.sample_ld, a.kprime, qt * (uint32_t)BN + split + (uint32_t)wave * a.nsplit,
+                                8u * a.nsplit, (qt + 1u) * (uint32_t)BN, a.nq, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // (also: every wave has read boot_ok_s before it is rewritten)
+            // rendezvous B counts PUBLISHED shares only: a workgroup that did not compute its thresholds never arrives, so a full
+            // count means all 256 thresholds of the tile exist; the others leave through `degraded` (set before anyone skips)
+            if (tid == 0) boot_ok_s = (ok_a && boot_rendezvous(bs.arrive_b, bs.degraded, a.nsplit)) ? 1u : 0u;
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool good = boot_ok_s != 0u;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 v = stash[((mb * NB + nb) * 4 + r4) * 64];
+                        acc[mb][nb][4 * r4] = v.x;
+                        acc[mb][nb][4 * r4 + 1] = v.y;
+                        acc[mb][nb][4 * r4 + 2] = v.z;
+                        acc[mb][nb][4 * r4 + 3] = v.w;
+                    }
+            // (3) every lane's thresholds (its NB queries), or - degraded - no emission and the exact scan for the tile's queries
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const uint32_t q = qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
+                const bool valid = q < a.nq;
+                float tau = INFINITY;
+                if (valid && good) tau = __hip_atomic_load(a.tau_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (valid && !good && wm == 0 && lane < 32) a.overflow[q] = 1u;
+                const float iq = invq[nb];
+                tauv[nb] = tau;
+                tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
+                tone[nb] = (a.metric == METRIC_DOT) || !(fabsf(tq[nb]) < INFINITY);
+                tneg[nb] = tq[nb] < 0.0f;
+                ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
+            }
+        }
+    };
+
     // ---- prologue: three stages in flight --------------------------------------------
     if (total == 0) {  // uniform: nothing to stream for this workgroup
         for (int i = tid; i < BN; i += NT) a.cand_cnt[(uint64_t)g * BN + i] = 0;
+        if (MODE == 3 && tid == 0) {  // (the host never launches such a workgroup in this mode; the group must not wait for it)
+            const BootSync bs = boot_sync_of(a, qt);
+            __hip_atomic_fetch_add(bs.arrive_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bs.arrive_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     issue_side(t_first, 0);
@@ -813,11 +972,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 
 #define CGV_EPILOGUE(TILE, SEQ)                                                                                    \
     if (!(ABL & 1)) {                                                                                              \
-        if (MODE == 0 && EPI != 0)                                                                                 \
+        if (EMIT && EPI != 0)                                                                                      \
             tile_filter_emit<BM, BN, WTM, WTN, MB, NB>(a, acc, thr, TILE, wm, wn, lane, g, qt, tauv, invq, cntq,     \
                                                        invn_s + ((SEQ) & (NINV - 1)) * 256);                       \
         else                                                                                                       \
-            tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,  \
+            tile_epilogue<BM, BN, WTM, WTN, MB, NB, (MODE == 3 ? 0 : MODE)>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,  \
                                                           invn_s + ((SEQ) & (NINV - 1)) * 256,                     \
                                                           stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ)); \
     }
@@ -861,12 +1020,15 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             CGV_A_PHASE(sb);
         }
     }
-#pragma unroll 1
-    for (uint32_t tl = 1; tl < ntl; ++tl) {
+    // One tile boundary + the rest of the tile that starts there. BOOT (COARSE_EMIT_BOOT, first boundary only): the
+    // rendezvous block sits between the ended tile's last MFMA and its filters. It is a PEELED copy of the loop body - inside
+    // the loop the block's register pressure (it spills around the rendezvous, once per launch) reached the steady-state path.
+    auto tile_iter = [&](uint32_t tl, auto boot_c) __attribute__((always_inline)) {
+        constexpr bool BOOT = decltype(boot_c)::value != 0;
         {
             const char* sb = (SI >= 2) ? smem : smem + (s & (NSTAGE - 1)) * STAGE;
             if (SI >= 2) si_slot = (uint32_t)(3 * STAGE);
-            if (MODE != 0 || EPI == 0) {
+            if (!EMIT || EPI == 0) {
                 CGV_B_PHASE(sb);
             } else {
                 CGV_B_PHASE_LAST(sb, tl - 1);
@@ -874,8 +1036,12 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             if (wave == 0) pace_step(pace, tl + 1, lane);
             const uint32_t nt = next_tile(ct);
             side_wait();
-            if (MODE == 0 && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
-            if (MODE == 0 && EPI != 0) {
+            if (EMIT && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
+            if constexpr (BOOT) {  // the first tile ends here: rendezvous, thresholds, then its filters below
+                boot_block(a.T1 + ct, invn_s, stat_s);
+                CGV_THR_ALL(0);
+            }
+            if (EMIT && EPI != 0) {
                 ftile = a.T1 + ct;
                 finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
                 issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)
@@ -900,7 +1066,12 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 CGV_A_PHASE(sb);
             }
         }
-    }
+    };
+    // COARSE_EMIT_BOOT: every workgroup walks >= 2 tiles (the launcher refuses anything else: cnt >= 2 * nsplit), so the
+    // peeled boundary is unconditional - no branch around MFMAs, no accumulator phis
+    if constexpr (MODE == 3) tile_iter(1u, IntC<1>{});
+#pragma unroll 1
+    for (uint32_t tl = (MODE == 3 ? 2u : 1u); tl < ntl; ++tl) tile_iter(tl, IntC<0>{});
 #undef CGV_TILE_REST_U4
 #undef CGV_ITER_AT
     // tail: second k-step of the last stage, then the last tile's epilogue
@@ -910,7 +1081,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = Mfma<DT>::mma(fa1[mb], fb1[nb], acc[mb][nb]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy DMA tail (and a short tile's side data)
     __builtin_amdgcn_s_barrier();
-    if (MODE == 0 && EPI != 0) CGV_THR_ALL(ntl - 1);
+    if (EMIT && EPI != 0) CGV_THR_ALL(ntl - 1);
     CGV_EPILOGUE(a.T1 + ct, ntl - 1);
 #undef CGV_A_PHASE_Z
 #undef CGV_B_PHASE

@@ -314,64 +314,14 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
 // one - with M / 16 >> k' groups the k' best rows of the sample almost surely sit in k' different groups.
 // ONE WAVE per query, values only (32-bit ordered keys, no row ids): <= 16 keys per lane sorted in registers, then
 // k' rounds of wave maximum + pop. Also clears nbest / overflow of the query (the launches that follow append).
-__device__ inline void cmpx_desc32(uint32_t& x, uint32_t& y) {
-    const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
-    x = hi;
-    y = lo;
-}
 __global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
                                                   uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (q >= nq) return;
-    const float* d = dense + (uint64_t)q * ld;
-    uint32_t r[16];
-    // lane l owns elements 4l..4l+3 of every 256-element slab (16-byte loads, coalesced); M <= 1024
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t e = 256u * j + 4u * (uint32_t)lane;
-        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (e + 3 < M) {
-            v = *(const float4*)(d + e);
-        } else {
-            if (e < M) v.x = d[e];
-            if (e + 1 < M) v.y = d[e + 1];
-            if (e + 2 < M) v.z = d[e + 2];
-        }
-        // NaN never occurs (non-finite inputs are rejected); -inf = "no row": key 0x007fffff, never 0
-        r[4 * j] = f2ord(v.x + 0.0f);
-        r[4 * j + 1] = f2ord(v.y + 0.0f);
-        r[4 * j + 2] = f2ord(v.z + 0.0f);
-        r[4 * j + 3] = f2ord(v.w + 0.0f);
-    }
-    // bitonic sorting network on 16 registers, descending
-#pragma unroll
-    for (int k2 = 2; k2 <= 16; k2 <<= 1)
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    if ((i & k2) == 0) cmpx_desc32(r[i], r[ixj]);
-                    else cmpx_desc32(r[ixj], r[i]);
-                }
-            }
-    uint32_t cnt = 0, last = 0;
-    while (cnt < kprime) {
-        const uint32_t w = wave_max_u32(r[0]);
-        if (w == 0u) break;  // fewer than k' values
-        const bool own = (r[0] == w);
-        cnt += (uint32_t)__popcll(__ballot(own));  // equal values in several lanes count once each
-        last = w;
-        if (own) {
-#pragma unroll
-            for (int i = 0; i < 15; ++i) r[i] = r[i + 1];
-            r[15] = 0u;
-        }
-    }
+    const float t = kth_largest_wave(dense + (uint64_t)q * ld, M, kprime, lane);   // common.h
     if (lane == 0) {
-        tau[q] = (cnt >= kprime) ? ord2f(last) : -INFINITY;
+        tau[q] = t;
         nbest[q] = 0u;
     }
 }
@@ -408,8 +358,10 @@ struct RescoreArgs {
 // memset before the next one. host[done_word] = marker tells the host the mirror is current. (A ticket counter in
 // the last kernel instead - 1024 returning atomics on one word - cost 25 us: r03b.)
 __global__ void publish_flags_kernel(uint32_t* __restrict__ flags, uint32_t* __restrict__ host, uint32_t n_flags,
-                                     uint32_t done_word, uint32_t marker) {
+                                     uint32_t done_word, uint32_t marker, uint32_t* __restrict__ extra = nullptr,
+                                     uint32_t n_extra = 0u) {
     const uint32_t i = threadIdx.x;
+    for (uint32_t j = i; j < n_extra; j += blockDim.x) extra[j] = 0u;  // rendezvous words of a fused sample + emit launch
     if (i < n_flags) {
         const uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         host[i] = (i == done_word) ? marker : v;
@@ -632,6 +584,9 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);
 }
 
+// id slot 0 of a PROVISIONAL record (pack_topk_kernel below): never a row id
+constexpr uint64_t PROVISIONAL_ID = 0xFFFFFFFFFFFFFFFEull;  // == CGV_PROVISIONAL_ID (cgvec.h)
+
 // The same merge without the LDS capacity limit (G * k <= 4096 above): ONE WAVE per query walks the G <= 64 sorted lists
 // like a G-way merge - lane g holds the head of list g, a round is a wave maximum of the ordered scores, then the smallest
 // id among the lanes that hold it, and the winner advances. k dependent rounds: slow (k = 2048: a few ms per batch), but
@@ -639,7 +594,8 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
 __global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
                                                               const char* __restrict__ score_base, uint64_t score_stride,
                                                               uint32_t G, uint32_t nq, uint32_t k,
-                                                              uint64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+                                                              uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                              uint32_t* __restrict__ redo = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -655,6 +611,11 @@ __global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __rest
         if (mine && h < k) {
             id = *(const uint64_t*)(ip + (uint64_t)h * 8);
             sc = *(const float*)(sp + (uint64_t)h * 4);
+            if (id == PROVISIONAL_ID) {  // this rank will redo the query: the batch's exchange is repeated (pack_topk_kernel)
+                if (redo) *redo = 1u;
+                id = UINT64_MAX;
+                sc = -INFINITY;
+            }
         }
     };
     load_head();
@@ -686,15 +647,21 @@ __global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __rest
 // Per-shard results -> one packed record row per query for the single all-gather of SURVEY.md §8(e):
 // w int32 per query = k u64 ids | k f32 scores | (k odd: one pad word, keeps the next row 8-byte aligned).
 __host__ __device__ inline uint32_t packed_width(uint32_t k) { return 3u * k + (k & 1u); }
+// PROVISIONAL records (join-free exchange, cgv_search_packed_begin_f32_dev): a query whose top-k the device could not prove
+// (prov[q] != 0: it will be re-run through the exact scan once the host looks at the flags) - or every query when
+// prov_all is set (an exact-scan-only index) - is packed with id slot 0 = PROVISIONAL_ID. The merge kernels raise their redo
+// word when they meet one: every rank merges the same gathered records, so all ranks learn it without another collective.
 __global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ score, uint32_t nq,
-                                 uint32_t k, uint32_t* __restrict__ out) {
+                                 uint32_t k, uint32_t* __restrict__ out, const uint32_t* __restrict__ prov = nullptr,
+                                 uint32_t prov_all = 0u) {
     const uint32_t w = packed_width(k);
     const uint64_t total = (uint64_t)nq * w;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t q = (uint32_t)(i / w), c = (uint32_t)(i % w);
         uint32_t v = 0u;
         if (c < 2 * k) {
-            const uint64_t id = idx[(uint64_t)q * k + (c >> 1)];
+            uint64_t id = idx[(uint64_t)q * k + (c >> 1)];
+            if (c < 2 && (prov_all || (prov && prov[q] != 0u))) id = PROVISIONAL_ID;
             v = (c & 1u) ? (uint32_t)(id >> 32) : (uint32_t)id;
         } else if (c < 3 * k) {
             v = __float_as_uint(score[(uint64_t)q * k + (c - 2 * k)]);
@@ -711,7 +678,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const char* __restrict_
                                                          const char* __restrict__ score_base,
                                                          uint64_t score_stride, uint32_t G, uint32_t nq,
                                                          uint32_t k, uint64_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_score) {
+                                                         float* __restrict__ out_score, uint32_t* __restrict__ redo = nullptr) {
     // Global ids are 64-bit, so sort (ordered score, position) keys and carry the id
     // through the position; ties on score are resolved by a second pass on the id.
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -727,6 +694,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const char* __restrict_
             const uint32_t gi = i / k, j = i % k;
             id = *(const uint64_t*)(idx_base + ((uint64_t)gi * nq + q) * idx_stride + (uint64_t)j * 8);
             const float s = *(const float*)(score_base + ((uint64_t)gi * nq + q) * score_stride + (uint64_t)j * 4);
+            if (id == PROVISIONAL_ID) {  // rank gi will redo this query: the batch's exchange is repeated (pack_topk_kernel)
+                if (redo) *redo = 1u;
+                id = UINT64_MAX;
+            }
             if (id != UINT64_MAX) key = make_key(s, i);
         }
         keys[i] = key;

@@ -41,6 +41,8 @@
 #include "../../include/cgvec.h"
 
 extern "C" int cgv_set_error_(int code, const char* msg);  // cgvec.hip: the library's thread-local error message
+extern "C" int cgv_score_pairs_f32_(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint32_t* qsel_host,
+                                    const uint64_t* ids_host, uint64_t npairs, float* out_host);  // cgvec.hip
 
 namespace {
 
@@ -200,6 +202,8 @@ struct cgv_sharded {
     } slots[3];
     std::condition_variable slot_cv;
     bool rccl_broken = false;  // a rank failed to post a collective: communicators aborted, copy exchange from now on
+    std::mutex abort_mu;       // abort_comms_now(): the failing rank's worker aborts every communicator, once
+    bool comms_aborted = false;
     // a handle over ONE shard normally skips pack / exchange / merge; CGV_SHARDED_FORCE_EXCHANGE=1 (read at create) runs them
     // anyway - a one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
     bool force_xch = false;
@@ -416,7 +420,7 @@ int cgv_sharded_destroy(cgv_sharded* s) {
     for (Shard* sh : s->sh) {
         (void)hipSetDevice(sh->device);
         if (sh->xs) (void)hipStreamSynchronize(sh->xs);
-        if (sh->comm && r) (void)r->CommDestroy(sh->comm);
+        if (sh->comm && r && !s->comms_aborted) (void)r->CommDestroy(sh->comm);
         if (sh->ix) (void)cgv_destroy(sh->ix);
         sh->stage.release();
         for (auto& sb : sh->slot)
@@ -539,7 +543,9 @@ int cgv_sharded_get_row_f32(cgv_sharded* s, uint64_t id, float* out_host) {
 }
 
 // cgv_score_ids_f32 over the shards: every (query, id) pair is scored on the shard that owns the row (global id ->
-// shard, local row: locate()), all shards in parallel, one device launch each.
+// shard, local row: locate()), all shards in parallel, one device launch each. Each shard receives ONLY its own pairs as a
+// compact list (query index, local row) and returns one score per pair, scattered back through the pair's position: host
+// memory and device work are O(nq * m) in total, not per shard.
 int cgv_sharded_score_ids_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, int op, const uint64_t* ids_host,
                               uint32_t m, float* out_host) {
     if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
@@ -547,33 +553,41 @@ int cgv_sharded_score_ids_f32(cgv_sharded* s, const float* queries_host, uint32_
     if (!queries_host || !ids_host || !out_host) return fail(CGV_ERR_INVALID_ARG, "NULL buffer");
     DeviceGuard guard;
     std::lock_guard<std::mutex> lk(s->mu);
+    if (int brc = busy_if_in_flight(s, "cgv_sharded_score_ids_f32")) return brc;
     const size_t pairs = (size_t)nq * m;
-    std::vector<std::vector<uint64_t>> local(s->G, std::vector<uint64_t>(pairs, UINT64_MAX));
-    std::vector<uint8_t> owner(pairs, 0xff);
-    std::vector<char> used(s->G, 0);
+    struct Part {
+        std::vector<uint32_t> qsel;   // query of the pair
+        std::vector<uint64_t> local;  // local row on the shard
+        std::vector<size_t> pos;      // position of the pair in the caller's [nq][m] arrays
+        std::vector<float> score;
+    };
+    std::vector<Part> part(s->G);
     for (size_t i = 0; i < pairs; ++i) {
+        out_host[i] = 0.0f;  // UINT64_MAX or beyond the index: scores 0.0 (a missing embedding, search.rs:207-217)
         const uint64_t id = ids_host[i];
-        if (id >= s->n) continue;  // UINT64_MAX or beyond the index: scores 0.0 (a missing embedding, search.rs:207-217)
+        if (id >= s->n) continue;
         uint32_t g;
         uint64_t l;
         locate(s, id, &g, &l);
-        local[g][i] = l;
-        owner[i] = (uint8_t)g;
-        used[g] = 1;
+        part[g].qsel.push_back((uint32_t)(i / m));
+        part[g].local.push_back(l);
+        part[g].pos.push_back(i);
     }
-    std::vector<std::vector<float>> part(s->G);
     std::vector<std::function<int()>> jobs(s->G);
     for (uint32_t g = 0; g < s->G; ++g) {
-        if (!used[g]) continue;
-        part[g].assign(pairs, 0.0f);
+        Part* p = &part[g];
+        if (p->pos.empty()) continue;
+        p->score.assign(p->pos.size(), 0.0f);
         Shard* sh = s->sh[g];
-        const uint64_t* lp = local[g].data();
-        float* op_out = part[g].data();
-        jobs[g] = [=]() -> int { return cgv_score_ids_f32(sh->ix, queries_host, nq, op, lp, m, op_out); };
+        jobs[g] = [=]() -> int {
+            return cgv_score_pairs_f32_(sh->ix, queries_host, nq, op, p->qsel.data(), p->local.data(), (uint64_t)p->pos.size(),
+                                        p->score.data());
+        };
     }
     const int rc = run_all(s, jobs);
     if (rc) return rc;
-    for (size_t i = 0; i < pairs; ++i) out_host[i] = owner[i] == 0xff ? 0.0f : part[owner[i]][i];
+    for (const Part& p : part)
+        for (size_t j = 0; j < p.pos.size(); ++j) out_host[p.pos[j]] = p.score[j];
     return CGV_OK;
 }
 
@@ -625,14 +639,27 @@ void drain_streams(cgv_sharded* s) {
     (void)run_all(s, jobs);
 }
 
-// A rank failed to post its part of a collective: the other ranks would wait in it forever. Abort every communicator
-// (unblocks them) and fall back to the copy exchange for the rest of the handle's life.
-void abort_rccl(cgv_sharded* s, const Rccl* r) {
-    s->rccl_broken = true;
+// A rank failed to post its part of a collective: the other ranks have posted theirs and sit in hipStreamSynchronize on a
+// kernel that can never complete - on their WORKER threads, inside the jobs run_all() is waiting for. So the abort has to
+// come from the failing rank's own job (abort_comms_now, once, from whichever worker gets there first): ncclCommAbort is
+// made to be called from another thread and makes the stuck collectives return. abort_rccl() then runs on the caller's
+// thread after the join: the communicators are gone and the handle continues with the copy exchange. Without
+// ncclCommAbort in the library the communicators are destroyed instead.
+void abort_comms_now(cgv_sharded* s, const Rccl* r) {
+    std::lock_guard<std::mutex> lk(s->abort_mu);
+    if (s->comms_aborted) return;
+    s->comms_aborted = true;
     for (Shard* sh : s->sh) {
-        if (sh->comm && r && r->CommAbort) (void)r->CommAbort(sh->comm);
-        sh->comm = nullptr;
+        if (!sh->comm || !r) continue;
+        if (r->CommAbort) (void)r->CommAbort(sh->comm);
+        else (void)r->CommDestroy(sh->comm);
     }
+}
+
+void abort_rccl(cgv_sharded* s, const Rccl* r) {
+    abort_comms_now(s, r);  // (no-op when the failing worker already did it)
+    s->rccl_broken = true;
+    for (Shard* sh : s->sh) sh->comm = nullptr;
     s->exchange = CGV_EXCHANGE_COPY;
 }
 
@@ -764,7 +791,8 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
                             rc = CGV_ERR_HIP;
                             err = std::string("ncclAllGather: ") + rccl->GetErrorString(e);
                         }
-                        return fail(rc, err);  // no stream wait: the caller aborts the communicators
+                        abort_comms_now(s, rccl);  // the other ranks posted theirs and wait on the stream: unblock them
+                        return fail(rc, err);      // no stream wait here
                     }
                 } else if (rc == CGV_OK) {
                     char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;

@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -104,12 +105,24 @@ const char* column_for_dimension(size_t dim) {
         case 2560: return "embedding_2560";
         case 3072: return "embedding_3072";
         case 4096: return "embedding_4096";
-        default:
-            fprintf(stderr,
-                    "WARN Unsupported embedding dimension %zu, falling back to 2048. Supported dimensions: 384, "
-                    "768, 1024, 1536, 2048, 2560, 3072, 4096\n",
-                    dim);
+        default: {
+            // the reference's warn! goes to `tracing` (a subscriber decides); here it is stderr, so ONCE per dimension per
+            // process - a store of an unsupported dimension calls this on every search (16 KB of this line
+            // pushed the failing test's name out of the driver's log tail)
+            static std::mutex warn_mu;
+            static std::set<size_t> warned;
+            bool first;
+            {
+                std::lock_guard<std::mutex> lk(warn_mu);
+                first = warned.insert(dim).second;
+            }
+            if (first)
+                fprintf(stderr,
+                        "WARN Unsupported embedding dimension %zu, falling back to 2048. Supported dimensions: 384, "
+                        "768, 1024, 1536, 2048, 2560, 3072, 4096 (logged once per dimension)\n",
+                        dim);
             return "embedding_2048";
+        }
     }
 }
 

@@ -8,8 +8,58 @@ subset of the union of the local top-k.
 The reference has no distributed path (no collective anywhere); this is the
 multi-GPU extension BASELINE.json's north_star asks for.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
+
+PROVISIONAL_ID = 0xFFFFFFFFFFFFFFFE   # CGV_PROVISIONAL_ID (include/cgvec.h): id slot 0 of a record the rank will redo
+
+
+def packed_width(k):
+    """int32 words per query of a packed record: k u64 ids | k f32 scores | one pad word when k is odd (cgv_packed_width)."""
+    return 3 * int(k) + (int(k) & 1)
+
+
+def pack_records_host(idx, score, provisional=None):
+    """Host restatement of pack_topk_kernel (csrc/kernels_select.h) for the CPU (gloo) tests and as documentation of the wire
+    format: [nq, k] uint64 ids + f32 scores -> int32 [nq, packed_width(k)]; rows of `provisional` queries carry
+    PROVISIONAL_ID in id slot 0."""
+    idx = np.ascontiguousarray(idx, dtype=np.uint64).copy()
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    nq, k = idx.shape
+    if provisional is not None:
+        idx[np.asarray(provisional, dtype=bool), 0] = np.uint64(PROVISIONAL_ID)
+    rec = np.zeros((nq, packed_width(k)), dtype=np.int32)
+    rec[:, :2 * k] = idx.view(np.int32).reshape(nq, 2 * k)
+    rec[:, 2 * k:3 * k] = score.view(np.int32).reshape(nq, k)
+    return rec
+
+
+def merge_packed_host(gathered, k):
+    """Host restatement of merge_topk_kernel over the all-gather output [G, nq, packed_width(k)] int32 ->
+    (ids uint64 [nq, k], scores f32 [nq, k], redo): (score desc, id asc), padding (UINT64_MAX) last; redo is True when any
+    list is provisional (its entries are then ignored, the batch's exchange must be repeated)."""
+    g = np.ascontiguousarray(gathered, dtype=np.int32)
+    G, nq, _ = g.shape
+    ids = np.ascontiguousarray(g[:, :, :2 * k]).view(np.uint64).reshape(G, nq, k)
+    sc = np.ascontiguousarray(g[:, :, 2 * k:3 * k]).view(np.float32).reshape(G, nq, k)
+    out_i = np.full((nq, k), np.uint64(2**64 - 1), dtype=np.uint64)
+    out_s = np.full((nq, k), -np.inf, dtype=np.float32)
+    redo = False
+    for q in range(nq):
+        cand = []
+        for r in range(G):
+            for j in range(k):
+                i = int(ids[r, q, j])
+                if i == PROVISIONAL_ID:
+                    redo = True
+                    continue
+                if i != 2**64 - 1:
+                    cand.append((-float(sc[r, q, j]), i, sc[r, q, j]))
+        cand.sort(key=lambda t: (t[0], t[1]))
+        for j, (_, i, s_) in enumerate(cand[:k]):
+            out_i[q, j], out_s[q, j] = np.uint64(i), s_
+    return out_i, out_s, redo
 
 
 def shard_range(n_total, rank, world):
@@ -40,6 +90,78 @@ class ShardedKnn:
 
     def search(self, queries, k):
         return self._exchange(*self.local.search(queries, k), k)
+
+    # ---- join-free step (round 4): search -> pack on the library's stream, collective + merge enqueued behind an event,
+    # ONE host synchronisation per batch; provisional records make every rank repeat the exchange (include/cgvec.h) --------
+    redo_batches = 0
+    time_exchange = False      # step_packed: HIP-event pair around all-gather + merge on the stream they run on
+    last_exchange_ms = 0.0
+    _ev = None
+
+    def _buffers(self, nq, k, like):
+        w = packed_width(k)
+        key = (nq, w, str(like.device) if like.is_cuda else "cpu")
+        if getattr(self, "_pk_key", None) != key:
+            dev = like.device if like.is_cuda else torch.device("cpu")
+            self._pk_rec = torch.empty((nq, w), dtype=torch.int32, device=dev)
+            self._pk_gathered = torch.empty((self.world, nq, w), dtype=torch.int32, device=dev)
+            self._pk_redo = torch.zeros(1, dtype=torch.int32)
+            if like.is_cuda:
+                self._pk_redo = self._pk_redo.pin_memory()   # written in place by the merge kernel, read by the host after the sync
+            self._pk_key = key
+        return self._pk_rec, self._pk_gathered, self._pk_redo
+
+    def _gather_merge(self, rec, gathered, k, out, redo):
+        if rec.is_cuda:
+            from .cgvec import merge_packed
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+            return merge_packed(gathered, k, out=out, redo=redo)
+        parts = [gathered[r] for r in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(parts, rec, group=self.group)     # gloo (CPU tests)
+        else:
+            parts[0].copy_(rec)
+        ids, sc, again = merge_packed_host(gathered.numpy(), k)
+        redo[0] = 1 if again else 0
+        oi, os_ = torch.from_numpy(ids.view(np.int64)), torch.from_numpy(sc)
+        if out is not None:
+            out[0].copy_(oi)
+            out[1].copy_(os_)
+            return out
+        return oi, os_
+
+    def step_packed(self, queries, k, out=None, device=None):
+        """One batch, one host synchronisation: local.search_packed_begin (shard search + packed records, the consumer stream
+        waits for them) -> all-gather -> merge with the redo flag -> sync -> local.search_packed_end. When any rank's records
+        were provisional (the same flag on every rank), the exchange is repeated with the final records.
+        `local` needs search_packed_begin(queries, k, rec) -> ticket and search_packed_end(ticket) -> bool."""
+        nq = queries.shape[0]
+        like = queries if queries.is_cuda else (torch.empty(0, device=device) if device is not None else queries)
+        rec, gathered, redo = self._buffers(nq, k, like)
+        redo.zero_()
+        ticket = self.local.search_packed_begin(queries, k, rec)
+        timed = rec.is_cuda and self.time_exchange
+        if timed:   # the consumer stream already waits for the records: ev0 = records ready, ev1 = merged results written
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+        res = self._gather_merge(rec, gathered, k, out, redo)
+        if timed:
+            self._ev[1].record()
+        if rec.is_cuda:
+            torch.cuda.current_stream(rec.device).synchronize()
+        if timed:
+            self.last_exchange_ms = self._ev[0].elapsed_time(self._ev[1])
+        self.local.search_packed_end(ticket)
+        if int(redo[0]) != 0:
+            self.redo_batches += 1
+            redo.zero_()
+            res = self._gather_merge(rec, gathered, k, out, redo)
+            if rec.is_cuda:
+                torch.cuda.current_stream(rec.device).synchronize()
+            if int(redo[0]) != 0:
+                raise RuntimeError("records still provisional after search_packed_end")
+        return res
 
     def search_begin(self, queries, k):
         """Pipelined form: the local shard search is enqueued now; wait() completes it, then runs

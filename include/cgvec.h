@@ -254,6 +254,35 @@ int cgv_pack_topk_dev(int device_id, const uint64_t* idx_dev, const float* score
 int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
                          uint64_t* out_idx_dev, float* out_score_dev, void* stream);
 
+/* Device-visible address of a pinned / registered HOST range on `device_id` (equal to the host address for hipHostMalloc
+ * memory, possibly different for hipHostRegister-ed memory), or NULL when [host_ptr, host_ptr + bytes) is not WHOLLY such
+ * memory mapping to one contiguous device range. What cgv_search_f32 uses to decide "in place or staged" per buffer. */
+void* cgv_host_device_alias(int device_id, const void* host_ptr, size_t bytes);
+
+/* ---- one rank's share of a batch WITHOUT a host join between the shard search and the exchange -------------------------
+ * (row-sharded deployment, one process per GPU; the reference has no counterpart - its "batch" is B
+ * independent futures, search.rs:358-361.)
+ * cgv_search_packed_begin_f32_dev enqueues the shard search of the batch (queries_dev: device memory or the device alias of
+ * pinned host memory, cgv_host_device_alias) and, on the same internal stream right behind its last kernel, the packing of
+ * the top-k into rec_out_dev (cgv_packed_width(k) int32 words per query, device memory owned by the caller), and makes
+ * `consumer_stream` (a hipStream_t) wait for the records. The caller then enqueues on that stream the all-gather of every
+ * rank's records and cgv_merge_packed_flag_dev, and synchronises ONCE - the host never sits between the search and the
+ * collective. A query whose top-k the device could not prove (ties / near-duplicates at the k' boundary, a zero query, an
+ * exact-scan-only index ...) is packed PROVISIONAL: id slot 0 = CGV_PROVISIONAL_ID. The merge raises *redo_flag_dev (a
+ * device word, or a pinned host word written in place; the caller zeroes it) when any rank's list of any query is
+ * provisional. Every rank merges the same gathered records, so ALL ranks read the same flag - no second collective to agree:
+ *   flag == 0: the merged results are final; cgv_search_packed_end(ticket) releases the context (and returns the search's
+ *              status: a NaN / Inf query fails HERE with CGV_ERR_NONFINITE, its records were provisional);
+ *   flag != 0: every rank calls cgv_search_packed_end (the rank that owns the provisional queries runs the exact scan and
+ *              re-packs rec_out_dev, *repacked = 1), then all-gathers and merges again.
+ * Tickets share the handle's contexts with cgv_search_begin_f32_dev (cgv_max_batches_in_flight). */
+#define CGV_PROVISIONAL_ID 0xFFFFFFFFFFFFFFFEull
+int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint32_t k, uint32_t* rec_out_dev,
+                                    void* consumer_stream, uint64_t* ticket);
+int cgv_search_packed_end(cgv_index* h, uint64_t ticket, int* repacked);
+int cgv_merge_packed_flag_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uint32_t nq, uint32_t k,
+                              uint64_t* out_idx_dev, float* out_score_dev, uint32_t* redo_flag_dev, void* stream);
+
 /* Run this handle's work on an external hipStream_t (e.g. PyTorch's current stream).
  * The value is used as-is: NULL is HIP's legacy default ("null") stream — which is what
  * PyTorch uses unless told otherwise — NOT "no stream". */

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so   # the measurement flavour (make ABLATE=1): ablation masks, knobs, traces
 # timing-only ablations of the one-wave-per-SIMD coarse kernels (results are wrong for masks != 0): main-launch ms per mask.
 # bf16 (WL=c2, needs CGV_COARSE=w4): masks 1 3 5 9 11 17; fp8 (WL=c5mini, the default kernel): masks 1 3 9
 export TMPDIR=/tmp

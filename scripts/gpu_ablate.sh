@@ -1,4 +1,5 @@
 #!/bin/bash
+export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so   # the measurement flavour (make ABLATE=1): ablation masks, knobs, traces
 # Timing-only ablations of the bf16 coarse kernel on C2 (CGV_ABLATE mask, kernels_coarse.h):
 # 1 no epilogue, 2 no DMA, 4 no barrier, 8 no fragment reads, 16 no vmcnt wait, 32 global_load-lds form
 # of the DMA (correct results). Results are wrong

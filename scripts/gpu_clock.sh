@@ -1,4 +1,5 @@
 #!/bin/bash
+export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so   # the measurement flavour (make ABLATE=1): ablation masks, knobs, traces
 # clock of the coarse kernel under ablations: GRBM_GUI_ACTIVE cycles / kernel duration (is the kernel power-limited?)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so   # the measurement flavour (make ABLATE=1): ablation masks, knobs, traces
 # Workgroup pacing A/B (CGV_NO_PACE=1 = off): HBM fetch traffic of the longest coarse launch (one PMC pass:
 # FETCH_SIZE + TCC_HIT_sum; a third TCC counter exceeds what one pass can collect and rocprofv3 aborts)
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so   # the measurement flavour (make ABLATE=1): ablation masks, knobs, traces
 # One GPU call's worth of round evidence: the -m gpu suite, a bench line per workload, kernel timelines of C2 and its
 # 8-GPU shard, the final kernel's phase stamps, and (optionally) interleaved A/B runs of knob variants.
 #   gpu_round.sh <tag> ["<ab variants for c2>"]       outputs under gpurun_out/<tag>/

@@ -11,7 +11,7 @@ from _util import pkg
 pytestmark = pytest.mark.gpu
 
 ODT = {"f32": 0, "bf16": 1, "fp16": 2, "fp8": 3, "f32s": 0}   # f32s: f32 rows + bf16 shadow -> f32 oracle
-OMETRIC = {"cosine": 0, "dot": 1, "cosine_seq": 2}
+OMETRIC = {"cosine": 0, "dot": 1, "cosine_seq": 2, "cosine_scalar": 3}
 
 
 def _unit(rng, n, d):
@@ -84,7 +84,8 @@ def test_mfma_tile_mapping_dense_scores(dtype, d, oracle):
                                           ("fp16", "dot"), ("f32", "cosine"), ("f32", "dot"),
                                           ("fp8", "cosine"), ("bf16", "cosine_seq"), ("f32", "cosine_seq"),
                                           ("fp8", "cosine_seq"), ("f32s", "cosine"), ("f32s", "dot"),
-                                          ("f32s", "cosine_seq")])
+                                          ("f32s", "cosine_seq"), ("f32", "cosine_scalar"), ("bf16", "cosine_scalar"),
+                                          ("fp8", "cosine_scalar"), ("f32s", "cosine_scalar")])
 def test_parity_small(oracle, dtype, metric):
     _run(oracle, n=1000, d=256, nq=7, k=10, dtype=dtype, metric=metric)
 
@@ -94,6 +95,39 @@ def test_parity_small(oracle, dtype, metric):
 def test_parity_ragged_dims(oracle, dtype, d):
     """D < 32 takes the reference's scalar branch (simd_ops.rs:281-295); D % 8 != 0 the tail."""
     _run(oracle, n=777, d=d, nq=5, k=10, dtype=dtype, metric="cosine", seed=d, unit=False)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "fp16", "f32s"])
+@pytest.mark.parametrize("d", [8, 31, 32, 33, 100, 768])
+def test_parity_scalar_host_mode(oracle, dtype, d):
+    """CGV_METRIC_COSINE_SCALAR: cosine_similarity_scalar (simd_ops.rs:257-278) for EVERY length - what
+    adaptive_cosine_similarity (:281-295) computes on a host without AVX2 + FMA and on every non-x86_64 host (the aarch64
+    builds of the reference). Bit-exact ids and scores against the oracle's metric 3 (cgo_cosine_scalar per row, full sort)
+    at D below, at and above the AVX2 path's 32-element switch; the MFMA path nominates, the scalar formula re-scores."""
+    st = _run(oracle, n=3000, d=d, nq=9, k=10, dtype=dtype, metric="cosine_scalar", seed=100 + d, unit=False)
+    if dtype != "f32":
+        assert st["last_path"] == 1
+
+
+def test_scalar_and_avx2_orders_really_differ(oracle):
+    """The two modes are different arithmetic, not aliases: at D = 768 the scalar order's scores differ from the AVX2
+    order's in the last bits for most pairs (if they were equal the mode could not be told from a no-op) - and each
+    device mode matches ITS oracle function through the building-block API too (CGV_OP_COSINE_SCALAR)."""
+    m = pkg()
+    rng = np.random.default_rng(4)
+    rows = rng.standard_normal((500, 768)).astype(np.float32)
+    q = rng.standard_normal(768).astype(np.float32)
+    ix = m.HipKnnIndex(768, dtype="f32")
+    try:
+        ix.add(rows)
+        a = ix.batch_similarity(q, "cosine")
+        b = ix.batch_similarity(q, "cosine_scalar")
+        ra = np.array([oracle.cosine_adaptive(q, r) for r in rows], dtype=np.float32)
+        rb = np.array([oracle.cosine_scalar(q, r) for r in rows], dtype=np.float32)
+        assert np.array_equal(a, ra) and np.array_equal(b, rb)
+        assert (a != b).mean() > 0.3
+    finally:
+        ix.close()
 
 
 def test_parity_c1_shape_f32(oracle):
@@ -143,9 +177,10 @@ def test_fp8_mixed_row_scales_staged(oracle):
 
 
 def test_reference_epilogue_variant(oracle):
-    """CGV_EPI=0: the round-2 epilogue of the bf16 coarse kernel (everything at the tile boundary), kept in the build as
-    the A/B reference of the interleaved one - same candidates, same bit-exact results, no fallback. A child process:
-    the switch is read at load time."""
+    """CGV_EPI=0: the round-2 epilogue of the bf16 coarse kernel (everything at the tile boundary), kept in the MEASUREMENT
+    flavour of the library (`make ABLATE=1`, libcgvec_hip_ablate.so) as the A/B reference of the interleaved one - same
+    candidates, same bit-exact results, no fallback. A child process that loads that flavour (CGV_LIB_PATH): the production
+    library carries neither the instantiation nor the switch."""
     import os
     import subprocess
     import sys
@@ -169,8 +204,9 @@ assert np.array_equal(idx, ri) and np.array_equal(sc, rs), "results differ from 
 assert st["last_path"] == 1 and st["fallback_queries"] == 0, st
 print("EPI0-OK")
 """
-    env = dict(os.environ, CGV_EPI="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    abl = pkg().cgvec.build_library(ablate=True)      # a no-op when __graft_entry__.build() made it (it travels with the tree)
+    env = dict(os.environ, CGV_EPI="0", CGV_LIB_PATH=abl)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "EPI0-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

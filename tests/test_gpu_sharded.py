@@ -272,6 +272,15 @@ def _rank_main(rank, world, port, n, d, nq, k, out):
     i2, s2 = p2.wait()
     assert torch.equal(i1, idx) and torch.equal(s1, sc)
     assert torch.equal(i2, torch.flip(idx, dims=[0])) and torch.equal(s2, torch.flip(sc, dims=[0]))
+    # the join-free step the bench drives (round 4): pinned batch in place, records packed on the library's stream, RCCL
+    # all-gather + merge into pinned host arrays behind an event, ONE synchronisation; q[5] = a stored row with near-copies
+    # around it -> its guarantee check fails on the owning rank -> PROVISIONAL record -> every rank repeats the exchange
+    qp = torch.from_numpy(q).pin_memory()
+    oi, osc = torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory()
+    for _ in range(3):
+        r = sh.step_packed(qp, k, out=(oi, osc), device=torch.device("cuda", rank))
+        assert r[0] is oi and torch.equal(oi, idx.cpu()) and torch.equal(osc, sc.cpu())
+    np.save(f"{out}.{rank}.redo.npy", np.array([sh.redo_batches]))
     np.save(f"{out}.{rank}.idx.npy", idx.cpu().numpy().view(np.uint64))
     np.save(f"{out}.{rank}.sc.npy", sc.cpu().numpy())
     ix.close()
@@ -345,3 +354,139 @@ def test_two_ranks_rccl_device_exchange(tmp_path, oracle):
     for r in range(2):
         assert np.array_equal(np.load(f"{out}.{r}.idx.npy"), ri)
         assert np.array_equal(np.load(f"{out}.{r}.sc.npy"), rs)
+
+
+# ---- round 4 -------------------------------------------------------------------------------------------------------
+
+def test_sharded_handle_is_busy_while_a_batch_is_in_flight(oracle):
+    """add / update_row / get_row / reserve / score_ids on a cgv_sharded handle between search_begin and search_end
+    used to deadlock (the shard call waits for a context its worker holds until end, which needs the handle's mutex).
+    Now: CGV_ERR_BUSY, nothing changed, and the batch in flight still ends with the right answer."""
+    m = pkg()
+    rng = np.random.default_rng(41)
+    n, d, k = 2 * C + 300, 64, 10
+    rows = _unit(rng, n, d)
+    q = _unit(rng, 40, d)
+    sx = m.ShardedIndex(d, _devices(m, 2), dtype="bf16")
+    try:
+        sx.add(rows)
+        pend = sx.search_begin(q, k)
+        for call in (lambda: sx.get_row(5), lambda: sx.update_row(5, q[0]), lambda: sx.add(rows[:10]),
+                     lambda: sx.reserve(10 * n)):
+            with pytest.raises(m.CgvError) as ei:
+                call()
+            assert ei.value.code == m.cgvec.CGV_ERR_BUSY, ei.value
+        idx, sc = pend.wait()
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+        assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+        assert len(sx) == n and np.array_equal(sx.get_row(5), oracle.round_trip(rows[5], 1))   # and now they work
+        sx.update_row(5, q[0])
+        assert np.array_equal(sx.get_row(5), oracle.round_trip(q[0], 1))
+    finally:
+        sx.close()
+
+
+def test_device_pack_and_merge_match_the_host_restatement(oracle):
+    """pack_topk_kernel / merge_topk_kernel / merge_topk_wave_kernel word for word against pack_records_host /
+    merge_packed_host (codegraph-rust_amd/sharded.py - what the CPU gloo test of the packed exchange runs on): odd k (pad
+    word), ids beyond 2^32, padded tails, a cross-list tie, and the PROVISIONAL marker raising the redo word."""
+    import torch
+    from importlib import import_module
+    m = pkg()
+    sp = import_module("codegraph-rust_amd.sharded")
+    rng = np.random.default_rng(8)
+    for g, nq, k in ((3, 9, 5), (8, 33, 10), (5, 4, 1000)):
+        sc = np.sort(rng.standard_normal((g, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+        ids = (rng.permutation(g * nq * k).astype(np.uint64) + np.uint64(7 << 32)).reshape(g, nq, k)
+        sc[1, :, 0] = sc[0, :, 0]
+        for gi in range(g):
+            for q in range(nq):
+                o = np.lexsort((ids[gi, q], -sc[gi, q]))
+                ids[gi, q], sc[gi, q] = ids[gi, q][o], sc[gi, q][o]
+        ids[2, :, k - k // 3:] = np.uint64(2**64 - 1)
+        sc[2, :, k - k // 3:] = -np.inf
+        recs = []
+        for gi in range(g):
+            di, ds = torch.from_numpy(ids[gi].view(np.int64)).cuda(), torch.from_numpy(sc[gi]).cuda()
+            rec = m.pack_topk(di, ds)
+            assert np.array_equal(rec.cpu().numpy(), sp.pack_records_host(ids[gi], sc[gi])), (g, k, gi)
+            recs.append(rec)
+        gathered = torch.stack(recs).contiguous()
+        redo = torch.zeros(1, dtype=torch.int32).pin_memory()
+        oi, os_ = m.merge_packed(gathered, k, redo=redo)
+        torch.cuda.synchronize()
+        hi, hs, hredo = sp.merge_packed_host(gathered.cpu().numpy(), k)
+        assert not hredo and int(redo[0]) == 0
+        assert np.array_equal(oi.cpu().numpy().view(np.uint64), hi) and np.array_equal(os_.cpu().numpy(), hs), (g, k)
+        prov = np.zeros(nq, dtype=bool)
+        prov[nq // 2] = True
+        gp = gathered.clone()
+        gp[1] = torch.from_numpy(sp.pack_records_host(ids[1], sc[1], prov)).cuda()
+        oi, os_ = m.merge_packed(gp, k, redo=redo)
+        torch.cuda.synchronize()
+        hi, hs, hredo = sp.merge_packed_host(gp.cpu().numpy(), k)
+        assert hredo and int(redo[0]) == 1
+        keep = ~prov
+        assert np.array_equal(oi.cpu().numpy().view(np.uint64)[keep], hi[keep]) and np.array_equal(os_.cpu().numpy()[keep], hs[keep])
+
+
+@pytest.mark.parametrize("dtype,odt", [("bf16", 1), ("f32", 0)])
+def test_join_free_packed_step_one_rank(oracle, dtype, odt):
+    """cgv_search_packed_begin_f32_dev / cgv_search_packed_end / cgv_merge_packed_flag_dev in this process (no process
+    group: the all-gather of ONE rank is a copy): clean batches need one exchange; a query whose guarantee check fails is
+    packed PROVISIONAL, the merge raises the redo word, end() re-packs and the second merge equals the oracle; an f32 index
+    (exact scan only) is provisional throughout; a NaN query fails at end() and leaves the handle usable."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(13)
+    n, d, nq, k = 30_000, 128, 260, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[9000:9060] = rows[17] * (1 + 1e-4 * rng.standard_normal((60, 1)).astype(np.float32))   # near-duplicates of row 17
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        w = m.cgvec.packed_width(k)
+        rec = torch.empty((nq, w), dtype=torch.int32, device="cuda")
+        redo = torch.zeros(1, dtype=torch.int32).pin_memory()
+        oi = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+        osc = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+
+        def step(qt):
+            redo.zero_()
+            t = ix.search_packed_begin(qt, k, rec)
+            m.merge_packed(rec.view(1, nq, w), k, out=(oi, osc), redo=redo)
+            torch.cuda.current_stream().synchronize()
+            repacked = ix.search_packed_end(t)
+            first = int(redo[0])
+            if first:
+                redo.zero_()
+                m.merge_packed(rec.view(1, nq, w), k, out=(oi, osc), redo=redo)
+                torch.cuda.current_stream().synchronize()
+                assert int(redo[0]) == 0
+            return first, repacked
+
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+        qp = torch.from_numpy(q).pin_memory()
+        for src in (qp, torch.from_numpy(q).cuda()):          # pinned host batch read in place / device batch
+            first, repacked = step(src)
+            assert (first, repacked) == ((0, False) if dtype == "bf16" else (1, True))
+            assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+        q2 = q.copy()
+        q2[3] = rows[17]                                       # straddles the k' boundary of its cluster: exact scan
+        ri2, rs2 = oracle.batch_top_k(q2, rows, k, dtype=odt)
+        first, repacked = step(torch.from_numpy(q2).pin_memory())
+        assert first == 1 and repacked
+        assert np.array_equal(oi.numpy().view(np.uint64), ri2) and np.array_equal(osc.numpy(), rs2)
+        bad = q.copy()
+        bad[7, 5] = np.nan
+        redo.zero_()
+        t = ix.search_packed_begin(torch.from_numpy(bad).pin_memory(), k, rec)
+        torch.cuda.current_stream().synchronize()
+        with pytest.raises(m.CgvError) as ei:
+            ix.search_packed_end(t)
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+        first, repacked = step(qp)                             # the handle still answers
+        assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+    finally:
+        ix.close()

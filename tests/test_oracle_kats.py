@@ -295,3 +295,34 @@ def test_fp8_row_scaling(oracle):
         assert np.array_equal(oracle.round_trip(qr * np.float32(2.0 ** e), oracle.FP8, scaled_fp8=False), qr * np.float32(2.0 ** e))
     # cosine is scale invariant bit-for-bit (power-of-two scaling is exact)
     assert oracle.cosine_avx2(q[0], q[1]) == oracle.cosine_avx2(q[0] * np.float32(256), q[1] * np.float32(0.125))
+
+
+def test_scalar_host_metric_of_the_oracle(oracle):
+    """Oracle metric 3 (COSINE_SCALAR) = cosine_similarity_scalar (simd_ops.rs:257-278) for every length: what
+    parallel_top_k_search computes on a host without AVX2 (adaptive_cosine_similarity :291-294). Pinned by an independent
+    pure-Python restatement with one f32 rounding per operation (no FMA), at lengths on both sides of the AVX2 switch, and
+    by the reference's own scalar KAT (simd_ops.rs:462-472: [1,2,3] . [4,5,6] = 0.974631...)."""
+    f32 = np.float32
+
+    def scalar(a, b):
+        dp = na = nb = f32(0.0)
+        for x, y in zip(a, b):
+            dp = f32(dp + f32(x * y))
+            na = f32(na + f32(x * x))
+            nb = f32(nb + f32(y * y))
+        npd = f32(np.sqrt(f32(na * nb)))
+        return f32(0.0) if npd == 0 else f32(dp / npd)
+
+    assert abs(float(oracle.cosine_scalar(np.array([1, 2, 3], f32), np.array([4, 5, 6], f32))) - 0.974631846) < 1e-6
+    rng = np.random.default_rng(12)
+    for d in (3, 31, 32, 33, 100, 768):
+        rows = rng.standard_normal((40, d)).astype(f32)
+        q = rng.standard_normal(d).astype(f32)
+        want = np.array([scalar(q, r) for r in rows], dtype=f32)
+        got = np.array([oracle.cosine_scalar(q, r) for r in rows], dtype=f32)
+        assert np.array_equal(got, want), d
+        idx, sc = oracle.parallel_top_k(q, rows, 10, metric=oracle.COSINE_SCALAR)
+        order = np.lexsort((np.arange(40), -want.astype(np.float64)))[:10]
+        assert np.array_equal(idx, order.astype(np.uint64)) and np.array_equal(sc, want[order]), d
+    # a zero vector scores 0.0 (norm product == 0), never NaN
+    assert oracle.cosine_scalar(np.zeros(40, f32), np.ones(40, f32)) == 0.0
