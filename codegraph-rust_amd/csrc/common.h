@@ -420,6 +420,10 @@ __device__ inline void cmpx_desc32(uint32_t& x, uint32_t& y) {
     x = hi;
     y = lo;
 }
+// COHERENT: the values were written by OTHER workgroups of the same launch with agent-scope (sc1, write-through) stores and
+// are read here with agent-scope loads, which never hit a stale line of this CU's L1 or this XCD's L2 - no acquire fence
+// (MI355X_MICROARCH.md: a buffer_inv / buffer_wbl2 pair per hand-off is what makes a fenced hand-off 2-3x dearer).
+template <bool COHERENT = false>
 __device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k, int lane) {
     uint32_t r[16];
     // lane l owns elements 4l..4l+3 of every 256-element slab (16-byte loads, coalesced); M <= 1024
@@ -427,7 +431,12 @@ __device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k,
     for (int j = 0; j < 4; ++j) {
         const uint32_t e = 256u * j + 4u * (uint32_t)lane;
         float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (e + 3 < M) {
+        if (COHERENT) {
+            if (e < M) v.x = __hip_atomic_load(d + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e + 1 < M) v.y = __hip_atomic_load(d + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e + 2 < M) v.z = __hip_atomic_load(d + e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e + 3 < M) v.w = __hip_atomic_load(d + e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (e + 3 < M) {
             v = *(const float4*)(d + e);
         } else {
             if (e < M) v.x = d[e];

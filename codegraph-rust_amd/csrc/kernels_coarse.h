@@ -101,7 +101,8 @@ struct CoarseArgs {
     uint32_t* pace;         // [W] progress words of the workgroups (Pace below); NULL = no pacing
     uint32_t sample_ld;     // SAMPLE mode: floats per query row of `dump`
     uint32_t sample_vals;   // SAMPLE mode: group maxima per (query, tile): 16, 8 or 4 (tile_epilogue)
-    uint32_t epi;           // A/B switches (scripts/ab.py): bit 0 clear = round-2 epilogue (bf16 build only); bit 1 = no NT hint
+    uint32_t epi;           // A/B switches (scripts/ab.py): bit 0 clear = round-2 epilogue (bf16 build only); bit 1 = no NT hint;
+                            // bits 3-5: issue-side / loop forms (coarse_launch_2byte.h); bit 6: s_setprio 1 for waves 4-7
     // COARSE_EMIT_BOOT (the fused sample + first emitting launch, BootSync below)
     float* tau_out;         // [nq] the first thresholds, written by the launch itself
     uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
@@ -440,9 +441,10 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // the only ones whose maxima its queries need: nsplit <= 64 workgroups) at a rendezvous; each then computes the threshold of
 // its share of the tile's 256 queries (kth_largest_wave over the nsplit x 16 maxima), a second rendezvous makes all 256
 // thresholds visible, and the kept accumulators are filtered with them - the walk continues as an ordinary emitting launch.
-// Rendezvous = one monotonic arrival counter per query tile and phase (release fence -> relaxed agent-scope add; ONE wave
-// polls with relaxed loads + s_sleep, the others wait at s_barrier; acquire fence after - MI355X_MICROARCH.md, row
-// barrier-counter; the groups are 16-64 workgroups, not the grid).
+// Rendezvous = one monotonic arrival counter per query tile and phase: payload written with agent-scope write-through stores
+// and drained (s_waitcnt vmcnt(0)) -> relaxed agent-scope add; ONE lane polls with relaxed loads + s_sleep, the other waves
+// wait at s_barrier; the payload is then read with agent-scope loads - no fences (MI355X_MICROARCH.md, rows barrier-counter /
+// handoff-flag; the groups are 16-64 workgroups, not the grid).
 // It needs the group co-resident, which a plain launch cannot promise (another process' kernel, a second batch in flight on
 // the device): every wait is BOUNDED (BOOT_TIMEOUT_TICKS of the 100 MHz wall clock). A workgroup that times out raises the
 // group's `degraded` word - every later wait of the group ends on it - marks its 256 queries `overflow` (the final kernel
@@ -462,12 +464,12 @@ __device__ inline BootSync boot_sync_of(const CoarseArgs& a, uint32_t qt) {
 __device__ inline void boot_thresholds(const float* dump, float* tau_out, uint32_t sample_ld, uint32_t kprime,
                                                           uint32_t q0, uint32_t qstep, uint32_t qend, uint32_t nq, int lane) {
     for (uint32_t q = q0; q < qend && q < nq; q += qstep) {
-        const float t = kth_largest_wave(dump + (uint64_t)q * sample_ld, sample_ld, kprime, lane);
+        const float t = kth_largest_wave<true>(dump + (uint64_t)q * sample_ld, sample_ld, kprime, lane);
         if (lane == 0) __hip_atomic_store(tau_out + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// ONE lane: arrive (the caller's data was released by a fence + s_waitcnt before) and wait for `need` arrivals.
+// ONE lane: arrive (the caller's write-through stores were drained before) and wait for `need` arrivals.
 // Returns false when the group is degraded (timeout here or elsewhere).
 __device__ inline bool boot_rendezvous(uint32_t* counter, uint32_t* degraded, uint32_t need) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,6 +528,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     uint32_t qt, split;
     const uint32_t g = block_to_work(a, qt, split);
     const Pace pace = pace_init(a, g, qt);
+
+    // A/B probe (epi bit 6; MI355X_MICROARCH.md "Two waves per SIMD", item 4): static priority for the second-dispatched half
+    // of the workgroup, the arbitration loser of every SIMD pair. `wave` is a readfirstlane value: a scalar branch around ONE
+    // s_setprio (a per-thread condition would be if-converted into an unconditional one).
+    if ((a.epi & 64u) != 0u && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
 
@@ -842,13 +849,18 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     auto boot_block = [&](uint32_t tile0, const float* inv0, const float* stat0) __attribute__((always_inline)) {
         if constexpr (MODE == 3) {
             const BootSync bs = boot_sync_of(a, qt);
+            // Hand-offs between workgroups use NO fences (round-4 measurement: with a release fence per wave before each arrival
+            // and an acquire after it - 16 x buffer_wbl2 + 16 x buffer_inv per workgroup, each walking an L2 that also held
+            // 64 MB of dirty stash - this block cost 120 us per launch). Instead: what other workgroups read (the maxima, the
+            // thresholds) is written with agent-scope write-through (sc1) stores, drained with s_waitcnt vmcnt(0) before the
+            // arrival, and read with agent-scope loads (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag").
             // (1) block by block: the block's contribution to the tile's group maxima (tile_epilogue's SAMPLE layout: 16 / 8 / 4
             // values per (query, tile) at a.dump[q][split * vals ..]), then the block's 16 accumulators go to the STASH - the
             // first tile's accumulators wait out the rendezvous in GLOBAL memory, not in registers (with 128 accumulators live
             // across it the kernel went over 256 VGPRs and the allocator spilled values that the cold hit paths of the WHOLE
             // kernel then reloaded from scratch, behind a vmcnt(0) = behind the DMA in flight). The stash is the workgroup's own
-            // candidate-list region, still empty: nothing is emitted before the first threshold exists. 32 coalesced 16-byte
-            // stores per lane, 32 loads afterwards: ~256 KiB per workgroup through the L2, once per launch.
+            // candidate-list region, still empty: nothing is emitted before the first threshold exists. Plain stores: only this
+            // workgroup reads them back (same CU, same L2). 32 coalesced 16-byte stores per lane, 32 loads afterwards.
             float4* stash = (float4*)(a.cand + (uint64_t)g * BN * CAND_CAPS) + (uint32_t)wave * 2048u + (uint32_t)lane;
             const uint32_t lg = (uint32_t)(wm * 2 + (lane >> 5));  // the lane's row group within the tile: 0..3
 #pragma unroll
@@ -873,36 +885,37 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 const uint32_t q = qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
                 if (q < a.nq) {
                     float* dst = a.dump + (uint64_t)q * a.sample_ld + split * a.sample_vals;
+                    auto put = [&](uint32_t i, float v) { __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
                     if (a.sample_vals == 16u) {
-                        *(float4*)(dst + lg * 4u) = make_float4(m[0], m[1], m[2], m[3]);
+                        put(lg * 4u, m[0]);
+                        put(lg * 4u + 1u, m[1]);
+                        put(lg * 4u + 2u, m[2]);
+                        put(lg * 4u + 3u, m[3]);
                     } else if (a.sample_vals == 8u) {
-                        *(float2*)(dst + lg * 2u) = make_float2(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                        put(lg * 2u, fmaxf(m[0], m[1]));
+                        put(lg * 2u + 1u, fmaxf(m[2], m[3]));
                     } else {
-                        dst[lg] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                        put(lg, fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back is done before the arrival (guide: the pass drops it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left (write-through: they are in memory)
             __builtin_amdgcn_s_barrier();
             // rendezvous A: every workgroup of the query tile has published its maxima. ONE lane waits; the verdict reaches the
             // other waves through LDS (every wave of the workgroup must act on the SAME verdict).
             if (tid == 0) boot_ok_s = boot_rendezvous(bs.arrive_a, bs.degraded, a.nsplit) ? 1u : 0u;
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const bool ok_a = boot_ok_s != 0u;
             // (2) thresholds of this workgroup's share of the query tile: queries split + nsplit * (wave + 8 j), one wave each
             if (ok_a)
                 boot_thresholds(a.dump, a.tau_out, a.sample_ld, a.kprime, qt * (uint32_t)BN + split + (uint32_t)wave * a.nsplit,
                                 8u * a.nsplit, (qt + 1u) * (uint32_t)BN, a.nq, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // (also: every wave has read boot_ok_s before it is rewritten)
             // rendezvous B counts PUBLISHED shares only: a workgroup that did not compute its thresholds never arrives, so a full
             // count means all 256 thresholds of the tile exist; the others leave through `degraded` (set before anyone skips)
             if (tid == 0) boot_ok_s = (ok_a && boot_rendezvous(bs.arrive_b, bs.degraded, a.nsplit)) ? 1u : 0u;
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const bool good = boot_ok_s != 0u;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)

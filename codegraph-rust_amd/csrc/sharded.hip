@@ -167,10 +167,13 @@ struct Shard {
     Buf stage;                 // ingest staging
     struct SlotBufs {          // one set per batch in flight
         Buf qdev, oidx, osc, rec, gathered;
-        uint64_t ticket = 0;   // the shard's own search ticket (cgv_search_begin_f32_dev)
-        int rc_a = CGV_OK;     // status of the first half (queries in + search enqueued)
+        uint64_t ticket = 0;   // the shard's own search ticket (cgv_search_begin_f32_dev / cgv_search_packed_begin_f32_dev)
+        int rc_a = CGV_OK;     // status of the first half (queries in + search enqueued + records packed + exchange posted)
         std::string err_a;
-        std::chrono::steady_clock::time_point t_search_done;
+        bool packed = false;   // the ticket is a packed one (cgv_search_packed_end)
+        int xerr = 0;          // this shard's ncclAllGather CALL failed (the communicators were aborted by its job)
+        int repacked = 0;      // cgv_search_packed_end replaced provisional records
+        hipEvent_t x0 = nullptr, x1 = nullptr;  // root only: records ready -> merged results copied (last_exchange_ms)
     } slot[3];
     Worker w;
 };
@@ -195,6 +198,8 @@ struct cgv_sharded {
         float* pin_q = nullptr;
         size_t pin_q_bytes = 0;
         Buf moidx, mosc;  // merged results, on the root device
+        uint32_t* pin_redo = nullptr;  // pinned word the merge kernel raises when a record was PROVISIONAL (cgvec.h)
+        bool merged_in_begin = false;  // RCCL exchange: the root's merge + result copy were enqueued by the first half
         uint64_t* out_idx = nullptr;
         float* out_score = nullptr;
         std::vector<uint64_t> job_a;  // per shard: sequence number of the first-half job
@@ -207,7 +212,7 @@ struct cgv_sharded {
     // a handle over ONE shard normally skips pack / exchange / merge; CGV_SHARDED_FORCE_EXCHANGE=1 (read at create) runs them
     // anyway - a one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
     bool force_xch = false;
-    uint64_t searches = 0, queries = 0;
+    uint64_t searches = 0, queries = 0, redo_batches = 0;
     float last_search_ms = 0.0f, last_exchange_ms = 0.0f;
 };
 
@@ -423,8 +428,11 @@ int cgv_sharded_destroy(cgv_sharded* s) {
         if (sh->comm && r && !s->comms_aborted) (void)r->CommDestroy(sh->comm);
         if (sh->ix) (void)cgv_destroy(sh->ix);
         sh->stage.release();
-        for (auto& sb : sh->slot)
+        for (auto& sb : sh->slot) {
             for (Buf* b : {&sb.qdev, &sb.oidx, &sb.osc, &sb.rec, &sb.gathered}) b->release();
+            if (sb.x0) (void)hipEventDestroy(sb.x0);
+            if (sb.x1) (void)hipEventDestroy(sb.x1);
+        }
         if (sh->xs) (void)hipStreamDestroy(sh->xs);
     }
     if (!s->sh.empty()) {
@@ -434,8 +442,10 @@ int cgv_sharded_destroy(cgv_sharded* s) {
             sl.mosc.release();
         }
     }
-    for (auto& sl : s->slots)
+    for (auto& sl : s->slots) {
         if (sl.pin_q) (void)hipHostFree(sl.pin_q);
+        if (sl.pin_redo) (void)hipHostFree(sl.pin_redo);
+    }
     for (Shard* sh : s->sh) delete sh;
     delete s;
     return CGV_OK;
@@ -607,14 +617,7 @@ int cgv_sharded_set_exchange(cgv_sharded* s, int kind) {
     return set_exchange_locked(s, kind);
 }
 
-// ---- search: batches in flight ----------------------------------------------------------------------
-// begin  = slot + buffers, one host pass of the queries into pinned staging, then per shard (its worker thread):
-//          H2D over the shard's own PCIe link + cgv_search_begin_f32_dev (the single-device pipeline, enqueued, no wait);
-// end    = per shard: cgv_search_end (its results exist), pack, the exchange (ncclAllGather posted by EVERY shard,
-//          whatever its own search returned - a collective some rank skips hangs the others; or the copy into the root's
-//          gather buffer) and the stream wait; then ONE join of the workers, the root's merge and the result copy.
-// A caller that keeps two batches in flight (begin i+1 before end i) overlaps batch i's exchange + merge + D2H with
-// batch i+1's search on the devices.
+// ---- search: batches in flight (cgv_sharded_search_begin_f32 / _end, below) ----------------------------------------
 namespace {
 
 int slot_of_ticket(cgv_sharded* s, uint64_t ticket, cgv_sharded::Slot** out) {
@@ -665,6 +668,27 @@ void abort_rccl(cgv_sharded* s, const Rccl* r) {
 
 }  // namespace
 
+// Root side of the exchange: merge the G gathered record blocks (raising the slot's redo word on a provisional record) and
+// copy the merged results to the caller's host arrays, all on the root's stream, no wait. The root device is current.
+static int enqueue_root_merge(cgv_sharded* s, cgv_sharded::Slot& sl, int si) {
+    Shard* root = s->sh[0];
+    int rc = cgv_merge_packed_flag_dev(root->device, (const uint32_t*)root->slot[si].gathered.p, s->G, sl.nq, sl.k,
+                                       (uint64_t*)sl.moidx.p, (float*)sl.mosc.p, sl.pin_redo, root->xs);
+    if (rc) return rc;
+    SHIP(hipMemcpyAsync(sl.out_idx, sl.moidx.p, (size_t)sl.nq * sl.k * 8, hipMemcpyDeviceToHost, root->xs));
+    SHIP(hipMemcpyAsync(sl.out_score, sl.mosc.p, (size_t)sl.nq * sl.k * 4, hipMemcpyDeviceToHost, root->xs));
+    return CGV_OK;
+}
+
+// Round 4: NO host join between a shard's search and the exchange. The first half (begin) enqueues, per shard and on its
+// worker thread: queries in -> cgv_search_packed_begin_f32_dev (search + records packed on the search's own stream; the
+// shard's exchange stream waits for them by an event) -> the exchange, straight behind:
+//   RCCL  ncclAllGather posted by EVERY shard right here (also by one whose search failed to enqueue: a collective some rank
+//         skips never completes on the others); the root also enqueues merge + result copy behind its all-gather;
+//   COPY  the records go into the root's gather buffer; the root merges in the second half, once every copy has landed.
+// The second half (end) is ONE join: every shard waits for its stream and ends its search (cgv_search_packed_end: status,
+// exact scan + re-pack of provisional records). The merge raised the slot's pinned redo word if any record was provisional
+// (a query whose top-k a shard could not prove on the device): only then is the exchange repeated with the final records.
 int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint32_t nq, uint32_t k,
                                  uint64_t* out_idx_host, float* out_score_host, uint64_t* ticket) {
     if (!ticket) return fail(CGV_ERR_INVALID_ARG, "ticket is NULL");
@@ -688,6 +712,8 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
     const uint32_t w = cgv_packed_width(k);
     const size_t qbytes = (size_t)nq * D * 4, rec_bytes = (size_t)nq * w * 4;
     Shard* root = s->sh[0];
+    const bool xch = G > 1 || s->force_xch;
+    const int exchange = s->exchange;
     if (sl.pin_q_bytes < qbytes) {  // (the slot is idle: nothing reads its staging)
         if (sl.pin_q) (void)hipHostFree(sl.pin_q);
         sl.pin_q = nullptr;
@@ -696,25 +722,40 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
         SHIP(hipHostMalloc((void**)&sl.pin_q, qbytes, hipHostMallocPortable));
         sl.pin_q_bytes = qbytes;
     }
+    if (!sl.pin_redo) {
+        SHIP(hipSetDevice(root->device));
+        SHIP(hipHostMalloc((void**)&sl.pin_redo, 64, hipHostMallocPortable | hipHostMallocMapped));
+    }
     for (Shard* sh : s->sh) {
         SHIP(hipSetDevice(sh->device));
         Shard::SlotBufs& b = sh->slot[si];
         int rc;
         if ((rc = b.qdev.ensure(qbytes))) return rc;
-        if ((rc = b.oidx.ensure((size_t)nq * k * 8))) return rc;
-        if ((rc = b.osc.ensure((size_t)nq * k * 4))) return rc;
-        if (G > 1 || s->force_xch) {
+        if (!xch) {
+            if ((rc = b.oidx.ensure((size_t)nq * k * 8))) return rc;
+            if ((rc = b.osc.ensure((size_t)nq * k * 4))) return rc;
+        } else {
             if ((rc = b.rec.ensure(rec_bytes))) return rc;
-            if ((s->exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = b.gathered.ensure((size_t)G * rec_bytes))) return rc;
+            if ((exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = b.gathered.ensure((size_t)G * rec_bytes))) return rc;
+        }
+        if (sh == root && !b.x0) {
+            SHIP(hipEventCreate(&b.x0));
+            SHIP(hipEventCreate(&b.x1));
         }
     }
-    if (G > 1 || s->force_xch) {
+    if (xch) {
         SHIP(hipSetDevice(root->device));
         int rc;
         if ((rc = sl.moidx.ensure((size_t)nq * k * 8))) return rc;
         if ((rc = sl.mosc.ensure((size_t)nq * k * 4))) return rc;
     }
+    const Rccl* rccl = nullptr;
+    if (xch && exchange == CGV_EXCHANGE_RCCL) {
+        std::string why;
+        if (!(rccl = load_rccl(&why))) return fail(CGV_ERR_HIP, "librccl could not be loaded: " + why);
+    }
     memcpy(sl.pin_q, queries_host, qbytes);  // one pass; every device then pulls it over its own link
+    *sl.pin_redo = 0u;                       // (the slot is idle: no kernel writes it)
     sl.busy = true;
     sl.gen++;
     sl.nq = nq;
@@ -722,22 +763,63 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
     sl.out_idx = out_idx_host;
     sl.out_score = out_score_host;
     sl.t0 = Clock::now();
+    sl.merged_in_begin = xch && exchange == CGV_EXCHANGE_RCCL;
     sl.job_a.assign(G, 0);
     const float* pin_q = sl.pin_q;
+    cgv_sharded::Slot* slp = &sl;
     for (uint32_t g = 0; g < G; ++g) {
         Shard* sh = s->sh[g];
         sl.job_a[g] = sh->w.post([=]() -> int {
             Shard::SlotBufs& b = sh->slot[si];
             b.ticket = 0;
             b.rc_a = CGV_OK;
-            auto half = [&]() -> int {
+            b.packed = xch;
+            b.xerr = 0;
+            b.repacked = 0;
+            auto search_half = [&]() -> int {
                 SHIP(hipMemcpyAsync(b.qdev.p, pin_q, qbytes, hipMemcpyHostToDevice, sh->xs));
-                return cgv_search_begin_f32_dev(sh->ix, (const float*)b.qdev.p, nq, k, (uint64_t*)b.oidx.p, (float*)b.osc.p,
-                                                &b.ticket);
+                if (!xch)
+                    return cgv_search_begin_f32_dev(sh->ix, (const float*)b.qdev.p, nq, k, (uint64_t*)b.oidx.p, (float*)b.osc.p,
+                                                    &b.ticket);
+                return cgv_search_packed_begin_f32_dev(sh->ix, (const float*)b.qdev.p, nq, k, (uint32_t*)b.rec.p, (void*)sh->xs,
+                                                       &b.ticket);
             };
-            b.rc_a = half();
+            b.rc_a = search_half();
             if (b.rc_a) b.err_a = cgv_last_error();
-            return CGV_OK;  // the status travels with the slot: the second half reports it
+            if (!xch) return CGV_OK;  // the status travels with the slot: the second half reports it
+            if (sh == root) (void)hipEventRecord(b.x0, sh->xs);   // the root's records are ready
+            if (exchange == CGV_EXCHANGE_RCCL) {
+                // entered by every shard, whatever its own search returned (the buffers exist; the batch's status discards
+                // the result): a collective that one rank skips never completes on the others
+                const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                if (e != 0) {
+                    b.xerr = 1;
+                    if (b.rc_a == CGV_OK) {
+                        b.rc_a = CGV_ERR_HIP;
+                        b.err_a = std::string("ncclAllGather: ") + rccl->GetErrorString(e);
+                    }
+                    abort_comms_now(s, rccl);  // the other ranks posted theirs and will wait on their streams: unblock them
+                    return CGV_OK;
+                }
+                if (sh == root && b.rc_a == CGV_OK) {
+                    const int mrc = enqueue_root_merge(s, *slp, si);
+                    if (mrc) {
+                        b.rc_a = mrc;
+                        b.err_a = cgv_last_error();
+                    }
+                    (void)hipEventRecord(b.x1, sh->xs);
+                }
+            } else if (b.rc_a == CGV_OK) {
+                char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
+                const hipError_t he = sh->device == root->device
+                                          ? hipMemcpyAsync(dst, b.rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs)
+                                          : hipMemcpyPeerAsync(dst, root->device, b.rec.p, sh->device, rec_bytes, sh->xs);
+                if (he != hipSuccess) {
+                    b.rc_a = CGV_ERR_HIP;
+                    b.err_a = std::string("exchange copy: ") + hipGetErrorString(he);
+                }
+            }
+            return CGV_OK;
         });
     }
     *ticket = ((uint64_t)sl.gen << 8) | (uint64_t)(si + 1);
@@ -757,99 +839,122 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
     const uint32_t w = cgv_packed_width(k);
     const size_t rec_bytes = (size_t)nq * w * 4;
     Shard* root = s->sh[0];
-    const int exchange = s->exchange;
     const bool xch = G > 1 || s->force_xch;
+    const bool rccl_mode = sl.merged_in_begin;  // the exchange the first half used
     std::string why;
-    const Rccl* rccl = exchange == CGV_EXCHANGE_RCCL ? load_rccl(&why) : nullptr;
-    std::vector<std::function<int()>> jobs(G);
-    std::vector<int> xerr(G, 0);  // a rank's collective call failed
-    for (uint32_t g = 0; g < G; ++g) {
-        Shard* sh = s->sh[g];
-        int* xe = &xerr[g];
-        jobs[g] = [=]() -> int {
-            Shard::SlotBufs& b = sh->slot[si];
-            int rc = b.rc_a;
-            std::string err = b.err_a;
-            if (rc == CGV_OK && b.ticket) {
-                rc = cgv_search_end(sh->ix, b.ticket);
-                if (rc) err = cgv_last_error();
-            }
-            b.t_search_done = Clock::now();
-            if (xch) {
-                if (rc == CGV_OK) {
-                    rc = cgv_pack_topk_dev(sh->device, (const uint64_t*)b.oidx.p, (const float*)b.osc.p, nq, k, (uint32_t*)b.rec.p,
-                                           sh->xs);
-                    if (rc) err = cgv_last_error();
-                }
-                if (exchange == CGV_EXCHANGE_RCCL) {
-                    // entered by every shard, also after a failure of its own (the buffers exist; the batch's status
-                    // discards the result): a collective that one rank skips never completes on the others
-                    const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
-                    if (e != 0) {
-                        *xe = 1;
-                        if (rc == CGV_OK) {
-                            rc = CGV_ERR_HIP;
-                            err = std::string("ncclAllGather: ") + rccl->GetErrorString(e);
-                        }
-                        abort_comms_now(s, rccl);  // the other ranks posted theirs and wait on the stream: unblock them
-                        return fail(rc, err);      // no stream wait here
-                    }
-                } else if (rc == CGV_OK) {
-                    char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
-                    hipError_t he = sh->device == root->device
-                                        ? hipMemcpyAsync(dst, b.rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs)
-                                        : hipMemcpyPeerAsync(dst, root->device, b.rec.p, sh->device, rec_bytes, sh->xs);
-                    if (he != hipSuccess) {
-                        rc = CGV_ERR_HIP;
-                        err = std::string("exchange copy: ") + hipGetErrorString(he);
-                    }
-                }
-            }
-            const hipError_t se = hipStreamSynchronize(sh->xs);
-            if (se != hipSuccess && rc == CGV_OK) {
-                rc = CGV_ERR_HIP;
-                err = std::string("hipStreamSynchronize: ") + hipGetErrorString(se);
-            }
-            return rc ? fail(rc, err) : CGV_OK;
-        };
-    }
-    int rc = run_all(s, jobs);  // the ONE host join of the batch
-    bool any_xerr = false;
-    for (int e : xerr) any_xerr = any_xerr || e;
-    if (any_xerr) {
-        const std::string msg = cgv_last_error();
-        abort_rccl(s, rccl);
-        drain_streams(s);
-        rc = fail(rc ? rc : CGV_ERR_HIP, msg + " (RCCL communicators aborted; the handle continues with the copy exchange)");
-    }
+    const Rccl* rccl = rccl_mode ? load_rccl(&why) : nullptr;
     auto finish = [&](int code) {
         sl.busy = false;
         s->slot_cv.notify_all();
         return code;
     };
-    if (rc) return finish(rc);
-    auto t1 = s->sh[0]->slot[si].t_search_done;
-    for (Shard* sh : s->sh) t1 = std::max(t1, sh->slot[si].t_search_done);
-    hipError_t he = hipSetDevice(root->device);
-    const uint64_t* ri = (const uint64_t*)root->slot[si].oidx.p;
-    const float* rs = (const float*)root->slot[si].osc.p;
-    if (he == hipSuccess && xch) {
-        rc = cgv_merge_packed_dev(root->device, (const uint32_t*)root->slot[si].gathered.p, G, nq, k, (uint64_t*)sl.moidx.p,
-                                  (float*)sl.mosc.p, root->xs);
-        ri = (const uint64_t*)sl.moidx.p;
-        rs = (const float*)sl.mosc.p;
+    // ---- the ONE join: every shard's stream idle, every search ended ----
+    std::vector<std::function<int()>> jobs(G);
+    for (uint32_t g = 0; g < G; ++g) {
+        Shard* sh = s->sh[g];
+        jobs[g] = [=]() -> int {
+            Shard::SlotBufs& b = sh->slot[si];
+            int rc = b.rc_a;
+            std::string err = b.err_a;
+            const hipError_t se = hipStreamSynchronize(sh->xs);  // exchange (and, RCCL root, merge + result copy) done
+            if (se != hipSuccess && rc == CGV_OK) {
+                rc = CGV_ERR_HIP;
+                err = std::string("hipStreamSynchronize: ") + hipGetErrorString(se);
+            }
+            if (b.ticket) {  // ends the search whatever happened around it (the context must be released)
+                const int erc = b.packed ? cgv_search_packed_end(sh->ix, b.ticket, &b.repacked) : cgv_search_end(sh->ix, b.ticket);
+                if (erc && rc == CGV_OK) {
+                    rc = erc;
+                    err = cgv_last_error();
+                }
+                b.ticket = 0;
+            }
+            return rc ? fail(rc, err) : CGV_OK;
+        };
     }
-    if (rc == CGV_OK && he == hipSuccess) he = hipMemcpyAsync(sl.out_idx, ri, (size_t)nq * k * 8, hipMemcpyDeviceToHost, root->xs);
-    if (rc == CGV_OK && he == hipSuccess) he = hipMemcpyAsync(sl.out_score, rs, (size_t)nq * k * 4, hipMemcpyDeviceToHost, root->xs);
-    const hipError_t se = hipStreamSynchronize(root->xs);  // also on the error paths: nothing stays in flight
-    if (rc == CGV_OK && he == hipSuccess) he = se;
-    if (rc == CGV_OK && he != hipSuccess) rc = fail(CGV_ERR_HIP, std::string("sharded search, result copy: ") + hipGetErrorString(he));
+    int rc = run_all(s, jobs);
+    bool any_xerr = false;
+    for (Shard* sh : s->sh) any_xerr = any_xerr || sh->slot[si].xerr;
+    if (any_xerr) {
+        const std::string msg = rc ? cgv_last_error() : "a rank failed to post its ncclAllGather";
+        abort_rccl(s, rccl);
+        drain_streams(s);
+        rc = fail(rc ? rc : CGV_ERR_HIP, msg + " (RCCL communicators aborted; the handle continues with the copy exchange)");
+    }
     if (rc) return finish(rc);
+    hipError_t he = hipSetDevice(root->device);
+    if (he != hipSuccess) return finish(fail(CGV_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)));
+    if (!xch) {  // one shard, no exchange: its results go back as they are
+        he = hipMemcpyAsync(sl.out_idx, root->slot[si].oidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, root->xs);
+        if (he == hipSuccess) he = hipMemcpyAsync(sl.out_score, root->slot[si].osc.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, root->xs);
+        const hipError_t se = hipStreamSynchronize(root->xs);
+        if (he == hipSuccess) he = se;
+        if (he != hipSuccess) return finish(fail(CGV_ERR_HIP, std::string("sharded search, result copy: ") + hipGetErrorString(he)));
+    } else {
+        auto root_round = [&]() -> int {  // merge + result copy on the root, waited for
+            int r = enqueue_root_merge(s, sl, si);
+            (void)hipEventRecord(root->slot[si].x1, root->xs);
+            const hipError_t se = hipStreamSynchronize(root->xs);  // also on the error path: nothing stays in flight
+            if (r == CGV_OK && se != hipSuccess) r = fail(CGV_ERR_HIP, std::string("sharded search, merge: ") + hipGetErrorString(se));
+            return r;
+        };
+        if (!rccl_mode && (rc = root_round())) return finish(rc);  // COPY: every shard's records have landed (the join above)
+        if (*sl.pin_redo != 0u) {
+            // a shard could not prove a query on the device: its search has now run the exact scan and re-packed (the end
+            // jobs above) - the exchange is repeated once with the final records
+            *sl.pin_redo = 0u;
+            std::vector<std::function<int()>> again(G);
+            std::vector<int> xerr2(G, 0);
+            for (uint32_t g = 0; g < G; ++g) {
+                Shard* sh = s->sh[g];
+                int* xe = &xerr2[g];
+                again[g] = [=]() -> int {
+                    Shard::SlotBufs& b = sh->slot[si];
+                    if (rccl_mode) {
+                        const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                        if (e != 0) {
+                            *xe = 1;
+                            abort_comms_now(s, rccl);
+                            return fail(CGV_ERR_HIP, std::string("ncclAllGather: ") + rccl->GetErrorString(e));
+                        }
+                    } else {
+                        char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
+                        const hipError_t ce = sh->device == root->device
+                                                  ? hipMemcpyAsync(dst, b.rec.p, rec_bytes, hipMemcpyDeviceToDevice, sh->xs)
+                                                  : hipMemcpyPeerAsync(dst, root->device, b.rec.p, sh->device, rec_bytes, sh->xs);
+                        if (ce != hipSuccess) return fail(CGV_ERR_HIP, std::string("exchange copy: ") + hipGetErrorString(ce));
+                    }
+                    const hipError_t se = hipStreamSynchronize(sh->xs);
+                    return se == hipSuccess ? CGV_OK : fail(CGV_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
+                };
+            }
+            rc = run_all(s, again);
+            bool x2 = false;
+            for (int e : xerr2) x2 = x2 || e;
+            if (x2) {
+                const std::string msg = cgv_last_error();
+                abort_rccl(s, rccl);
+                drain_streams(s);
+                rc = fail(CGV_ERR_HIP, msg + " (RCCL communicators aborted; the handle continues with the copy exchange)");
+            }
+            if (rc) return finish(rc);
+            if (hipSetDevice(root->device) != hipSuccess) return finish(fail(CGV_ERR_HIP, "hipSetDevice(root)"));
+            if ((rc = root_round())) return finish(rc);
+            if (*sl.pin_redo != 0u) return finish(fail(CGV_ERR_INTERNAL, "records still provisional after the searches ended"));
+            s->redo_batches++;
+        }
+    }
     const auto t2 = Clock::now();
     s->searches++;
     s->queries += nq;
     s->last_search_ms = std::chrono::duration<float, std::milli>(t2 - sl.t0).count();
-    s->last_exchange_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    if (xch) {  // the root's records ready -> merged results copied to the host (events on the root's stream)
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, root->slot[si].x0, root->slot[si].x1) == hipSuccess) s->last_exchange_ms = ms;
+        else (void)hipGetLastError();
+    } else {
+        s->last_exchange_ms = 0.0f;
+    }
     return finish(CGV_OK);
 }
 
