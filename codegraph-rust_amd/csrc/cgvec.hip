@@ -166,7 +166,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, stash;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -183,7 +183,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace};
+                                &qshadow, &qres, &trace, &stash};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -191,7 +191,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace};
+                          &qshadow, &qres, &trace, &stash};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -911,15 +911,19 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         const uint32_t fvals = sample_vals_of(std::max<uint32_t>(nsplit0, 1u));
         const bool can_fuse = p.sample_tiles > 0 && nsplit0 > 0 && (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) && a.kc >= 4 &&
                               a.kc % 4 == 0 && nqt > 1 && nqt * 4u <= BOOT_WORDS && nsplit0 * fvals >= 4u * kprime &&
-                              nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 2 * nsplit0;  // (every workgroup walks >= 2 tiles)
+                              nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 3 * nsplit0;  // (every workgroup walks >= 3 tiles)
         const int fs = tun().fuse_sample;
         const bool fuse = can_fuse && (fs > 0 || (fs < 0 && dev_inflight(h) == 1));
         c->boot_used = fuse;
         a.tau_out = c->tau.as<float>();
         a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
         a.kprime = kprime;
+        a.boot_stash = nullptr;
         if (fuse) {
             if ((rc = c->dump.ensure((size_t)nq * nsplit0 * fvals * 4))) return rc;
+            // the first two tiles' accumulators of every workgroup wait for the thresholds here: 512 KiB per workgroup
+            if ((rc = c->stash.ensure((size_t)nqt * nsplit0 * 2 * 8 * 2048 * 16))) return rc;
+            a.boot_stash = c->stash.as<float4>();
         } else if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
             const uint32_t vals = sample_vals_of(p.sample_tiles);
@@ -2300,6 +2304,7 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.epi = 1;
     a.tau_out = nullptr;
     a.boot_sync = nullptr;
+    a.boot_stash = nullptr;
     a.kprime = 0;
     if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));

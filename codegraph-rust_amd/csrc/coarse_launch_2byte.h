@@ -52,7 +52,7 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         return coarse_hip_status("coarse_kernel (sample)");
     }
     if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (cgvec.hip: can_fuse)
-        if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.tau_out && a.dump && a.cnt >= 2 * a.nsplit))
+        if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.boot_stash && a.tau_out && a.dump && a.cnt >= 3 * a.nsplit))
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT launched on a shape it does not serve");
         hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (emit + boot)");

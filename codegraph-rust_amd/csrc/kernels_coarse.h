@@ -106,6 +106,7 @@ struct CoarseArgs {
     // COARSE_EMIT_BOOT (the fused sample + first emitting launch, BootSync below)
     float* tau_out;         // [nq] the first thresholds, written by the launch itself
     uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
+    float4* boot_stash;     // [W][2][8 waves][2048] the first two tiles' accumulators of every workgroup (512 KiB each)
     uint32_t kprime;        // the threshold is the k'-th largest group maximum
 };
 
@@ -436,15 +437,26 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 // ---- COARSE_EMIT_BOOT: sample + first threshold + first emitting pass in ONE launch (round 4) ----------
 // Round 3 spent three launches on the first threshold: a sample launch (one tile per workgroup, block maxima only), tau_kernel,
 // then the first emitting launch, which scored the sample tiles AGAIN - 32 + 7 us + two launch boundaries + a second ramp per
-// batch, and 13 % of a 125 k-row shard scored twice. Here every workgroup scores the FIRST tile of its walk, keeps the
-// accumulators in its registers, publishes the tile's group maxima, and meets the other workgroups of its QUERY TILE (they are
-// the only ones whose maxima its queries need: nsplit <= 64 workgroups) at a rendezvous; each then computes the threshold of
-// its share of the tile's 256 queries (kth_largest_wave over the nsplit x 16 maxima), a second rendezvous makes all 256
-// thresholds visible, and the kept accumulators are filtered with them - the walk continues as an ordinary emitting launch.
-// Rendezvous = one monotonic arrival counter per query tile and phase: payload written with agent-scope write-through stores
-// and drained (s_waitcnt vmcnt(0)) -> relaxed agent-scope add; ONE lane polls with relaxed loads + s_sleep, the other waves
-// wait at s_barrier; the payload is then read with agent-scope loads - no fences (MI355X_MICROARCH.md, rows barrier-counter /
-// handoff-flag; the groups are 16-64 workgroups, not the grid).
+// batch, and 13 % of a 125 k-row shard scored twice. Here the first tile of every workgroup's walk IS its sample, and nothing
+// waits for anything it can avoid:
+//   boundary tile 0 -> 1   the tile's group maxima are published (one 16-value record per lane and N-block, what the sample
+//                          launch wrote), its 128 accumulators per lane go to a STASH in global memory, the workgroup ARRIVES at
+//                          rendezvous A of its QUERY TILE (the nsplit <= 64 workgroups whose maxima its queries need - not the
+//                          grid) and walks on: tile 1 is scored while the others publish;
+//   boundary tile 1 -> 2   tile 1's accumulators are stashed too (nothing is live in registers now), rendezvous A is complete
+//                          (everybody arrived a tile-time ago: the wait is a formality), the workgroup computes the thresholds
+//                          of its share of the tile's 256 queries (kth_largest_wave over nsplit x 16 maxima, one wave per
+//                          query), publishes them, meets the others at rendezvous B, reads all thresholds of its lanes' queries
+//                          and filters the two STASHED tiles with them (block by block out of the L2: 16 scores per lane, the
+//                          ordinary block_hits slow path for the few that pass); from tile 2 on it is an ordinary emitting walk.
+// First form of this (kept in profiles/r04b_fused_ab.txt): rendezvous + thresholds right at the first boundary with the first
+// tile's accumulators held back - in registers it spilled (and the allocator's spill choices reached the cold hit paths of the
+// whole kernel), stashed it cost the wait: 53 us per launch against the ~50 us of the three launches it replaced.
+// Hand-offs use NO fences: what other workgroups read (maxima, thresholds) is written with agent-scope write-through (sc1)
+// stores, drained with s_waitcnt vmcnt(0) before the arrival, and read with agent-scope loads (MI355X_MICROARCH.md: "sc1
+// payload -> vmcnt(0) -> sc1 flag"; with a release + acquire fence pair per wave and hand-off the block cost 120 us).
+// Rendezvous = one monotonic arrival counter per query tile and phase; ONE lane polls with relaxed loads + s_sleep, the other
+// waves wait at s_barrier.
 // It needs the group co-resident, which a plain launch cannot promise (another process' kernel, a second batch in flight on
 // the device): every wait is BOUNDED (BOOT_TIMEOUT_TICKS of the 100 MHz wall clock). A workgroup that times out raises the
 // group's `degraded` word - every later wait of the group ends on it - marks its 256 queries `overflow` (the final kernel
@@ -469,10 +481,12 @@ __device__ inline void boot_thresholds(const float* dump, float* tau_out, uint32
     }
 }
 
-// ONE lane: arrive (the caller's write-through stores were drained before) and wait for `need` arrivals.
-// Returns false when the group is degraded (timeout here or elsewhere).
-__device__ inline bool boot_rendezvous(uint32_t* counter, uint32_t* degraded, uint32_t need) {
+// ONE lane. Arrive: the caller's write-through stores were drained (s_waitcnt vmcnt(0)) before. Wait: for `need` arrivals;
+// false when the group is degraded (a timeout here or elsewhere).
+__device__ inline void boot_arrive(uint32_t* counter) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool boot_wait(uint32_t* counter, uint32_t* degraded, uint32_t need) {
     const uint64_t t0 = wall_clock64();
     for (;;) {
         if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
@@ -843,25 +857,19 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         CGV_THR(2, 0, mn4.z, mx4.z) CGV_THR(2, 1, mn4.z, mx4.z) CGV_THR(3, 0, mn4.w, mx4.w) CGV_THR(3, 1, mn4.w, mx4.w) \
     }
 
-    // COARSE_EMIT_BOOT: runs ONCE, at the workgroup's first tile boundary (or in the tail of a one-tile walk), between the
-    // tile's last MFMA and its filters; `tile0` / `inv0` / `stat0` = the first tile and its side data. See BootSync above.
+    // COARSE_EMIT_BOOT, the two peeled tile boundaries (BootSync above). stash_tile: the ended tile's accumulators -> global
+    // memory, block by block (32 coalesced 16-byte stores per lane; plain stores: only this workgroup reads them back).
     __shared__ uint32_t boot_ok_s;
-    auto boot_block = [&](uint32_t tile0, const float* inv0, const float* stat0) __attribute__((always_inline)) {
+    uint32_t boot_tile[2] = {0u, 0u};
+    auto stash_of = [&](int which) {
+        return a.boot_stash + (((uint64_t)g * 2u + (uint32_t)which) * 8u + (uint32_t)wave) * 2048u + (uint32_t)lane;
+    };
+    // boundary tile 0 -> 1: publish the tile's group maxima, stash it, ARRIVE (no wait)
+    auto boot_publish = [&](uint32_t tile0, const float* inv0) __attribute__((always_inline)) {
         if constexpr (MODE == 3) {
             const BootSync bs = boot_sync_of(a, qt);
-            // Hand-offs between workgroups use NO fences (round-4 measurement: with a release fence per wave before each arrival
-            // and an acquire after it - 16 x buffer_wbl2 + 16 x buffer_inv per workgroup, each walking an L2 that also held
-            // 64 MB of dirty stash - this block cost 120 us per launch). Instead: what other workgroups read (the maxima, the
-            // thresholds) is written with agent-scope write-through (sc1) stores, drained with s_waitcnt vmcnt(0) before the
-            // arrival, and read with agent-scope loads (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag").
-            // (1) block by block: the block's contribution to the tile's group maxima (tile_epilogue's SAMPLE layout: 16 / 8 / 4
-            // values per (query, tile) at a.dump[q][split * vals ..]), then the block's 16 accumulators go to the STASH - the
-            // first tile's accumulators wait out the rendezvous in GLOBAL memory, not in registers (with 128 accumulators live
-            // across it the kernel went over 256 VGPRs and the allocator spilled values that the cold hit paths of the WHOLE
-            // kernel then reloaded from scratch, behind a vmcnt(0) = behind the DMA in flight). The stash is the workgroup's own
-            // candidate-list region, still empty: nothing is emitted before the first threshold exists. Plain stores: only this
-            // workgroup reads them back (same CU, same L2). 32 coalesced 16-byte stores per lane, 32 loads afterwards.
-            float4* stash = (float4*)(a.cand + (uint64_t)g * BN * CAND_CAPS) + (uint32_t)wave * 2048u + (uint32_t)lane;
+            boot_tile[0] = tile0;
+            float4* stash = stash_of(0);
             const uint32_t lg = (uint32_t)(wm * 2 + (lane >> 5));  // the lane's row group within the tile: 0..3
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -901,35 +909,74 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left (write-through: they are in memory)
             __builtin_amdgcn_s_barrier();
-            // rendezvous A: every workgroup of the query tile has published its maxima. ONE lane waits; the verdict reaches the
-            // other waves through LDS (every wave of the workgroup must act on the SAME verdict).
-            if (tid == 0) boot_ok_s = boot_rendezvous(bs.arrive_a, bs.degraded, a.nsplit) ? 1u : 0u;
-            __builtin_amdgcn_s_barrier();
-            const bool ok_a = boot_ok_s != 0u;
-            // (2) thresholds of this workgroup's share of the query tile: queries split + nsplit * (wave + 8 j), one wave each
-            if (ok_a)
-                boot_thresholds(a.dump, a.tau_out, a.sample_ld, a.kprime, qt * (uint32_t)BN + split + (uint32_t)wave * a.nsplit,
-                                8u * a.nsplit, (qt + 1u) * (uint32_t)BN, a.nq, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // (also: every wave has read boot_ok_s before it is rewritten)
-            // rendezvous B counts PUBLISHED shares only: a workgroup that did not compute its thresholds never arrives, so a full
-            // count means all 256 thresholds of the tile exist; the others leave through `degraded` (set before anyone skips)
-            if (tid == 0) boot_ok_s = (ok_a && boot_rendezvous(bs.arrive_b, bs.degraded, a.nsplit)) ? 1u : 0u;
-            __builtin_amdgcn_s_barrier();
-            const bool good = boot_ok_s != 0u;
+            if (tid == 0) boot_arrive(bs.arrive_a);
+        }
+    };
+    // one stashed tile against the thresholds: block by block out of the L2, the ordinary slow path for blocks with a hit
+    auto filter_stashed = [&](int which, uint32_t tile, uint32_t seq) __attribute__((always_inline)) {
+        const float4* stash = stash_of(which);
+        const float* inv = invn_s + (seq & (NINV - 1)) * 256;
+        const float* st = stat_s + (seq & (NINV - 1)) * 16 + wm * MB;
+#pragma unroll 1
+        for (int blk = 0; blk < MB * NB; ++blk) {
+            const int mb = blk >> 1, nb = blk & 1;
+            f32x16_t v;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 x = stash[(blk * 4 + r4) * 64];
+                v[4 * r4] = x.x;
+                v[4 * r4 + 1] = x.y;
+                v[4 * r4 + 2] = x.z;
+                v[4 * r4 + 3] = x.w;
+            }
+            const bool one = nb ? tone[1] : tone[0], neg = nb ? tneg[1] : tneg[0];
+            const float tan = nb ? ta[1] : ta[0];
+            const float thr_b = tan * (one ? 1.0f : (neg ? st[8 + mb] : st[mb]));
+            float bm = v[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, v[r]);
+            if (__ballot(bm > thr_b) != 0ull)
+                block_hits<BM, BN>(a, v, thr_b, nb ? tauv[1] : tauv[0], nb ? invq[1] : invq[0], (uint32_t)(wm * WTM + mb * 32),
+                                   (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane, g, qt, cntq, inv);
+        }
+    };
+    // boundary tile 1 -> 2: stash tile 1, rendezvous A (a formality by now), thresholds, rendezvous B, filter both stashed tiles
+    auto boot_resolve = [&](uint32_t tile1) __attribute__((always_inline)) {
+        if constexpr (MODE == 3) {
+            const BootSync bs = boot_sync_of(a, qt);
+            boot_tile[1] = tile1;
+            float4* stash = stash_of(1);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const float4 v = stash[((mb * NB + nb) * 4 + r4) * 64];
-                        acc[mb][nb][4 * r4] = v.x;
-                        acc[mb][nb][4 * r4 + 1] = v.y;
-                        acc[mb][nb][4 * r4 + 2] = v.z;
-                        acc[mb][nb][4 * r4 + 3] = v.w;
-                    }
-            // (3) every lane's thresholds (its NB queries), or - degraded - no emission and the exact scan for the tile's queries
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        stash[((mb * NB + nb) * 4 + r4) * 64] = make_float4(acc[mb][nb][4 * r4], acc[mb][nb][4 * r4 + 1],
+                                                                             acc[mb][nb][4 * r4 + 2], acc[mb][nb][4 * r4 + 3]);
+            // ONE lane waits; the verdict reaches the other waves through LDS (every wave must act on the SAME verdict)
+            if (tid == 0) boot_ok_s = boot_wait(bs.arrive_a, bs.degraded, a.nsplit) ? 1u : 0u;
+            __builtin_amdgcn_s_barrier();
+            const bool ok_a = boot_ok_s != 0u;
+            // thresholds of this workgroup's share of the query tile: queries split + nsplit * (wave + 8 j), one wave each
+            if (ok_a)
+                boot_thresholds(a.dump, a.tau_out, a.sample_ld, a.kprime, qt * (uint32_t)BN + split + (uint32_t)wave * a.nsplit,
+                                8u * a.nsplit, (qt + 1u) * (uint32_t)BN, a.nq, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // thresholds (and the stash) have left
+            __builtin_amdgcn_s_barrier();   // (also: every wave has read boot_ok_s before it is rewritten)
+            // rendezvous B counts PUBLISHED shares only: a workgroup that did not compute its thresholds never arrives, so a full
+            // count means all 256 thresholds of the tile exist; the others leave through `degraded` (set before anyone skips)
+            if (tid == 0) {
+                bool ok = ok_a;
+                if (ok) {
+                    boot_arrive(bs.arrive_b);
+                    ok = boot_wait(bs.arrive_b, bs.degraded, a.nsplit);
+                }
+                boot_ok_s = ok ? 1u : 0u;
+            }
+            __builtin_amdgcn_s_barrier();
+            const bool good = boot_ok_s != 0u;
+            // every lane's thresholds (its NB queries), or - degraded - no emission and the exact scan for the tile's queries
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const uint32_t q = qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
@@ -944,6 +991,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 tneg[nb] = tq[nb] < 0.0f;
                 ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
             }
+            filter_stashed(0, boot_tile[0], 0u);
+            filter_stashed(1, boot_tile[1], 1u);
         }
     };
 
@@ -1037,11 +1086,17 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // rendezvous block sits between the ended tile's last MFMA and its filters. It is a PEELED copy of the loop body - inside
     // the loop the block's register pressure (it spills around the rendezvous, once per launch) reached the steady-state path.
     auto tile_iter = [&](uint32_t tl, auto boot_c) __attribute__((always_inline)) {
-        constexpr bool BOOT = decltype(boot_c)::value != 0;
+        constexpr int BOOT = decltype(boot_c)::value;   // 0 ordinary; 1 / 2: the peeled first two boundaries of COARSE_EMIT_BOOT
         {
             const char* sb = (SI >= 2) ? smem : smem + (s & (NSTAGE - 1)) * STAGE;
             if (SI >= 2) si_slot = (uint32_t)(3 * STAGE);
-            if (!EMIT || EPI == 0) {
+            if constexpr (BOOT != 0) {
+                // the ended tile's last k-step WITHOUT the early reads of the next tile's first fragments: 24 fewer live
+                // registers across the boot block (with them the kernel spilled, and the allocator's choice - the queries'
+                // inverse norms - was reloaded from scratch, behind a vmcnt(0), in every hit of the whole walk)
+                CGV_KSTEP_X(CGV_MMA, fa1, fb1, fa1, CGV_STAGE_SYNC, CGV_NOP_ACTION, CGV_NOP_ACTION, issue_q(0), CGV_NOP_ACTION,
+                            issue_q(1), CGV_NOP_ACTION, CGV_NOP_ACTION)
+            } else if (!EMIT || EPI == 0) {
                 CGV_B_PHASE(sb);
             } else {
                 CGV_B_PHASE_LAST(sb, tl - 1);
@@ -1050,11 +1105,14 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             const uint32_t nt = next_tile(ct);
             side_wait();
             if (EMIT && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
-            if constexpr (BOOT) {  // the first tile ends here: rendezvous, thresholds, then its filters below
-                boot_block(a.T1 + ct, invn_s, stat_s);
-                CGV_THR_ALL(0);
-            }
-            if (EMIT && EPI != 0) {
+            if constexpr (BOOT == 1) boot_publish(a.T1 + ct, invn_s);   // tile 0 ends: maxima out, stash, arrive - no wait
+            if constexpr (BOOT == 2) boot_resolve(a.T1 + ct);           // tile 1 ends: thresholds exist; both tiles filtered
+            if constexpr (BOOT != 0) {   // the ended tile was stashed: no filters in front of the zero-C MFMAs
+                issue_side(nt, tl);
+                ct = nt;
+                CGV_LOAD_FRAGS(fa0, fb0, sb, 0);   // the starting tile's first fragments (not read early, see above)
+                CGV_A_PHASE_Z(sb);
+            } else if (EMIT && EPI != 0) {
                 ftile = a.T1 + ct;
                 finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
                 issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)
@@ -1080,11 +1138,14 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             }
         }
     };
-    // COARSE_EMIT_BOOT: every workgroup walks >= 2 tiles (the launcher refuses anything else: cnt >= 2 * nsplit), so the
-    // peeled boundary is unconditional - no branch around MFMAs, no accumulator phis
-    if constexpr (MODE == 3) tile_iter(1u, IntC<1>{});
+    // COARSE_EMIT_BOOT: every workgroup walks >= 3 tiles (the launcher refuses anything else: cnt >= 3 * nsplit), so the two
+    // peeled boundaries are unconditional - no branch around MFMAs, no accumulator phis
+    if constexpr (MODE == 3) {
+        tile_iter(1u, IntC<1>{});
+        tile_iter(2u, IntC<2>{});
+    }
 #pragma unroll 1
-    for (uint32_t tl = (MODE == 3 ? 2u : 1u); tl < ntl; ++tl) tile_iter(tl, IntC<0>{});
+    for (uint32_t tl = (MODE == 3 ? 3u : 1u); tl < ntl; ++tl) tile_iter(tl, IntC<0>{});
 #undef CGV_TILE_REST_U4
 #undef CGV_ITER_AT
     // tail: second k-step of the last stage, then the last tile's epilogue
