@@ -479,6 +479,51 @@ __device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k,
     return (cnt >= k) ? ord2f(last) : -INFINITY;
 }
 
+// The same selection with T instead of 16 registers per lane: every lane keeps only the T largest of its <= 16 values
+// (insertion as they are loaded), and the k-th largest of the UNION of those lists is returned. Dropping elements of a
+// multiset can only lower its k-th largest, so the result is ALWAYS a valid lower bound of the true one - which is all a first
+// threshold has to be - and it IS the true one unless a single lane holds more than T of the k largest
+// (T = 8, k = 16, 64 lanes: ~1e-9 per query). For the fused sample + emit launch of the coarse kernel, where 128
+// accumulators per lane are live around the call: with the 16-register network the kernel spilled, and the allocator's choice
+// was reloaded from scratch in every hit path of the whole walk (kernels_coarse.h: boot_resolve).
+template <bool COHERENT, int T>
+__device__ inline float kth_largest_wave_top(const float* d, uint32_t M, uint32_t k, int lane) {
+    uint32_t r[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) r[i] = 0u;   // empty: below every key (-inf is 0x007fffff)
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4u; ++j) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; ++c) {
+            const uint32_t e = 256u * j + 4u * (uint32_t)lane + c;
+            float v = -INFINITY;
+            if (e < M) v = COHERENT ? __hip_atomic_load(d + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d[e];
+            uint32_t key = f2ord(v + 0.0f);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {   // sorted insertion: r[] stays descending
+                const uint32_t hi = r[i] > key ? r[i] : key, lo = r[i] > key ? key : r[i];
+                r[i] = hi;
+                key = lo;
+            }
+        }
+    }
+    const uint32_t none = f2ord(-INFINITY);
+    uint32_t cnt = 0, last = 0;
+    while (cnt < k) {
+        const uint32_t w = wave_max_u32(r[0]);
+        if (w <= none) break;  // fewer than k values (kept)
+        const bool own = (r[0] == w);
+        cnt += (uint32_t)__popcll(__ballot(own));
+        last = w;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < T - 1; ++i) r[i] = r[i + 1];
+            r[T - 1] = 0u;
+        }
+    }
+    return (cnt >= k) ? ord2f(last) : -INFINITY;
+}
+
 // 64-bit max as two 32-bit phases (high word, then low word among the lanes that hold it).
 __device__ inline uint64_t wave_max_u64(uint64_t k) {
     const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;

@@ -476,7 +476,7 @@ __device__ inline BootSync boot_sync_of(const CoarseArgs& a, uint32_t qt) {
 __device__ inline void boot_thresholds(const float* dump, float* tau_out, uint32_t sample_ld, uint32_t kprime,
                                                           uint32_t q0, uint32_t qstep, uint32_t qend, uint32_t nq, int lane) {
     for (uint32_t q = q0; q < qend && q < nq; q += qstep) {
-        const float t = kth_largest_wave<true>(dump + (uint64_t)q * sample_ld, sample_ld, kprime, lane);
+        const float t = kth_largest_wave_top<true, 8>(dump + (uint64_t)q * sample_ld, sample_ld, kprime, lane);
         if (lane == 0) __hip_atomic_store(tau_out + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -860,16 +860,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // COARSE_EMIT_BOOT, the two peeled tile boundaries (BootSync above). stash_tile: the ended tile's accumulators -> global
     // memory, block by block (32 coalesced 16-byte stores per lane; plain stores: only this workgroup reads them back).
     __shared__ uint32_t boot_ok_s;
-    uint32_t boot_tile[2] = {0u, 0u};
-    auto stash_of = [&](int which) {
-        return a.boot_stash + (((uint64_t)g * 2u + (uint32_t)which) * 8u + (uint32_t)wave) * 2048u + (uint32_t)lane;
-    };
-    // boundary tile 0 -> 1: publish the tile's group maxima, stash it, ARRIVE (no wait)
+    // boundary tile 0 -> 1, first half: publish the tile's group maxima (the accumulators stay in their registers), ARRIVE
     auto boot_publish = [&](uint32_t tile0, const float* inv0) __attribute__((always_inline)) {
         if constexpr (MODE == 3) {
             const BootSync bs = boot_sync_of(a, qt);
-            boot_tile[0] = tile0;
-            float4* stash = stash_of(0);
             const uint32_t lg = (uint32_t)(wm * 2 + (lane >> 5));  // the lane's row group within the tile: 0..3
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -884,11 +878,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                         if (tile0 * (uint32_t)BM + rl < a.n) mm = fmaxf(mm, sc);
                     }
                     m[mb] = (mm == -INFINITY) ? -INFINITY : mm * invq[nb];
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
-                        stash[((mb * NB + nb) * 4 + r4) * 64] = make_float4(acc[mb][nb][4 * r4], acc[mb][nb][4 * r4 + 1],
-                                                                             acc[mb][nb][4 * r4 + 2], acc[mb][nb][4 * r4 + 3]);
-                    asm volatile("" ::: "memory");   // block by block, in this order
+                    asm volatile("" ::: "memory");   // block by block (no 128 inverse-norm reads in flight at once)
                 }
                 const uint32_t q = qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
                 if (q < a.nq) {
@@ -912,48 +902,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             if (tid == 0) boot_arrive(bs.arrive_a);
         }
     };
-    // one stashed tile against the thresholds: block by block out of the L2, the ordinary slow path for blocks with a hit
-    auto filter_stashed = [&](int which, uint32_t tile, uint32_t seq) __attribute__((always_inline)) {
-        const float4* stash = stash_of(which);
-        const float* inv = invn_s + (seq & (NINV - 1)) * 256;
-        const float* st = stat_s + (seq & (NINV - 1)) * 16 + wm * MB;
-#pragma unroll 1
-        for (int blk = 0; blk < MB * NB; ++blk) {
-            const int mb = blk >> 1, nb = blk & 1;
-            f32x16_t v;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 x = stash[(blk * 4 + r4) * 64];
-                v[4 * r4] = x.x;
-                v[4 * r4 + 1] = x.y;
-                v[4 * r4 + 2] = x.z;
-                v[4 * r4 + 3] = x.w;
-            }
-            const bool one = nb ? tone[1] : tone[0], neg = nb ? tneg[1] : tneg[0];
-            const float tan = nb ? ta[1] : ta[0];
-            const float thr_b = tan * (one ? 1.0f : (neg ? st[8 + mb] : st[mb]));
-            float bm = v[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, v[r]);
-            if (__ballot(bm > thr_b) != 0ull)
-                block_hits<BM, BN>(a, v, thr_b, nb ? tauv[1] : tauv[0], nb ? invq[1] : invq[0], (uint32_t)(wm * WTM + mb * 32),
-                                   (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane, g, qt, cntq, inv);
-        }
-    };
-    // boundary tile 1 -> 2: stash tile 1, rendezvous A (a formality by now), thresholds, rendezvous B, filter both stashed tiles
-    auto boot_resolve = [&](uint32_t tile1) __attribute__((always_inline)) {
+    // boundary tile 0 -> 1, second half: rendezvous A, thresholds, rendezvous B, every lane's thresholds
+    auto boot_resolve = [&]() __attribute__((always_inline)) {
         if constexpr (MODE == 3) {
             const BootSync bs = boot_sync_of(a, qt);
-            boot_tile[1] = tile1;
-            float4* stash = stash_of(1);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
-                        stash[((mb * NB + nb) * 4 + r4) * 64] = make_float4(acc[mb][nb][4 * r4], acc[mb][nb][4 * r4 + 1],
-                                                                             acc[mb][nb][4 * r4 + 2], acc[mb][nb][4 * r4 + 3]);
             // ONE lane waits; the verdict reaches the other waves through LDS (every wave must act on the SAME verdict)
             if (tid == 0) boot_ok_s = boot_wait(bs.arrive_a, bs.degraded, a.nsplit) ? 1u : 0u;
             __builtin_amdgcn_s_barrier();
@@ -991,8 +943,6 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 tneg[nb] = tq[nb] < 0.0f;
                 ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
             }
-            filter_stashed(0, boot_tile[0], 0u);
-            filter_stashed(1, boot_tile[1], 1u);
         }
     };
 
@@ -1105,14 +1055,13 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             const uint32_t nt = next_tile(ct);
             side_wait();
             if (EMIT && EPI != 0 && KC < 3) CGV_THR_ALL(tl - 1);  // short tiles: the side data is only certain to be there now
-            if constexpr (BOOT == 1) boot_publish(a.T1 + ct, invn_s);   // tile 0 ends: maxima out, stash, arrive - no wait
-            if constexpr (BOOT == 2) boot_resolve(a.T1 + ct);           // tile 1 ends: thresholds exist; both tiles filtered
-            if constexpr (BOOT != 0) {   // the ended tile was stashed: no filters in front of the zero-C MFMAs
-                issue_side(nt, tl);
-                ct = nt;
+            if constexpr (BOOT == 1) {   // tile 0 ends: maxima out, rendezvous, thresholds; its accumulators never leave
+                boot_publish(a.T1 + ct, invn_s);
+                boot_resolve();
+                CGV_THR_ALL(0);
                 CGV_LOAD_FRAGS(fa0, fb0, sb, 0);   // the starting tile's first fragments (not read early, see above)
-                CGV_A_PHASE_Z(sb);
-            } else if (EMIT && EPI != 0) {
+            }
+            if (EMIT && EPI != 0) {
                 ftile = a.T1 + ct;
                 finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
                 issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)
@@ -1138,14 +1087,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             }
         }
     };
-    // COARSE_EMIT_BOOT: every workgroup walks >= 3 tiles (the launcher refuses anything else: cnt >= 3 * nsplit), so the two
-    // peeled boundaries are unconditional - no branch around MFMAs, no accumulator phis
-    if constexpr (MODE == 3) {
-        tile_iter(1u, IntC<1>{});
-        tile_iter(2u, IntC<2>{});
-    }
+    // COARSE_EMIT_BOOT: every workgroup walks >= 2 tiles (the launcher refuses anything else), so the peeled boundary is
+    // unconditional - no branch around MFMAs, no accumulator phis
+    if constexpr (MODE == 3) tile_iter(1u, IntC<1>{});
 #pragma unroll 1
-    for (uint32_t tl = (MODE == 3 ? 3u : 1u); tl < ntl; ++tl) tile_iter(tl, IntC<0>{});
+    for (uint32_t tl = (MODE == 3 ? 2u : 1u); tl < ntl; ++tl) tile_iter(tl, IntC<0>{});
 #undef CGV_TILE_REST_U4
 #undef CGV_ITER_AT
     // tail: second k-step of the last stage, then the last tile's epilogue
