@@ -166,7 +166,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, stash;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -183,7 +183,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &stash};
+                                &qshadow, &qres, &trace};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -191,7 +191,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &stash};
+                          &qshadow, &qres, &trace};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -698,8 +698,7 @@ struct Tunables {
     double launch_us = CGV_ENV_DBL("CGV_PLAN_LAUNCH_US", 40.0);
     int zero_copy = CGV_ENV_INT("CGV_ZERO_COPY", 3);          // pinned host buffers in place: 1 queries, 2 results
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
-    int sub_batch = CGV_ENV_INT("CGV_SUB_BATCH", -1);         // cgv_search_f32 as two half batches on two contexts: -1 auto, 0 off, 1 on
-    int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", -1);     // sample + tau + first emitting launch as ONE launch: -1 auto, 0 off, 1 on
+    int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
 };
 Tunables& tun() {
     static Tunables t;
@@ -904,26 +903,30 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         const uint32_t* pace_words = (Wmax <= PACE_WORDS && tun().pace) ? c->flags + F_COUNT : nullptr;
         a.pace = const_cast<uint32_t*>(pace_words);
 
-        // Fused form (round 4): the first emitting launch takes its own first threshold from the first tile of every
-        // workgroup (COARSE_EMIT_BOOT, kernels_coarse.h) - no sample launch, no tau_kernel, the sample tiles scored once. It
-        // holds workgroups at a rendezvous, so it is taken only when this search found the device idle (dev_inflight).
+        // Fused form (round 4, MEASUREMENT FLAVOUR ONLY): the first emitting launch takes its own first threshold from the first
+        // tile of every workgroup (COARSE_EMIT_BOOT, kernels_coarse.h) - no sample launch, no tau_kernel, the sample tiles scored
+        // once. Measured break-even at best against the three launches it replaces (profiles/r04_fused_launch_ab.txt:
+        // a rendezvous right behind the first tile exposes the launch's ramp skew, and 128 accumulators per lane held across it
+        // either spill or, stashed, cost more L2 / HBM traffic than scoring the tile again), so the production library does not
+        // carry it; knob `fuse_sample` of scripts/ab.py.
         const uint32_t nsplit0 = p.counts.empty() ? 0u : std::min<uint32_t>(p.counts[0], nsplit_max);
         const uint32_t fvals = sample_vals_of(std::max<uint32_t>(nsplit0, 1u));
         const bool can_fuse = p.sample_tiles > 0 && nsplit0 > 0 && (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) && a.kc >= 4 &&
                               a.kc % 4 == 0 && nqt > 1 && nqt * 4u <= BOOT_WORDS && nsplit0 * fvals >= 4u * kprime &&
-                              nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 3 * nsplit0;  // (every workgroup walks >= 3 tiles)
-        const int fs = tun().fuse_sample;
-        const bool fuse = can_fuse && (fs > 0 || (fs < 0 && dev_inflight(h) == 1));
+                              nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 2 * nsplit0;  // (every workgroup walks >= 2 tiles)
+#ifdef CGV_ABLATE_BUILD
+        const bool fuse = can_fuse && tun().fuse_sample > 0;
+#else
+        const bool fuse = false;
+        (void)can_fuse;
+#endif
         c->boot_used = fuse;
         a.tau_out = c->tau.as<float>();
         a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
         a.kprime = kprime;
-        a.boot_stash = nullptr;
         if (fuse) {
             if ((rc = c->dump.ensure((size_t)nq * nsplit0 * fvals * 4))) return rc;
-            // the first two tiles' accumulators of every workgroup wait for the thresholds here: 512 KiB per workgroup
-            if ((rc = c->stash.ensure((size_t)nqt * nsplit0 * 2 * 8 * 2048 * 16))) return rc;
-            a.boot_stash = c->stash.as<float4>();
+
         } else if (p.sample_tiles > 0) {
             // first threshold: block maxima of the first sample_tiles tiles of the visiting order -> k'-th largest
             const uint32_t vals = sample_vals_of(p.sample_tiles);
@@ -1304,7 +1307,6 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "zero_copy")) t.zero_copy = (int)v;
     else if (!strcmp(key, "pace")) t.pace = (int)v;
     else if (!strcmp(key, "epi")) t.epi = (int)v;
-    else if (!strcmp(key, "sub_batch")) t.sub_batch = (int)v;
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else return -1;
     return 0;
@@ -2304,7 +2306,6 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.epi = 1;
     a.tau_out = nullptr;
     a.boot_sync = nullptr;
-    a.boot_stash = nullptr;
     a.kprime = 0;
     if ((rc = launch_coarse(cdt, COARSE_DUMP, a, nqt * nsplit, s))) return rc;
     HIPCHK(hipStreamSynchronize(s));

@@ -35,7 +35,9 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>))) return rc;
+#ifdef CGV_ABLATE_BUILD   // the fused sample + emit launch: a measured negative result, kept for A/B in the measurement flavour only
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>))) return rc;
+#endif
     return CGV_OK;
 }
 
@@ -52,10 +54,14 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         return coarse_hip_status("coarse_kernel (sample)");
     }
     if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (cgvec.hip: can_fuse)
-        if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.boot_stash && a.tau_out && a.dump && a.cnt >= 3 * a.nsplit))
+#ifdef CGV_ABLATE_BUILD
+        if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.tau_out && a.dump && a.cnt >= 2 * a.nsplit))
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT launched on a shape it does not serve");
         hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (emit + boot)");
+#else
+        return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT exists in the measurement flavour only (make ABLATE=1)");
+#endif
     }
     if constexpr (ABLATE) {
         // results are wrong when set: only the launch time means anything

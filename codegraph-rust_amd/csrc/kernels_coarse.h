@@ -106,7 +106,6 @@ struct CoarseArgs {
     // COARSE_EMIT_BOOT (the fused sample + first emitting launch, BootSync below)
     float* tau_out;         // [nq] the first thresholds, written by the launch itself
     uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
-    float4* boot_stash;     // [W][2][8 waves][2048] the first two tiles' accumulators of every workgroup (512 KiB each)
     uint32_t kprime;        // the threshold is the k'-th largest group maximum
 };
 
@@ -434,29 +433,29 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
     }
 }
 
-// ---- COARSE_EMIT_BOOT: sample + first threshold + first emitting pass in ONE launch (round 4) ----------
-// Round 3 spent three launches on the first threshold: a sample launch (one tile per workgroup, block maxima only), tau_kernel,
-// then the first emitting launch, which scored the sample tiles AGAIN - 32 + 7 us + two launch boundaries + a second ramp per
-// batch, and 13 % of a 125 k-row shard scored twice. Here the first tile of every workgroup's walk IS its sample, and nothing
-// waits for anything it can avoid:
-//   boundary tile 0 -> 1   the tile's group maxima are published (one 16-value record per lane and N-block, what the sample
-//                          launch wrote), its 128 accumulators per lane go to a STASH in global memory, the workgroup ARRIVES at
-//                          rendezvous A of its QUERY TILE (the nsplit <= 64 workgroups whose maxima its queries need - not the
-//                          grid) and walks on: tile 1 is scored while the others publish;
-//   boundary tile 1 -> 2   tile 1's accumulators are stashed too (nothing is live in registers now), rendezvous A is complete
-//                          (everybody arrived a tile-time ago: the wait is a formality), the workgroup computes the thresholds
-//                          of its share of the tile's 256 queries (kth_largest_wave over nsplit x 16 maxima, one wave per
-//                          query), publishes them, meets the others at rendezvous B, reads all thresholds of its lanes' queries
-//                          and filters the two STASHED tiles with them (block by block out of the L2: 16 scores per lane, the
-//                          ordinary block_hits slow path for the few that pass); from tile 2 on it is an ordinary emitting walk.
-// First form of this (kept in profiles/r04b_fused_ab.txt): rendezvous + thresholds right at the first boundary with the first
-// tile's accumulators held back - in registers it spilled (and the allocator's spill choices reached the cold hit paths of the
-// whole kernel), stashed it cost the wait: 53 us per launch against the ~50 us of the three launches it replaced.
+// ---- COARSE_EMIT_BOOT: sample + first threshold + first emitting pass in ONE launch (round 4) --------------------------
+// MEASUREMENT FLAVOUR ONLY (make ABLATE=1; knob `fuse_sample` of scripts/ab.py): a measured negative result, kept so that
+// the A/B in profiles/r04_fused_launch_ab.txt can be repeated. DESIGN.md §9.1 has the numbers.
+// Round 3 spends three launches on the first threshold: a sample launch (one tile per workgroup, block maxima only), tau_kernel,
+// then the first emitting launch, which scores the sample tiles AGAIN - 32 + 7 us + two launch boundaries + a second ramp per
+// batch. Here the first tile of every workgroup's walk IS its sample: at the tile's end the workgroup publishes the tile's group
+// maxima (what the sample launch wrote), meets the other workgroups of its QUERY TILE (the nsplit <= 64 workgroups whose maxima
+// its queries need - not the grid) at rendezvous A, computes the thresholds of its share of the tile's 256 queries (one wave per
+// query, kth_largest_wave_top over the nsplit x 16 maxima), meets them again at rendezvous B so that all 256 thresholds are
+// visible, and filters the tile's accumulators - which never left their registers - with them; from then on it is an ordinary
+// emitting walk. Four forms were built and measured (one MI355X, in-process A/B against the three launches, C2 step / 125 k-row
+// shard step): fences around every hand-off +89 / +86 us (16 buffer_wbl2 + 16 buffer_inv per workgroup); fence-free with the
+// accumulators stashed in global memory across the wait +19 / +18; arrive at boundary 0, resolve at boundary 1, both tiles
+// filtered out of the stash +20 / +22 (64 MB written and read back per stashed tile: more than scoring it again); this form,
+// accumulators in registers, a register-light selection, no early fragment reads at the peeled boundary: +1 / -1 us.
+// Break-even, because (i) a rendezvous right behind the first tile waits out the launch's own ramp skew (the workgroups of a
+// launch start over ~10 us), (ii) two rendezvous round trips + the selection are ~15 us, and (iii) the kernel sits at the
+// register limit: with 128 accumulators live across the block the allocator spills a few kernel-long values whose reloads sit
+// in the hit paths of the whole walk.
 // Hand-offs use NO fences: what other workgroups read (maxima, thresholds) is written with agent-scope write-through (sc1)
 // stores, drained with s_waitcnt vmcnt(0) before the arrival, and read with agent-scope loads (MI355X_MICROARCH.md: "sc1
-// payload -> vmcnt(0) -> sc1 flag"; with a release + acquire fence pair per wave and hand-off the block cost 120 us).
-// Rendezvous = one monotonic arrival counter per query tile and phase; ONE lane polls with relaxed loads + s_sleep, the other
-// waves wait at s_barrier.
+// payload -> vmcnt(0) -> sc1 flag"). Rendezvous = one monotonic arrival counter per query tile and phase; ONE lane polls with
+// relaxed loads + s_sleep, the other waves wait at s_barrier.
 // It needs the group co-resident, which a plain launch cannot promise (another process' kernel, a second batch in flight on
 // the device): every wait is BOUNDED (BOOT_TIMEOUT_TICKS of the 100 MHz wall clock). A workgroup that times out raises the
 // group's `degraded` word - every later wait of the group ends on it - marks its 256 queries `overflow` (the final kernel
@@ -470,9 +469,7 @@ struct BootSync {
 __device__ inline BootSync boot_sync_of(const CoarseArgs& a, uint32_t qt) {
     return BootSync{a.boot_sync + 4u * qt, a.boot_sync + 4u * qt + 1u, a.boot_sync + 4u * qt + 2u};
 }
-// The threshold computation of one workgroup's share of its query tile (boot_block runs it with the accumulators STASHED in
-// global memory: with 128 accumulators live across it the kernel went over 256 VGPRs and the allocator spilled values that the
-// cold hit paths of the WHOLE kernel then reloaded from scratch - behind a vmcnt(0), i.e. behind the DMA in flight).
+// The threshold computation of one workgroup's share of its query tile.
 __device__ inline void boot_thresholds(const float* dump, float* tau_out, uint32_t sample_ld, uint32_t kprime,
                                                           uint32_t q0, uint32_t qstep, uint32_t qend, uint32_t nq, int lane) {
     for (uint32_t q = q0; q < qend && q < nq; q += qstep) {
