@@ -130,6 +130,19 @@ class ShardedKnn:
             return out
         return oi, os_
 
+    @staticmethod
+    def _wait(device, spin_s=0.005):
+        """The batch's ONE host synchronisation: poll the stream for a few milliseconds before blocking - a batch takes 0.3-1.5
+        ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it (the library waits for its own
+        streams the same way, cgvec.hip: wait_stream)."""
+        import time
+        st = torch.cuda.current_stream(device)
+        t0 = time.perf_counter()
+        while not st.query():
+            if time.perf_counter() - t0 > spin_s:
+                st.synchronize()
+                return
+
     def step_packed(self, queries, k, out=None, device=None):
         """One batch, one host synchronisation: local.search_packed_begin (shard search + packed records, the consumer stream
         waits for them) -> all-gather -> merge with the redo flag -> sync -> local.search_packed_end. When any rank's records
@@ -149,7 +162,7 @@ class ShardedKnn:
         if timed:
             self._ev[1].record()
         if rec.is_cuda:
-            torch.cuda.current_stream(rec.device).synchronize()
+            self._wait(rec.device)
         if timed:
             self.last_exchange_ms = self._ev[0].elapsed_time(self._ev[1])
         self.local.search_packed_end(ticket)
@@ -158,7 +171,7 @@ class ShardedKnn:
             redo.zero_()
             res = self._gather_merge(rec, gathered, k, out, redo)
             if rec.is_cuda:
-                torch.cuda.current_stream(rec.device).synchronize()
+                self._wait(rec.device)
             if int(redo[0]) != 0:
                 raise RuntimeError("records still provisional after search_packed_end")
         return res
