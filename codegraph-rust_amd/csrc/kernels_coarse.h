@@ -10,7 +10,7 @@
 // bit-for-bit on those candidates, the same two-stage shape as
 // SemanticSearch::search_by_embedding (search.rs:113-137).
 //
-// Structure (gfx950) — see DESIGN.md §5.1 / §9 for the measurements behind each choice:
+// Structure (gfx950) — see DESIGN.md §5.1 / §10 for the measurements behind each choice:
 //   * workgroup = 256 x 256 output tile, 8 waves as 2(M) x 4(N), each wave 128 x 64 =
 //     4 x 2 blocks of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs);
 //   * both operands live in HBM in the BLOCKED layout B32 (common.h): a (tile, 64-byte K chunk)
@@ -501,7 +501,7 @@ __device__ inline bool boot_wait(uint32_t* counter, uint32_t* degraded, uint32_t
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
-// 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §9 quotes the numbers.
+// 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §10.2 quotes the numbers.
 // 256 / 512 / 768 = the stage's counted wait is vmcnt(4) / (6) / (2) instead of (8): results stay correct, the DMA lead shrinks
 // by 1 / 0.5 / 1.5 stages (how much of the 3-stage lead does the kernel need? r03i: two stages are enough).
 // EPI, the emitting epilogue: 1 (default) = the conservative thresholds are formed in the MFMA gaps of a tile's last
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // The 6 fragment reads go right behind the first MFMA (hipcc waits lgkmcnt(0), so they get 7 MFMAs to land;
     // the partner wave of the SIMD covers their issue), a DMA piece behind MFMAs 4 and 6. (One read per gap
     // measured the same: 1.003 vs 1.004 ms on the C2 main launch; giving the two waves of a SIMD different DMA
-    // gaps - waves 0-3 early, 4-7 late in the k-step - measured 4-8 % SLOWER: DESIGN.md §9.)
+    // gaps - waves 0-3 early, 4-7 late in the k-step - measured 4-8 % SLOWER: DESIGN.md §10.2.)
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                   \
     {                                                                                                            \
         /* serpentine block order: consecutive MFMAs share one operand block (0.5 % on the C2 main launch) */    \

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Hunt for the intermittent suite abort (DESIGN.md §9.4): the in-process stress under several allocator / logging modes,
+# Hunt for the intermittent suite abort (DESIGN.md §9.5): the in-process stress under several allocator / logging modes,
 # then the two test files in suite order a few times. Everything un-captured; abort_bt names the native stack.
 export TMPDIR=/tmp LIBC_FATAL_STDERR_=1
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/abort; cd $R
