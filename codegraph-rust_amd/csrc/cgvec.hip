@@ -1272,7 +1272,7 @@ int order_after_caller(cgv_index* h, SearchCtx* c) {
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 4u; }
+uint32_t cgv_version(void) { return (0u << 16) | 5u; }  // 0.5: + packed (join-free) search, merge with redo flag, host alias, COSINE_SCALAR
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }

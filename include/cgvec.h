@@ -80,7 +80,8 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_ERR_OUT_OF_RANGE 6 /* VectorError::IndexOutOfBounds, error.rs:14-15 */
 #define CGV_ERR_INTERNAL 7
 #define CGV_ERR_IO 8           /* corpus file errors; messages follow memory.rs:242-374 */
-#define CGV_ERR_BUSY 9         /* the calling thread already holds every search context (begin without end) */
+#define CGV_ERR_BUSY 9         /* the calling thread already holds every search context (begin without end); a cgv_sharded handle
+                                  is written / read while a batch begun on it is in flight */
 
 /* Largest k of a search. k <= CGV_FAST_MAX_K runs the MFMA coarse pass + exact re-score; larger k (the
  * over-fetch of SemanticSearch: prefetch_k(max(4*limit, limit+25)), search.rs:113,293) takes the exact
@@ -89,7 +90,9 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_FAST_MAX_K 228u
 
 /* Library/ABI version (major<<16 | minor). Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
- * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. */
+ * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. Minor 5 (round 4): cgv_search_packed_begin_f32_dev
+ * / cgv_search_packed_end / cgv_merge_packed_flag_dev (the join-free exchange), cgv_host_device_alias, CGV_METRIC_COSINE_SCALAR /
+ * CGV_OP_COSINE_SCALAR, CGV_ERR_BUSY from cgv_sharded_* writers / readers while a batch is in flight. */
 uint32_t cgv_version(void);
 
 /* Thread-local message for the last failing call on this thread ("" if none). */

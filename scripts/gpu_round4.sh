@@ -3,7 +3,7 @@
 # the round's changes: fused sample + emit launch on/off (in-process A/B, measurement flavour), the join-free exchange
 # (one-rank dry run), C2 / shard lines, the half-batch proxy for intra-call sub-batching.
 export TMPDIR=/tmp LIBC_FATAL_STDERR_=1
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4b; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
 timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 900 --durations=12 > $O/pytest_gpu.txt 2>&1
 echo "pytest rc=$?"; tail -25 $O/pytest_gpu.txt | cut -c1-240
 grep -c "abort_bt: native" $O/pytest_gpu.txt
