@@ -490,3 +490,76 @@ def test_join_free_packed_step_one_rank(oracle, dtype, odt):
         assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
     finally:
         ix.close()
+
+
+def _two_on_one_main(rank, world, port, n, d, nq, k, out):
+    """Two REAL ranks on ONE GPU (RCCL refuses two ranks on one device, so the records travel over gloo): each rank owns a
+    real HipKnnIndex shard, packs its records on the device (cgv_search_packed_begin_f32_dev), the all-gather runs on CPU
+    copies of the records, the merge (+ redo word) runs on the device again. Rank 1's shard holds a near-duplicate cluster of
+    one query's row: only rank 1 packs that query PROVISIONAL, both ranks must repeat the exchange."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = pkg()
+    rng = np.random.default_rng(61)
+    rows = _unit(rng, n, d)
+    lo1 = m.shard_range(n, 1, world)[0]
+    rows[lo1 + 100:lo1 + 160] = rows[lo1 + 7] * (1 + 1e-4 * rng.standard_normal((60, 1)).astype(np.float32))
+    q = _unit(rng, nq, d)
+    q[2] = rows[lo1 + 7]
+    lo, hi = m.shard_range(n, rank, world)
+    ix = m.HipKnnIndex(d, dtype="bf16", device=0)
+    ix.add(rows[lo:hi])
+    ix.set_index_base(lo)
+    w = m.cgvec.packed_width(k)
+    rec = torch.empty((nq, w), dtype=torch.int32, device="cuda")
+    redo = torch.zeros(1, dtype=torch.int32).pin_memory()
+    oi = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+    osc = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+    qp = torch.from_numpy(q).pin_memory()
+
+    def exchange():
+        torch.cuda.current_stream().synchronize()
+        mine = rec.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        redo.zero_()
+        m.merge_packed(torch.stack(parts).cuda(), k, out=(oi, osc), redo=redo)
+        torch.cuda.current_stream().synchronize()
+        return int(redo[0])
+
+    t = ix.search_packed_begin(qp, k, rec)
+    first = exchange()
+    repacked = ix.search_packed_end(t)
+    assert first == 1 and repacked == (rank == 1), (rank, first, repacked)   # the flag reaches BOTH ranks; only rank 1 re-packs
+    assert exchange() == 0
+    np.save(f"{out}.{rank}.idx.npy", oi.numpy().view(np.uint64))
+    np.save(f"{out}.{rank}.sc.npy", osc.numpy())
+    ix.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_device_records_and_redo(tmp_path, oracle):
+    """The 2-rank semantics of the packed exchange with REAL device shards, pack and merge kernels on the 1-GPU box: see
+    _two_on_one_main. Every rank ends with the single-index answer of the oracle."""
+    import torch.multiprocessing as mp
+    n, d, nq, k = 24_000, 128, 70, 10
+    out = str(tmp_path / "t")
+    mp.spawn(_two_on_one_main, args=(2, _free_port(), n, d, nq, k, out), nprocs=2, join=True)
+    m = pkg()
+    rng = np.random.default_rng(61)
+    rows = _unit(rng, n, d)
+    lo1 = m.shard_range(n, 1, 2)[0]
+    rows[lo1 + 100:lo1 + 160] = rows[lo1 + 7] * (1 + 1e-4 * rng.standard_normal((60, 1)).astype(np.float32))
+    q = _unit(rng, nq, d)
+    q[2] = rows[lo1 + 7]
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
+    for r in range(2):
+        assert np.array_equal(np.load(f"{out}.{r}.idx.npy"), ri), r
+        assert np.array_equal(np.load(f"{out}.{r}.sc.npy"), rs), r
