@@ -159,6 +159,11 @@ struct SearchCtx {
     hipEvent_t dep = nullptr;      // ordering after the caller's stream (ingest, query producer)
     hipEvent_t done = nullptr;     // cgv_search_packed_begin_f32_dev: the consumer stream waits for the packed records on it
     uint32_t* rec_out = nullptr;   // ... the caller's record buffer of the batch in flight (NULL: not a packed search)
+    // cgv_search_packed_begin_f32_dev runs the WHOLE batch on the consumer's stream (no hop onto `stream` and back: two
+    // cross-stream event waits, ~7 us each on this part, per batch of the N > 1 step): `run` is that stream while `on_caller`
+    bool on_caller = false;
+    hipStream_t run = nullptr;
+    hipStream_t cur() const { return on_caller ? run : stream; }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
@@ -801,7 +806,7 @@ void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float
 // Caller holds h->mu and owns the context.
 int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, uint32_t k, uint64_t* out_idx,
                    float* out_score) {
-    hipStream_t s = c->stream;
+    hipStream_t s = c->cur();
     int rc;
     h->st.searches++;
     h->st.queries += nq;
@@ -1144,7 +1149,7 @@ int wait_stream(hipStream_t s) {
 }
 
 int search_finish(cgv_index* h, SearchCtx* c) {
-    hipStream_t s = c->stream;
+    hipStream_t s = c->cur();
     const uint32_t nq = c->nq, k = c->k;
     int rc;
     if ((rc = wait_stream(s))) return rc;
@@ -1777,25 +1782,29 @@ int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint
     if (!c)
         return fail(CGV_ERR_BUSY, "this thread already holds all " + std::to_string(N_CTX) +
                                       " search contexts of the handle: call cgv_search_packed_end on one of its tickets first");
+    c->on_caller = true;   // the batch runs on the consumer's stream, in line with the collective and the merge behind it
+    c->run = (hipStream_t)consumer_stream;
     auto body = [&]() -> int {
         int r;
         if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
         if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
-        if ((r = order_after_caller(h, c))) return r;
+        if (h->stream != c->run) {   // what the caller queued on the handle's stream (ingest, a query producer) comes first
+            HIPCHK(hipEventRecord(c->dep, h->stream));
+            HIPCHK(hipStreamWaitEvent(c->run, c->dep, 0));
+        }
         if ((r = search_enqueue(h, c, queries_dev, nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>()))) return r;
         // exact-scan-only batches (f32 index, forced exact, k beyond the fast path) are produced by search_finish: every
         // record is provisional. An empty index pads its results at enqueue time: final.
         const bool all_prov = !c->mfma;
         launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), nq, k, rec_out_dev,
-                    c->mfma && h->n ? c->fbflag.as<uint32_t>() : nullptr, all_prov ? 1u : 0u, c->stream);
+                    c->mfma && h->n ? c->fbflag.as<uint32_t>() : nullptr, all_prov ? 1u : 0u, c->run);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->done, c->stream));
-        HIPCHK(hipStreamWaitEvent((hipStream_t)consumer_stream, c->done, 0));
         return CGV_OK;
     };
     rc = body();
     if (rc) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->run);
+        c->on_caller = false;
         c->busy = false;
         dev_inflight_add(h, -1);
         lk.unlock();
@@ -1821,14 +1830,15 @@ int cgv_search_packed_end(cgv_index* h, uint64_t ticket, int* repacked) {
     HIPCHK(hipSetDevice(h->device));
     int rc = search_finish(h, c);
     if (rc == CGV_OK && c->rewrote) {  // the exact scan replaced (some of) the results: final records now
-        launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), c->nq, c->k, c->rec_out, nullptr, 0u, c->stream);
+        launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), c->nq, c->k, c->rec_out, nullptr, 0u, c->cur());
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->cur());
         if (e != hipSuccess) rc = fail(CGV_ERR_HIP, std::string("re-pack: ") + hipGetErrorString(e));
         if (repacked) *repacked = 1;
     }
-    if (rc) (void)hipStreamSynchronize(c->stream);
+    if (rc) (void)hipStreamSynchronize(c->cur());
     c->rec_out = nullptr;
+    c->on_caller = false;
     release_ctx(h, c);
     return rc;
 }

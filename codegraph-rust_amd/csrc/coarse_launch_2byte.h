@@ -8,6 +8,9 @@
 
 #include "../../include/cgvec.h"
 #include "coarse_launch.h"
+#ifdef CGV_ABLATE_BUILD
+#include "kernels_coarse_w4.h"   // one wave per SIMD, 128 x 128 per wave (A/B against the 8-wave kernel; epi bit 7)
+#endif
 
 extern "C" int cgv_set_error_(int code, const char* msg);
 
@@ -98,6 +101,20 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
             return coarse_hip_status("coarse_kernel (ablation)");
         }
     }
+#ifdef CGV_ABLATE_BUILD
+    if ((a.epi & 128u) != 0 && a.kc >= 4) {  // A/B: one wave per SIMD with the folded epilogue (bit 8 = its boundary-block form)
+        if ((a.epi & 256u) != 0) {
+            auto kw = coarse_w4_kernel<DT, false>;
+            if (int rc = coarse_set_lds((const void*)kw)) return rc;
+            hipLaunchKernelGGL(kw, dim3(W), dim3(256), lds, s, a);
+        } else {
+            auto kw = coarse_w4_kernel<DT, true>;
+            if (int rc = coarse_set_lds((const void*)kw)) return rc;
+            hipLaunchKernelGGL(kw, dim3(W), dim3(256), lds, s, a);
+        }
+        return coarse_hip_status("coarse_w4_kernel");
+    }
+#endif
     if constexpr (ABLATE) {  // A/B reference: the round-2 epilogue (bf16 build only)
         if ((a.epi & 1u) == 0) {
             auto k0 = coarse_kernel<DT, COARSE_EMIT, 0, 0>;

@@ -265,12 +265,13 @@ void* cgv_host_device_alias(int device_id, const void* host_ptr, size_t bytes);
 /* ---- one rank's share of a batch WITHOUT a host join between the shard search and the exchange -------------------------
  * (row-sharded deployment, one process per GPU; the reference has no counterpart - its "batch" is B
  * independent futures, search.rs:358-361.)
- * cgv_search_packed_begin_f32_dev enqueues the shard search of the batch (queries_dev: device memory or the device alias of
- * pinned host memory, cgv_host_device_alias) and, on the same internal stream right behind its last kernel, the packing of
- * the top-k into rec_out_dev (cgv_packed_width(k) int32 words per query, device memory owned by the caller), and makes
- * `consumer_stream` (a hipStream_t) wait for the records. The caller then enqueues on that stream the all-gather of every
- * rank's records and cgv_merge_packed_flag_dev, and synchronises ONCE - the host never sits between the search and the
- * collective. A query whose top-k the device could not prove (ties / near-duplicates at the k' boundary, a zero query, an
+ * cgv_search_packed_begin_f32_dev enqueues ON `consumer_stream` (a hipStream_t; NULL = the legacy default stream) the shard
+ * search of the batch (queries_dev: device memory or the device alias of pinned host memory, cgv_host_device_alias) and, right
+ * behind its last kernel, the packing of the top-k into rec_out_dev (cgv_packed_width(k) int32 words per query, device memory
+ * owned by the caller). The caller then enqueues on that stream the all-gather of every rank's records and
+ * cgv_merge_packed_flag_dev, and synchronises ONCE - the host never sits between the search and the collective, and the batch
+ * never leaves the stream (no cross-stream event waits). Work queued on the handle's stream (cgv_set_stream) before the call is
+ * ordered in front of it. A query whose top-k the device could not prove (ties / near-duplicates at the k' boundary, a zero query, an
  * exact-scan-only index ...) is packed PROVISIONAL: id slot 0 = CGV_PROVISIONAL_ID. The merge raises *redo_flag_dev (a
  * device word, or a pinned host word written in place; the caller zeroes it) when any rank's list of any query is
  * provisional. Every rank merges the same gathered records, so ALL ranks read the same flag - no second collective to agree:
