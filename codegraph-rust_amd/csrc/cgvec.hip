@@ -157,8 +157,7 @@ uint32_t kprime_of(uint32_t k) {
 struct SearchCtx {
     hipStream_t stream = nullptr;  // owned, non-blocking
     hipEvent_t dep = nullptr;      // ordering after the caller's stream (ingest, query producer)
-    hipEvent_t done = nullptr;     // cgv_search_packed_begin_f32_dev: the consumer stream waits for the packed records on it
-    uint32_t* rec_out = nullptr;   // ... the caller's record buffer of the batch in flight (NULL: not a packed search)
+    uint32_t* rec_out = nullptr;   // cgv_search_packed_begin_f32_dev: the caller's record buffer of the batch in flight (NULL: not a packed search)
     // cgv_search_packed_begin_f32_dev runs the WHOLE batch on the consumer's stream (no hop onto `stream` and back: two
     // cross-stream event waits, ~7 us each on this part, per batch of the N > 1 step): `run` is that stream while `on_caller`
     bool on_caller = false;
@@ -1232,6 +1231,8 @@ SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk, bool spli
     got->split = split;
     got->owner = me;
     got->gen++;
+    got->on_caller = false;  // (a packed ticket ended through cgv_search_end leaves these set)
+    got->rec_out = nullptr;
     dev_inflight_add(h, +1);
     return got;
 }
@@ -1382,7 +1383,6 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     for (SearchCtx& c : h->ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
@@ -1423,7 +1423,6 @@ int cgv_destroy(cgv_index* h) {
         if (c.flags) (void)hipFree(c.flags);
         if (c.h_flags) (void)hipHostFree(c.h_flags);
         if (c.dep) (void)hipEventDestroy(c.dep);
-        if (c.done) (void)hipEventDestroy(c.done);
         for (int i = 0; i < 4; ++i)
             if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1748,7 +1747,9 @@ int cgv_search_end(cgv_index* h, uint64_t ticket) {
     }
     HIPCHK(hipSetDevice(h->device));
     int rc = search_finish(h, c);
-    if (rc) (void)hipStreamSynchronize(c->stream);
+    if (rc) (void)hipStreamSynchronize(c->cur());
+    c->on_caller = false;  // (a packed ticket ended here: its provisional records are simply not refreshed)
+    c->rec_out = nullptr;
     release_ctx(h, c);
     return rc;
 }

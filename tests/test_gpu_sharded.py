@@ -488,6 +488,26 @@ def test_join_free_packed_step_one_rank(oracle, dtype, odt):
         assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
         first, repacked = step(qp)                             # the handle still answers
         assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+        # a packed ticket ended through the plain cgv_search_end (a caller's mistake): no crash, the context comes back clean -
+        # the next ordinary search runs on the handle's own stream again and the next packed step is right
+        t = ix.search_packed_begin(qp, k, rec)
+        m.cgvec._check(m.cgvec.lib().cgv_search_end(ix._h, m.cgvec.C.c_uint64(t)))
+        gi, gs = ix.search(q, k)
+        assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+        first, repacked = step(qp)
+        assert np.array_equal(oi.numpy().view(np.uint64), ri) and np.array_equal(osc.numpy(), rs)
+        # two packed batches in flight on the one stream (tickets share the handle's contexts): both right, any end order
+        rec2 = torch.empty_like(rec)
+        t1 = ix.search_packed_begin(qp, k, rec)
+        t2 = ix.search_packed_begin(torch.from_numpy(q[::-1].copy()).pin_memory(), k, rec2)
+        torch.cuda.current_stream().synchronize()
+        ix.search_packed_end(t2)
+        ix.search_packed_end(t1)
+        for r_, want_i, want_s in ((rec, ri, rs), (rec2, ri[::-1], rs[::-1])):
+            redo.zero_()
+            m.merge_packed(r_.view(1, nq, w), k, out=(oi, osc), redo=redo)
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(oi.numpy().view(np.uint64), want_i) and np.array_equal(osc.numpy(), want_s)
     finally:
         ix.close()
 
