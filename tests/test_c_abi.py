@@ -81,3 +81,18 @@ def test_product_never_imports_oracle():
                 if re.search(r"\boracle\b", t):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_abort_bt_names_the_native_stack(tmp_path):
+    """tests/c_client/abort_bt.c (hooked into the pytest process by conftest.py): a child that calls abort() from native
+    code leaves the C-level stack of the raising thread on stderr - with abort() itself in it - before Python's faulthandler
+    prints the Python frames. (What round 3's two suite aborts lacked: DESIGN.md §9.5.)"""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes, faulthandler; sys.path.insert(0, %r); faulthandler.enable(); "
+            "from _util import install_abort_bt; assert install_abort_bt(); ctypes.CDLL(None).abort()"
+            % os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert "abort_bt: native backtrace of the raising thread" in p.stderr and "abort" in p.stderr.split("abort_bt: end")[0]
+    assert "Fatal Python error: Aborted" in p.stderr            # chained to faulthandler

@@ -326,3 +326,24 @@ def test_scalar_host_metric_of_the_oracle(oracle):
         assert np.array_equal(idx, order.astype(np.uint64)) and np.array_equal(sc, want[order]), d
     # a zero vector scores 0.0 (norm product == 0), never NaN
     assert oracle.cosine_scalar(np.zeros(40, f32), np.ones(40, f32)) == 0.0
+
+
+def test_cpu_baseline_leg_reports_its_split(oracle):
+    """The CPU-baseline leg (bench.py cpu_baseline): RowSet.top_k on separately allocated rows gives parallel_top_k's answer
+    for every thread count (the parallel sort is a strict total order: score desc, index asc), and last_timing() reports the
+    scoring / sort split of the calling thread's last search."""
+    rng = np.random.default_rng(2)
+    rows = rng.standard_normal((20000, 96)).astype(np.float32)
+    rows[77] = rows[19000]                       # a tie: lower index first
+    q = rng.standard_normal(96).astype(np.float32)
+    want_i, want_s = oracle.parallel_top_k(q, rows, 25, threads=1)
+    rs = oracle.RowSet(rows)
+    try:
+        for t in (1, 2, 0):
+            gi, gs = rs.top_k(q, 25, oracle.COSINE, t)
+            assert np.array_equal(gi, want_i) and np.array_equal(gs, want_s), t
+        sc_ms, so_ms = oracle.last_timing()
+        assert sc_ms > 0.0 and so_ms > 0.0
+        assert oracle.numa_nodes() >= 1 and oracle.max_threads() >= 1
+    finally:
+        rs.close()
