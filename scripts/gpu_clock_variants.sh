@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/clockv; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 for e in ${EPIS:-1 65 129 385}; do
   export CGV_EPI=$e
-  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-include-regex coarse --output-format csv -d $OUT/e$e -o p -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --cpu-seconds 0 --pipelined-steps 0 > $OUT/e$e.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-include-regex coarse --output-format csv -d $OUT/e$e -o p -- python $R/bench.py --workload c2 --steps 6 --warmup 2 --cpu-seconds 0 --pipelined-steps 0 > $OUT/e$e.log 2>&1
   python - <<PY
 import csv,glob,collections
 f=glob.glob('$OUT/e$e/**/p_counter_collection.csv',recursive=True)
@@ -20,11 +20,15 @@ for r in csv.DictReader(open(t[0])):
 acc=collections.defaultdict(dict)
 for r in csv.DictReader(open(f[0])):
     acc[r['Dispatch_Id']][r['Counter_Name']]=float(r['Counter_Value'])
-best=None
-for d,c in acc.items():
-    if d in dur and (best is None or dur[d][0]>dur[best][0]): best=d
+# the main launches = the coarse dispatches with the longest durations, one per step: take the MEDIAN of the last steps (the
+# first launch of a process carries the code-object load)
+cand=sorted([d for d in acc if d in dur], key=lambda d: int(d))
+longest=max(dur[d][0] for d in cand)
+mains=[d for d in cand if dur[d][0] > 0.6*longest][-5:]
+mains.sort(key=lambda d: dur[d][0])
+best=mains[len(mains)//2]
 c=acc[best]; ns=dur[best][0]
 cyc=c['GRBM_GUI_ACTIVE']/8
-print('epi $e  %-60s  %.4f ms  cycles/XCD %.0f  clock %.3f GHz  MFMA busy %.3f'%(dur[best][1][:60], ns/1e6, cyc, cyc/ns, c['SQ_VALU_MFMA_BUSY_CYCLES']/1024/cyc))
+print('epi $e  %-44s  median of %d main launches: %.4f ms  cycles/XCD %.0f  clock %.3f GHz  MFMA busy %.3f'%(dur[best][1][:44], len(mains), ns/1e6, cyc, cyc/ns, c['SQ_VALU_MFMA_BUSY_CYCLES']/1024/cyc))
 PY
 done
