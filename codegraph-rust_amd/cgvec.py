@@ -145,6 +145,12 @@ def lib():
     L.cgv_sharded_max_batches_in_flight.restype = u32
     L.cgv_sharded_exchange.argtypes = [vp]
     L.cgv_sharded_set_exchange.argtypes = [vp, i32]
+    L.cgv_sharded_force_exchange.argtypes = [vp, i32]
+    L.cgv_sharded_force_exchange.restype = i32
+    L.cgv_set_spin_us.argtypes = [vp, u32]
+    L.cgv_set_spin_us.restype = i32
+    L.cgv_debug_rccl_lib_.argtypes = [C.c_char_p]
+    L.cgv_debug_rccl_lib_.restype = i32
     L.cgv_sharded_get_stats.argtypes = [vp, C.POINTER(ShardedStats)]
     for name in ("cgv_set_id_map", "cgv_truncate", "cgv_score_ids_f32", "cgv_sharded_create", "cgv_sharded_destroy",
                  "cgv_sharded_reserve", "cgv_sharded_add_f32", "cgv_sharded_update_row_f32", "cgv_sharded_get_row_f32",
@@ -247,6 +253,10 @@ class HipKnnIndex:
     def set_force_exact(self, on=True):
         _check(lib().cgv_set_force_exact(self._h, 1 if on else 0))
 
+    def set_spin_us(self, us):
+        """How long the end of a search polls its stream before it blocks (cgv_set_spin_us; default 3000, 0 = block at once)."""
+        _check(lib().cgv_set_spin_us(self._h, int(us)))
+
     def synchronize(self):
         _check(lib().cgv_synchronize(self._h))
 
@@ -324,6 +334,29 @@ class HipKnnIndex:
             _check(lib().cgv_search_begin_f32_dev(self._h, C.c_void_p(q.data_ptr()), nq, k,
                                                   C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr()), C.byref(t)))
         return PendingSearch(self, t.value, q, idx, sc)
+
+    def search_begin_pinned(self, q_pinned, k, out):
+        """Host-in / host-out batch in flight: `q_pinned` (pinned CPU f32 [nq, dim]) is read in place over PCIe by the
+        conversion kernel, the last kernel writes ids / scores straight into the pinned CPU tensors out = (int64 [nq, k],
+        float32 [nq, k]); valid after .wait(). The same work as cgv_search_f32 on pinned buffers, split so that up to
+        max_in_flight batches overlap on the device (cgv_search_begin_f32_dev on the buffers' device aliases / cgv_search_end).
+        The tensors must stay alive and untouched until wait()."""
+        import torch
+        k = int(k)
+        oi, os_ = out
+        if not (_is_torch(q_pinned) and not q_pinned.is_cuda and q_pinned.is_pinned() and q_pinned.dtype == torch.float32 and
+                q_pinned.is_contiguous() and q_pinned.dim() == 2 and q_pinned.shape[1] == self.dim):
+            raise CgvError(CGV_ERR_INVALID_ARG, f"search_begin_pinned takes a contiguous pinned CPU f32 tensor [nq, {self.dim}]")
+        nq = q_pinned.shape[0]
+        for t, dt in ((oi, torch.int64), (os_, torch.float32)):
+            if tuple(t.shape) != (nq, k) or t.dtype != dt or not t.is_contiguous() or t.is_cuda or not t.is_pinned():
+                raise CgvError(CGV_ERR_INVALID_ARG, "search_begin_pinned: out = contiguous pinned CPU [nq, k] int64 / float32 tensors")
+        self.use_own_stream()   # nothing of the caller's to order after: host memory in, host memory out
+        t = C.c_uint64(0)
+        if nq and k:
+            _check(lib().cgv_search_begin_f32_dev(self._h, C.c_void_p(self.device_alias(q_pinned)), nq, k,
+                                                  C.c_void_p(self.device_alias(oi)), C.c_void_p(self.device_alias(os_)), C.byref(t)))
+        return PendingSearch(self, t.value, q_pinned, oi, os_)
 
     def search(self, queries, k):
         """queries [nq, dim] -> (idx uint64 [nq,k], score f32 [nq,k]); numpy in -> numpy out,
@@ -507,6 +540,10 @@ class ShardedIndex:
 
     def set_exchange(self, kind):
         _check(lib().cgv_sharded_set_exchange(self._h, {"rccl": 1, "copy": 2}[kind]))
+
+    def force_exchange(self, on=True):
+        """A handle over ONE shard: run pack -> exchange (one-rank ncclAllGather) -> merge anyway (cgv_sharded_force_exchange)."""
+        _check(lib().cgv_sharded_force_exchange(self._h, 1 if on else 0))
 
     def reserve(self, n):
         _check(lib().cgv_sharded_reserve(self._h, int(n)))

@@ -164,6 +164,11 @@ struct SearchCtx {
     hipStream_t run = nullptr;
     hipStream_t cur() const { return on_caller ? run : stream; }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // cgv_search_packed_begin_f32_dev: recorded on the consumer's stream right behind the pack kernel. The consumer's stream is
+    // SHARED with whatever the caller enqueues next (the collective, the merge, the next batch of the same stream), so the
+    // search's end waits for THIS, not for the stream (end(A) used to be serialised behind batch B's device work)
+    hipEvent_t packed_done = nullptr;
+    bool wait_packed = false;
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
     uint32_t* h_flags_dev = nullptr;  // ... as the device sees it (the last kernel of a search publishes the flags there)
@@ -232,6 +237,7 @@ struct cgv_index {
     std::mutex mu;
     std::condition_variable cv;
     int profiling = 0;  // 0 off; 1 = HIP events around the dominant coarse launch; 2 = also around the whole pipeline
+    long spin_us = 3000;  // cgv_set_spin_us: how long a search's end polls its stream before it blocks
     bool force_exact = false;
     bool wide_range = false;  // a stored row's magnitude is outside [2^-40, 2^40]: searches take the exact scan (kernels_prep.h)
     cgv_stats st;
@@ -782,6 +788,7 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, 
 // device): the fused sample + emit launch (COARSE_EMIT_BOOT) holds its workgroups at a rendezvous and wants the device to
 // itself, so only a search that finds the device idle takes that form (search_enqueue); the others use the three-launch form,
 // which never waits. (Best effort - another process is invisible here; the rendezvous is bounded for that reason.)
+#ifdef CGV_ABLATE_BUILD   // (the production library has no fused launch: no counter, no bookkeeping - ADVICE r4)
 constexpr int MAX_DEVICES = 64;
 std::atomic<int> g_dev_inflight[MAX_DEVICES];
 void dev_inflight_add(const cgv_index* h, int d) {
@@ -790,6 +797,9 @@ void dev_inflight_add(const cgv_index* h, int d) {
 int dev_inflight(const cgv_index* h) {
     return (h->device >= 0 && h->device < MAX_DEVICES) ? g_dev_inflight[h->device].load(std::memory_order_relaxed) : 2;
 }
+#else
+inline void dev_inflight_add(const cgv_index*, int) {}
+#endif
 
 template <int DT>
 void launch_boot(cgv_index* h, SearchCtx* c, uint32_t n_boot, uint32_t nq, float* dense, BootMap bmap, hipStream_t s) {
@@ -919,7 +929,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                               a.kc % 4 == 0 && nqt > 1 && nqt * 4u <= BOOT_WORDS && nsplit0 * fvals >= 4u * kprime &&
                               nsplit0 <= SAMPLE_TILES_MAX && p.counts[0] >= 2 * nsplit0;  // (every workgroup walks >= 2 tiles)
 #ifdef CGV_ABLATE_BUILD
-        const bool fuse = can_fuse && tun().fuse_sample > 0;
+        const bool fuse = can_fuse && tun().fuse_sample > 0 && dev_inflight(h) <= 1;  // (this search is the one in flight)
 #else
         const bool fuse = false;
         (void)can_fuse;
@@ -1101,8 +1111,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 // Wait for the batch enqueued on `c`, run the exact path for the queries whose guarantee check
 // failed (or for all of them on an f32 / forced-exact index), fold the statistics in.
 // Called WITHOUT h->mu (the context is owned by the caller); takes it for the statistics.
-// Wait for a stream: poll for up to CGV_SPIN_US microseconds (default 3000; 0 = never) before blocking. A
-// batch takes ~1.5 ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it.
+// Wait for a stream: poll for up to cgv_index::spin_us microseconds (cgv_set_spin_us; default 3000; 0 = never) before blocking.
+// A batch takes ~1.5 ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it.
 // Device-visible alias of a pinned / registered HOST pointer, or NULL (pageable memory, device memory, unknown).
 // The WHOLE range [p, p + bytes) must be pinned / registered and map to one contiguous device range: a buffer that is only
 // partly registered, or that starts inside a pinned allocation and runs past its end, is staged like pageable memory
@@ -1128,12 +1138,12 @@ void* device_alias(const void* p, size_t bytes) {
     return at.devicePointer;
 }
 
-int wait_stream(hipStream_t s) {
-    static const long spin_us = getenv("CGV_SPIN_US") ? atol(getenv("CGV_SPIN_US")) : 3000;
+// ev != NULL: wait for that event (recorded on s) instead of the whole stream.
+int wait_stream(hipStream_t s, long spin_us, hipEvent_t ev = nullptr) {
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            const hipError_t e = hipStreamQuery(s);
+            const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(s);
             if (e == hipSuccess) return CGV_OK;
             if (e != hipErrorNotReady) {
                 (void)hipGetLastError();
@@ -1143,7 +1153,8 @@ int wait_stream(hipStream_t s) {
                 break;
         }
     }
-    HIPCHK(hipStreamSynchronize(s));
+    if (ev) HIPCHK(hipEventSynchronize(ev));
+    else HIPCHK(hipStreamSynchronize(s));
     return CGV_OK;
 }
 
@@ -1151,7 +1162,8 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     hipStream_t s = c->cur();
     const uint32_t nq = c->nq, k = c->k;
     int rc;
-    if ((rc = wait_stream(s))) return rc;
+    if ((rc = wait_stream(s, h->spin_us, c->wait_packed ? c->packed_done : nullptr))) return rc;
+    c->wait_packed = false;
     c->rewrote = false;
     if (c->published && c->h_flags[F_DONE] != nq)
         return fail(CGV_ERR_INTERNAL, "search pipeline finished without publishing its flags");
@@ -1233,6 +1245,7 @@ SearchCtx* acquire_ctx(cgv_index* h, std::unique_lock<std::mutex>& lk, bool spli
     got->gen++;
     got->on_caller = false;  // (a packed ticket ended through cgv_search_end leaves these set)
     got->rec_out = nullptr;
+    got->wait_packed = false;
     dev_inflight_add(h, +1);
     return got;
 }
@@ -1278,7 +1291,7 @@ int order_after_caller(cgv_index* h, SearchCtx* c) {
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 5u; }  // 0.5: + packed (join-free) search, merge with redo flag, host alias, COSINE_SCALAR
+uint32_t cgv_version(void) { return (0u << 16) | 6u; }  // 0.6: + cgv_set_spin_us, cgv_sharded_force_exchange (no environment reads)
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
@@ -1383,6 +1396,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     for (SearchCtx& c : h->ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.packed_done, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
@@ -1423,6 +1437,7 @@ int cgv_destroy(cgv_index* h) {
         if (c.flags) (void)hipFree(c.flags);
         if (c.h_flags) (void)hipHostFree(c.h_flags);
         if (c.dep) (void)hipEventDestroy(c.dep);
+        if (c.packed_done) (void)hipEventDestroy(c.packed_done);
         for (int i = 0; i < 4; ++i)
             if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1800,6 +1815,8 @@ int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint
         launch_pack(c->outidx.as<uint64_t>(), c->outscore.as<float>(), nq, k, rec_out_dev,
                     c->mfma && h->n ? c->fbflag.as<uint32_t>() : nullptr, all_prov ? 1u : 0u, c->run);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->packed_done, c->run));  // what this search's end waits for (not the consumer's whole stream)
+        c->wait_packed = true;
         return CGV_OK;
     };
     rc = body();
@@ -2237,6 +2254,12 @@ int cgv_get_stats(cgv_index* h, cgv_stats* out) {
 int cgv_set_profiling(cgv_index* h, int enabled) {
     if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
     h->profiling = enabled < 0 ? 0 : enabled;
+    return CGV_OK;
+}
+
+int cgv_set_spin_us(cgv_index* h, uint32_t spin_us) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    h->spin_us = (long)std::min<uint32_t>(spin_us, 1000000u);
     return CGV_OK;
 }
 

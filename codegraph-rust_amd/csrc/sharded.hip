@@ -33,7 +33,9 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -72,16 +74,17 @@ std::mutex g_rccl_mu;
 Rccl g_rccl;
 bool g_rccl_tried = false;
 std::string g_rccl_err;  // why the library is unusable (dlerror() text is consumed by the call that reads it)
+std::string g_rccl_forced;  // cgv_debug_rccl_lib_(): the only name to try (tests: a name that cannot be loaded exercises the
+                            // fall-back to the copy exchange). The library reads nothing from the environment.
 
-// why: receives the reason when NULL is returned. CGV_RCCL_LIB overrides the library name (tests: a name that
-// cannot be loaded exercises the fall-back to the copy exchange).
+// why: receives the reason when NULL is returned.
 const Rccl* load_rccl(std::string* why = nullptr) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (!g_rccl_tried) {
         g_rccl_tried = true;
         // a copy already mapped into the process (e.g. PyTorch's) is found first by its soname
         std::vector<std::string> names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        if (const char* forced = getenv("CGV_RCCL_LIB")) names = {forced};
+        if (!g_rccl_forced.empty()) names = {g_rccl_forced};
         for (const std::string& name : names) {
             g_rccl.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (g_rccl.lib) break;
@@ -174,6 +177,8 @@ struct Shard {
         int xerr = 0;          // this shard's ncclAllGather CALL failed (the communicators were aborted by its job)
         int repacked = 0;      // cgv_search_packed_end replaced provisional records
         hipEvent_t x0 = nullptr, x1 = nullptr;  // root only: records ready -> merged results copied (last_exchange_ms)
+        hipEvent_t done = nullptr;  // behind the last operation the first half enqueued for THIS batch on xs: what the second
+        bool done_ok = false;       // half waits for (xs is shared by the batches in flight - ADVICE r4)
     } slot[3];
     Worker w;
 };
@@ -200,6 +205,7 @@ struct cgv_sharded {
         Buf moidx, mosc;  // merged results, on the root device
         uint32_t* pin_redo = nullptr;  // pinned word the merge kernel raises when a record was PROVISIONAL (cgvec.h)
         bool merged_in_begin = false;  // RCCL exchange: the root's merge + result copy were enqueued by the first half
+        int exchange = CGV_EXCHANGE_NONE;  // the exchange the first half used
         uint64_t* out_idx = nullptr;
         float* out_score = nullptr;
         std::vector<uint64_t> job_a;  // per shard: sequence number of the first-half job
@@ -207,10 +213,14 @@ struct cgv_sharded {
     } slots[3];
     std::condition_variable slot_cv;
     bool rccl_broken = false;  // a rank failed to post a collective: communicators aborted, copy exchange from now on
-    std::mutex abort_mu;       // abort_comms_now(): the failing rank's worker aborts every communicator, once
-    bool comms_aborted = false;
-    // a handle over ONE shard normally skips pack / exchange / merge; CGV_SHARDED_FORCE_EXCHANGE=1 (read at create) runs them
-    // anyway - a one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
+    // abort_comms_now(): the failing rank's worker aborts every communicator, once - EXCLUSIVE; every ncclAllGather call is
+    // made under a SHARED hold after checking comms_aborted, so no worker can enter a collective on a freed communicator
+    // (ADVICE r4). ncclAllGather only enqueues (blocking communicators return once the kernel is on the stream), so a shared
+    // hold never waits for a peer.
+    std::shared_mutex abort_mu;
+    std::atomic<bool> comms_aborted{false};
+    // a handle over ONE shard normally skips pack / exchange / merge; cgv_sharded_force_exchange() runs them anyway - a
+    // one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
     bool force_xch = false;
     uint64_t searches = 0, queries = 0, redo_batches = 0;
     float last_search_ms = 0.0f, last_exchange_ms = 0.0f;
@@ -332,6 +342,14 @@ int set_exchange_locked(cgv_sharded* s, int kind) {
 
 extern "C" {
 
+// internal (tests): the only library name load_rccl() may try; must be called before the first use of RCCL in the process.
+int cgv_debug_rccl_lib_(const char* name) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_tried) return 0;
+    g_rccl_forced = name ? name : "";
+    return 1;
+}
+
 // internal (tests): try to load RCCL the way cgv_sharded_create does. Returns 1 when usable, else 0 with the
 // reason in msg (truncated to cap bytes). Needs no device.
 int cgv_debug_rccl_probe_(char* msg, uint32_t cap) {
@@ -358,7 +376,6 @@ int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, 
     s->metric = metric;
     s->dtype = dtype;
     s->G = n_devices;
-    if (const char* e = getenv("CGV_SHARDED_FORCE_EXCHANGE")) s->force_xch = atoi(e) != 0;
     for (uint32_t g = 0; g < n_devices; ++g)
         for (uint32_t g2 = 0; g2 < g; ++g2)
             if (device_ids[g] == device_ids[g2]) s->distinct = false;
@@ -388,13 +405,9 @@ int cgv_sharded_create(uint32_t dim, int metric, int dtype, uint32_t n_devices, 
         }
     }
     if (rc == CGV_OK) {
-        int want = s->distinct ? CGV_EXCHANGE_RCCL : CGV_EXCHANGE_COPY;
-        if (const char* e = getenv("CGV_SHARDED_EXCHANGE")) {
-            if (!strcmp(e, "copy")) want = CGV_EXCHANGE_COPY;
-            if (!strcmp(e, "rccl")) want = CGV_EXCHANGE_RCCL;
-        }
+        const int want = s->distinct ? CGV_EXCHANGE_RCCL : CGV_EXCHANGE_COPY;  // (cgv_sharded_set_exchange changes it)
         rc = set_exchange_locked(s, want);
-        if (rc != CGV_OK && want == CGV_EXCHANGE_RCCL && !getenv("CGV_SHARDED_EXCHANGE")) {
+        if (rc != CGV_OK && want == CGV_EXCHANGE_RCCL) {
             // RCCL not loadable on this box: the exchange still happens on the device side, by peer copies
             rc = set_exchange_locked(s, CGV_EXCHANGE_COPY);
         }
@@ -425,13 +438,14 @@ int cgv_sharded_destroy(cgv_sharded* s) {
     for (Shard* sh : s->sh) {
         (void)hipSetDevice(sh->device);
         if (sh->xs) (void)hipStreamSynchronize(sh->xs);
-        if (sh->comm && r && !s->comms_aborted) (void)r->CommDestroy(sh->comm);
+        if (sh->comm && r && !s->comms_aborted.load()) (void)r->CommDestroy(sh->comm);
         if (sh->ix) (void)cgv_destroy(sh->ix);
         sh->stage.release();
         for (auto& sb : sh->slot) {
             for (Buf* b : {&sb.qdev, &sb.oidx, &sb.osc, &sb.rec, &sb.gathered}) b->release();
             if (sb.x0) (void)hipEventDestroy(sb.x0);
             if (sb.x1) (void)hipEventDestroy(sb.x1);
+            if (sb.done) (void)hipEventDestroy(sb.done);
         }
         if (sh->xs) (void)hipStreamDestroy(sh->xs);
     }
@@ -617,6 +631,20 @@ int cgv_sharded_set_exchange(cgv_sharded* s, int kind) {
     return set_exchange_locked(s, kind);
 }
 
+int cgv_sharded_force_exchange(cgv_sharded* s, int enabled) {
+    if (!s) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    DeviceGuard guard;
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (const auto& sl : s->slots)
+        if (sl.busy) return fail(CGV_ERR_BUSY, "a search is in flight: call cgv_sharded_search_end first");
+    s->force_xch = enabled != 0;
+    if (s->G > 1) return CGV_OK;  // several shards always exchange
+    if (!s->force_xch) return set_exchange_locked(s, CGV_EXCHANGE_NONE);
+    int rc = set_exchange_locked(s, s->rccl_broken ? CGV_EXCHANGE_COPY : CGV_EXCHANGE_RCCL);
+    if (rc != CGV_OK) rc = set_exchange_locked(s, CGV_EXCHANGE_COPY);  // RCCL not loadable: the one-shard exchange by a copy
+    return rc;
+}
+
 // ---- search: batches in flight (cgv_sharded_search_begin_f32 / _end, below) ----------------------------------------
 namespace {
 
@@ -649,14 +677,22 @@ void drain_streams(cgv_sharded* s) {
 // thread after the join: the communicators are gone and the handle continues with the copy exchange. Without
 // ncclCommAbort in the library the communicators are destroyed instead.
 void abort_comms_now(cgv_sharded* s, const Rccl* r) {
-    std::lock_guard<std::mutex> lk(s->abort_mu);
-    if (s->comms_aborted) return;
-    s->comms_aborted = true;
+    std::unique_lock<std::shared_mutex> lk(s->abort_mu);  // no ncclAllGather call is in progress while the communicators go
+    if (s->comms_aborted.load()) return;
+    s->comms_aborted.store(true);
     for (Shard* sh : s->sh) {
         if (!sh->comm || !r) continue;
         if (r->CommAbort) (void)r->CommAbort(sh->comm);
         else (void)r->CommDestroy(sh->comm);
     }
+}
+
+// ncclAllGather of one shard's records, entered only while the communicators are alive. Returns 0, an RCCL error code, or -1
+// when the communicators were aborted (by a failing rank of this or an earlier batch): the call is skipped.
+int guarded_all_gather(cgv_sharded* s, const Rccl* r, Shard* sh, const void* src, void* dst, size_t count) {
+    std::shared_lock<std::shared_mutex> lk(s->abort_mu);
+    if (s->comms_aborted.load() || !sh->comm) return -1;
+    return r->AllGather(src, dst, count, NCCL_INT32, sh->comm, sh->xs);
 }
 
 void abort_rccl(cgv_sharded* s, const Rccl* r) {
@@ -713,7 +749,9 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
     const size_t qbytes = (size_t)nq * D * 4, rec_bytes = (size_t)nq * w * 4;
     Shard* root = s->sh[0];
     const bool xch = G > 1 || s->force_xch;
-    const int exchange = s->exchange;
+    // (a rank of an earlier batch failed to post its collective and aborted the communicators, and that batch has not been
+    // ended yet - abort_rccl() switches the handle over there: batches begun in between already use the copy exchange)
+    const int exchange = (s->exchange == CGV_EXCHANGE_RCCL && s->comms_aborted.load()) ? CGV_EXCHANGE_COPY : s->exchange;
     if (sl.pin_q_bytes < qbytes) {  // (the slot is idle: nothing reads its staging)
         if (sl.pin_q) (void)hipHostFree(sl.pin_q);
         sl.pin_q = nullptr;
@@ -738,10 +776,9 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
             if ((rc = b.rec.ensure(rec_bytes))) return rc;
             if ((exchange == CGV_EXCHANGE_RCCL || sh == root) && (rc = b.gathered.ensure((size_t)G * rec_bytes))) return rc;
         }
-        if (sh == root && !b.x0) {
-            SHIP(hipEventCreate(&b.x0));
-            SHIP(hipEventCreate(&b.x1));
-        }
+        if (sh == root && !b.x0) SHIP(hipEventCreate(&b.x0));  // (independently: a failed second create must not leave the
+        if (sh == root && !b.x1) SHIP(hipEventCreate(&b.x1));  //  first one looking like "both exist" - ADVICE r4)
+        if (!b.done) SHIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     }
     if (xch) {
         SHIP(hipSetDevice(root->device));
@@ -764,6 +801,7 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
     sl.out_score = out_score_host;
     sl.t0 = Clock::now();
     sl.merged_in_begin = xch && exchange == CGV_EXCHANGE_RCCL;
+    sl.exchange = exchange;
     sl.job_a.assign(G, 0);
     const float* pin_q = sl.pin_q;
     cgv_sharded::Slot* slp = &sl;
@@ -786,17 +824,24 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
             };
             b.rc_a = search_half();
             if (b.rc_a) b.err_a = cgv_last_error();
+            // whatever follows, the second half waits for THIS batch's last operation on xs, not for the stream
+            struct DoneMark {
+                Shard* sh;
+                Shard::SlotBufs& b;
+                ~DoneMark() { b.done_ok = hipEventRecord(b.done, sh->xs) == hipSuccess; }
+            } mark{sh, b};
             if (!xch) return CGV_OK;  // the status travels with the slot: the second half reports it
             if (sh == root) (void)hipEventRecord(b.x0, sh->xs);   // the root's records are ready
             if (exchange == CGV_EXCHANGE_RCCL) {
                 // entered by every shard, whatever its own search returned (the buffers exist; the batch's status discards
                 // the result): a collective that one rank skips never completes on the others
-                const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                const int e = guarded_all_gather(s, rccl, sh, b.rec.p, b.gathered.p, (size_t)nq * w);
                 if (e != 0) {
                     b.xerr = 1;
                     if (b.rc_a == CGV_OK) {
                         b.rc_a = CGV_ERR_HIP;
-                        b.err_a = std::string("ncclAllGather: ") + rccl->GetErrorString(e);
+                        b.err_a = e < 0 ? std::string("ncclAllGather skipped: the communicators were aborted by a failing rank")
+                                        : std::string("ncclAllGather: ") + rccl->GetErrorString(e);
                     }
                     abort_comms_now(s, rccl);  // the other ranks posted theirs and will wait on their streams: unblock them
                     return CGV_OK;
@@ -807,8 +852,8 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
                         b.rc_a = mrc;
                         b.err_a = cgv_last_error();
                     }
-                    (void)hipEventRecord(b.x1, sh->xs);
                 }
+                if (sh == root) (void)hipEventRecord(b.x1, sh->xs);  // (always: the second half reads the pair)
             } else if (b.rc_a == CGV_OK) {
                 char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
                 const hipError_t he = sh->device == root->device
@@ -856,10 +901,12 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
             Shard::SlotBufs& b = sh->slot[si];
             int rc = b.rc_a;
             std::string err = b.err_a;
-            const hipError_t se = hipStreamSynchronize(sh->xs);  // exchange (and, RCCL root, merge + result copy) done
+            // this batch's exchange (and, RCCL root, merge + result copy) done - its own event, not the stream the batches
+            // in flight share
+            const hipError_t se = b.done_ok ? hipEventSynchronize(b.done) : hipStreamSynchronize(sh->xs);
             if (se != hipSuccess && rc == CGV_OK) {
                 rc = CGV_ERR_HIP;
-                err = std::string("hipStreamSynchronize: ") + hipGetErrorString(se);
+                err = std::string("waiting for the batch: ") + hipGetErrorString(se);
             }
             if (b.ticket) {  // ends the search whatever happened around it (the context must be released)
                 const int erc = b.packed ? cgv_search_packed_end(sh->ix, b.ticket, &b.repacked) : cgv_search_end(sh->ix, b.ticket);
@@ -882,6 +929,15 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
         rc = fail(rc ? rc : CGV_ERR_HIP, msg + " (RCCL communicators aborted; the handle continues with the copy exchange)");
     }
     if (rc) return finish(rc);
+    // This batch posted every all-gather, but a rank of ANOTHER batch in flight then failed and aborted the communicators: the
+    // stream waits above returned because of the abort, not because the gather completed, so what the root merged may be
+    // incomplete. The shards' records are intact (the searches ended above): exchange them again by copies.
+    bool rerun_by_copy = false;
+    if (rccl_mode && s->comms_aborted.load()) {
+        abort_rccl(s, rccl);
+        drain_streams(s);
+        rerun_by_copy = true;
+    }
     hipError_t he = hipSetDevice(root->device);
     if (he != hipSuccess) return finish(fail(CGV_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)));
     if (!xch) {  // one shard, no exchange: its results go back as they are
@@ -899,10 +955,12 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
             return r;
         };
         if (!rccl_mode && (rc = root_round())) return finish(rc);  // COPY: every shard's records have landed (the join above)
-        if (*sl.pin_redo != 0u) {
+        if (*sl.pin_redo != 0u || rerun_by_copy) {
             // a shard could not prove a query on the device: its search has now run the exact scan and re-packed (the end
-            // jobs above) - the exchange is repeated once with the final records
+            // jobs above) - the exchange is repeated once with the final records (also: the rerun after a foreign abort)
+            const bool was_redo = *sl.pin_redo != 0u;
             *sl.pin_redo = 0u;
+            const bool by_rccl = rccl_mode && !rerun_by_copy;
             std::vector<std::function<int()>> again(G);
             std::vector<int> xerr2(G, 0);
             for (uint32_t g = 0; g < G; ++g) {
@@ -910,12 +968,13 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
                 int* xe = &xerr2[g];
                 again[g] = [=]() -> int {
                     Shard::SlotBufs& b = sh->slot[si];
-                    if (rccl_mode) {
-                        const int e = rccl->AllGather(b.rec.p, b.gathered.p, (size_t)nq * w, NCCL_INT32, sh->comm, sh->xs);
+                    if (by_rccl) {
+                        const int e = guarded_all_gather(s, rccl, sh, b.rec.p, b.gathered.p, (size_t)nq * w);
                         if (e != 0) {
                             *xe = 1;
                             abort_comms_now(s, rccl);
-                            return fail(CGV_ERR_HIP, std::string("ncclAllGather: ") + rccl->GetErrorString(e));
+                            return fail(CGV_ERR_HIP, e < 0 ? std::string("ncclAllGather skipped: communicators aborted")
+                                                           : std::string("ncclAllGather: ") + rccl->GetErrorString(e));
                         }
                     } else {
                         char* dst = (char*)root->slot[si].gathered.p + (size_t)sh->index * rec_bytes;
@@ -941,7 +1000,7 @@ int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket) {
             if (hipSetDevice(root->device) != hipSuccess) return finish(fail(CGV_ERR_HIP, "hipSetDevice(root)"));
             if ((rc = root_round())) return finish(rc);
             if (*sl.pin_redo != 0u) return finish(fail(CGV_ERR_INTERNAL, "records still provisional after the searches ended"));
-            s->redo_batches++;
+            if (was_redo) s->redo_batches++;
         }
     }
     const auto t2 = Clock::now();

@@ -70,10 +70,25 @@ def shard_range(n_total, rank, world):
     return lo, hi
 
 
+class _Batch:
+    """One batch in flight of ShardedKnn.step_packed_begin / _end: its record / gather buffers, the pinned redo word the merge
+    kernel raises, the stream the whole batch is enqueued on (shard search, packing, all-gather, merge - in line, no hop) and
+    the event behind its last kernel. Reused round-robin; `busy` between begin and end."""
+    __slots__ = ("key", "rec", "gathered", "redo", "stream", "done", "ev", "ticket", "k", "nq", "out", "res", "busy",
+                 "mode", "timed", "queries")
+
+    def __init__(self):
+        self.key = None
+        self.stream = self.done = self.ev = None
+        self.busy = False
+
+
 class ShardedKnn:
     """`local` is any object with search(queries, k) -> (idx int64[nq,k], score f32[nq,k]) whose
     ids are already GLOBAL (HipKnnIndex.set_index_base(lo)); `merge` maps gathered
     [G,nq,k] tensors to [nq,k] (default: the HIP merge kernel through the C ABI)."""
+
+    MAX_IN_FLIGHT = 3   # = the handle's search contexts (cgv_max_batches_in_flight)
 
     def __init__(self, local, rank=None, world=None, group=None, merge=None, force_collective=False):
         self.local = local
@@ -83,6 +98,8 @@ class ShardedKnn:
         self.world = dist.get_world_size(group) if world is None else world
         self._device_merge = merge is None   # default: packed records + the HIP merge kernel
         self._gathered = None
+        self._slots = [_Batch() for _ in range(self.MAX_IN_FLIGHT)]
+        self._next = 0
         if merge is None:
             from .cgvec import merge_topk
             merge = merge_topk
@@ -91,31 +108,72 @@ class ShardedKnn:
     def search(self, queries, k):
         return self._exchange(*self.local.search(queries, k), k)
 
-    # ---- join-free step (round 4): search -> pack on the library's stream, collective + merge enqueued behind an event,
-    # ONE host synchronisation per batch; provisional records make every rank repeat the exchange (include/cgvec.h) --------
+    # ---- join-free step: search -> pack -> all-gather -> merge enqueued in line on ONE stream per batch, one host
+    # synchronisation per batch; provisional records make every rank repeat the exchange (include/cgvec.h). Round 5: split into
+    # begin / end so that 2-3 batches are in flight (each on its own stream): the host reads batch i's redo word while batch
+    # i + 1 runs - the fixed per-batch cost that does not shrink with the shard (PCIe read of the replicated batch, sample, final,
+    # exchange, host) hides behind the neighbours' coarse kernels ("unless batches are pipelined") ----
     redo_batches = 0
-    time_exchange = False      # step_packed: HIP-event pair around all-gather + merge on the stream they run on
+    time_exchange = False      # HIP-event pair around all-gather + merge on the stream they run on
     last_exchange_ms = 0.0
-    _ev = None
 
-    def _buffers(self, nq, k, like):
+    def _collective(self):
+        """None: no collective (one rank, not forced); else the backend of the group ("nccl" = RCCL, "gloo")."""
+        if self.world == 1 and not self.force_collective:
+            return None
+        return self._backend()
+
+    def _backend(self):
+        # (no process group: a test's in-process stand-in for all_gather_into_tensor - the device branch)
+        return dist.get_backend(self.group) if dist.is_available() and dist.is_initialized() else "nccl"
+
+    def _take_slot(self, nq, k, like):
         w = packed_width(k)
-        key = (nq, w, str(like.device) if like.is_cuda else "cpu")
-        if getattr(self, "_pk_key", None) != key:
+        for _ in range(len(self._slots)):
+            b = self._slots[self._next]
+            self._next = (self._next + 1) % len(self._slots)
+            if not b.busy:
+                break
+        else:
+            raise RuntimeError(f"ShardedKnn: {len(self._slots)} batches already in flight - call step_packed_end first")
+        key = (nq, w, str(like.device) if like.is_cuda else "cpu", self.world)
+        if b.key != key:
             dev = like.device if like.is_cuda else torch.device("cpu")
-            self._pk_rec = torch.empty((nq, w), dtype=torch.int32, device=dev)
-            self._pk_gathered = torch.empty((self.world, nq, w), dtype=torch.int32, device=dev)
-            self._pk_redo = torch.zeros(1, dtype=torch.int32)
+            b.rec = torch.empty((nq, w), dtype=torch.int32, device=dev)
+            b.gathered = torch.empty((self.world, nq, w), dtype=torch.int32, device=dev)
+            b.redo = torch.zeros(1, dtype=torch.int32)
             if like.is_cuda:
-                self._pk_redo = self._pk_redo.pin_memory()   # written in place by the merge kernel, read by the host after the sync
-            self._pk_key = key
-        return self._pk_rec, self._pk_gathered, self._pk_redo
+                b.redo = b.redo.pin_memory()   # written in place by the merge kernel, read by the host after the batch's event
+                b.stream = torch.cuda.Stream(device=dev)
+                b.done = torch.cuda.Event()
+                b.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            b.key = key
+        return b
 
-    def _gather_merge(self, rec, gathered, k, out, redo):
+    def _gather_merge(self, b):
+        """all-gather of the batch's records + merge (redo word) - enqueued on the current stream (RCCL), or, when the records
+        travel over gloo, through the host (CPU stand-ins of the tests; real device shards of several ranks on ONE GPU, which RCCL
+        refuses: the dry run of the multi-GPU bench on a single-GPU box)."""
+        rec, gathered, k, out, redo = b.rec, b.gathered, b.k, b.out, b.redo
+        coll = self._collective()
         if rec.is_cuda:
             from .cgvec import merge_packed
-            dist.all_gather_into_tensor(gathered, rec, group=self.group)
-            return merge_packed(gathered, k, out=out, redo=redo)
+            if coll is None:
+                g = rec.view(1, rec.shape[0], rec.shape[1])
+            elif coll == "gloo":
+                torch.cuda.current_stream(rec.device).synchronize()
+                mine = rec.cpu()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                if self.world > 1:
+                    dist.all_gather(parts, mine, group=self.group)
+                else:
+                    parts[0].copy_(mine)
+                gathered.copy_(torch.stack(parts))
+                g = gathered
+            else:
+                dist.all_gather_into_tensor(gathered, rec, group=self.group)
+                g = gathered
+            return merge_packed(g, k, out=out, redo=redo)
         parts = [gathered[r] for r in range(self.world)]
         if self.world > 1:
             dist.all_gather(parts, rec, group=self.group)     # gloo (CPU tests)
@@ -131,72 +189,111 @@ class ShardedKnn:
         return oi, os_
 
     @staticmethod
-    def _wait(device, spin_s=0.005):
-        """The batch's ONE host synchronisation: poll the stream for a few milliseconds before blocking - a batch takes 0.3-1.5
-        ms, and the wake-up of a blocked hipStreamSynchronize costs tens of microseconds of it (the library waits for its own
+    def _wait(event, spin_s=0.005):
+        """The batch's ONE host synchronisation: poll its event for a few milliseconds before blocking - a batch takes 0.3-1.5
+        ms, and the wake-up of a blocked synchronize costs tens of microseconds of it (the library waits for its own
         streams the same way, cgvec.hip: wait_stream)."""
         import time
-        st = torch.cuda.current_stream(device)
         t0 = time.perf_counter()
-        while not st.query():
+        while not event.query():
             if time.perf_counter() - t0 > spin_s:
-                st.synchronize()
+                event.synchronize()
                 return
 
-    def step_packed(self, queries, k, out=None, device=None):
-        """One batch, one host synchronisation: local.search_packed_begin (shard search + packed records, the consumer stream
-        waits for them) -> all-gather -> merge with the redo flag -> sync -> local.search_packed_end. When any rank's records
-        were provisional (the same flag on every rank), the exchange is repeated with the final records.
+    def step_packed_begin(self, queries, k, out=None, device=None):
+        """First half of one batch: local.search_packed_begin (shard search + packed records) and - when the records travel
+        over RCCL - the all-gather and the merge with the redo flag, all enqueued in line on the batch's own stream; returns a
+        handle for step_packed_end. Up to MAX_IN_FLIGHT batches may be begun before the first is ended; EVERY rank must
+        begin and end its batches in the same order (the collectives are posted in that order).
+        `queries`: CUDA tensor, or pinned CPU tensor read in place over PCIe (then `device` names the GPU); `out` = (ids, scores)
+        tensors to fill (CUDA, or pinned CPU written in place by the merge kernel).
         `local` needs search_packed_begin(queries, k, rec) -> ticket and search_packed_end(ticket) -> bool."""
         nq = queries.shape[0]
         like = queries if queries.is_cuda else (torch.empty(0, device=device) if device is not None else queries)
-        rec, gathered, redo = self._buffers(nq, k, like)
-        redo.zero_()
-        ticket = self.local.search_packed_begin(queries, k, rec)
-        timed = rec.is_cuda and self.time_exchange
-        if timed:   # the consumer stream already waits for the records: ev0 = records ready, ev1 = merged results written
-            if self._ev is None:
-                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            self._ev[0].record()
-        res = self._gather_merge(rec, gathered, k, out, redo)
-        if timed:
-            self._ev[1].record()
-        if rec.is_cuda:
-            self._wait(rec.device)
-        if timed:
-            self.last_exchange_ms = self._ev[0].elapsed_time(self._ev[1])
-        self.local.search_packed_end(ticket)
-        if int(redo[0]) != 0:
-            self.redo_batches += 1
-            redo.zero_()
-            res = self._gather_merge(rec, gathered, k, out, redo)
-            if rec.is_cuda:
-                self._wait(rec.device)
-            if int(redo[0]) != 0:
-                raise RuntimeError("records still provisional after search_packed_end")
-        return res
+        b = self._take_slot(nq, int(k), like)
+        b.k, b.nq, b.out, b.res, b.queries = int(k), nq, out, None, queries
+        b.redo.zero_()                       # (the slot is idle: no kernel writes it)
+        b.timed = b.rec.is_cuda and self.time_exchange
+        if b.rec.is_cuda:
+            coll = self._collective()
+            b.mode = "host" if coll == "gloo" else "stream"
+            if queries.is_cuda:              # the producer of a CUDA batch comes first
+                b.stream.wait_stream(torch.cuda.current_stream(b.rec.device))
+            with torch.cuda.stream(b.stream):
+                b.ticket = self.local.search_packed_begin(queries, k, b.rec)
+                if b.mode == "stream":
+                    if b.timed:
+                        b.ev[0].record()
+                    b.res = self._gather_merge(b)
+                    if b.timed:
+                        b.ev[1].record()
+                b.done.record()
+        else:
+            b.mode = "cpu"
+            b.ticket = self.local.search_packed_begin(queries, k, b.rec)
+        b.busy = True
+        return b
 
-    def search_begin(self, queries, k):
-        """Pipelined form: the local shard search is enqueued now; wait() completes it, then runs
-        the all-gather + merge. With two batches in flight the exchange of batch i overlaps the
-        shard search of batch i+1 (which runs on its own stream inside the index)."""
-        pending = self.local.search_begin(queries, k)
-        outer = self
+    def step_packed_end(self, b):
+        """Second half: ONE host wait for the batch, local.search_packed_end, and - only when the merge met a provisional record
+        (the same word on every rank) - the exchange once more with the final records. Returns (ids, scores)."""
+        if not b.busy:
+            raise RuntimeError("ShardedKnn.step_packed_end: the batch is not in flight")
+        cuda = b.rec.is_cuda
+        try:
+            if cuda:
+                self._wait(b.done)
+                if b.mode == "host":             # records over gloo: the exchange happens here, through the host
+                    with torch.cuda.stream(b.stream):
+                        b.res = self._gather_merge(b)
+                        b.done.record()
+                    self._wait(b.done)
+                elif b.timed:
+                    self.last_exchange_ms = b.ev[0].elapsed_time(b.ev[1])
+            else:
+                b.res = self._gather_merge(b)
+            # A search that fails on ONE rank only (an OOM in its exact rescan ...) must not take that rank out of the collective
+            # sequence: the redo word is the same on every rank, so every rank - this one included - runs the second
+            # exchange, and the error is raised after it (ADVICE r4)
+            err = None
+            try:
+                self.local.search_packed_end(b.ticket)
+            except Exception as e:   # noqa: BLE001 - re-raised below, after the collective
+                err = e
+            if int(b.redo[0]) != 0:
+                self.redo_batches += 1
+                b.redo.zero_()
+                if cuda:
+                    with torch.cuda.stream(b.stream):
+                        b.res = self._gather_merge(b)
+                        b.done.record()
+                    self._wait(b.done)
+                else:
+                    b.res = self._gather_merge(b)
+                if err is None and int(b.redo[0]) != 0:
+                    raise RuntimeError("records still provisional after search_packed_end (a rank's search failed)")
+            if err is not None:
+                raise err
+            return b.res
+        finally:
+            b.busy = False
+            b.queries = None
 
-        class _Pending:
-            def wait(self_inner):
-                return outer._exchange(*pending.wait(), k)
-        return _Pending()
+    def step_packed(self, queries, k, out=None, device=None):
+        """One batch, one host synchronisation: step_packed_begin + step_packed_end (strictly serial batches)."""
+        return self.step_packed_end(self.step_packed_begin(queries, k, out=out, device=device))
 
     def _exchange(self, idx, score, k, out=None):
-        """out = (ids, scores): optional result tensors of the device path (CUDA, or pinned CPU tensors the merge kernel
+        """The unpacked exchange of search(): results of a finished local search -> all-gather -> merge.
+        out = (ids, scores): optional result tensors of the device path (CUDA, or pinned CPU tensors the merge kernel
         fills in place - the caller synchronises the stream before reading them)."""
         if self.world == 1 and not self.force_collective:
             return idx, score
         nq = idx.shape[0]
         # ONE all-gather of nq packed records (k u64 ids + k f32 scores, 12 B per hit) per rank:
         # latency-bound (<= 1 MiB per rank at nq=8192, k=10), so a single collective.
-        if idx.is_cuda and self._device_merge:
+        gloo = self._backend() == "gloo"
+        if idx.is_cuda and self._device_merge and not gloo:
             from .cgvec import merge_packed, pack_topk
             rec = pack_topk(idx, score)                       # one kernel instead of cat + 2 slice copies
             key = (self.world,) + tuple(rec.shape)
@@ -206,12 +303,21 @@ class ShardedKnn:
             return merge_packed(self._gathered, k, out=out)
         rec = torch.cat([idx.contiguous().view(torch.int32).reshape(nq, 2 * k),
                          score.contiguous().view(torch.int32).reshape(nq, k)], dim=1).contiguous()
-        gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=rec.device)
-        if dist.get_backend(self.group) == "gloo":  # CPU tests
+        dev = rec.device
+        if gloo:  # CPU tests; device shards of several ranks on one GPU (records through the host)
+            rec = rec.cpu()
+            gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32)
             parts = [gathered[r] for r in range(self.world)]
             dist.all_gather(parts, rec, group=self.group)
+            gathered = gathered.to(dev)
         else:
+            gathered = torch.empty((self.world, nq, 3 * k), dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(gathered, rec, group=self.group)
         g_idx = gathered[:, :, : 2 * k].contiguous().view(torch.int64).reshape(self.world, nq, k)
         g_score = gathered[:, :, 2 * k:].contiguous().view(torch.float32).reshape(self.world, nq, k)
-        return self.merge(g_idx, g_score)
+        res = self.merge(g_idx, g_score)
+        if out is not None:
+            out[0].copy_(res[0])
+            out[1].copy_(res[1])
+            return out
+        return res

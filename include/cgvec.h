@@ -89,7 +89,8 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_MAX_K 2048u
 #define CGV_FAST_MAX_K 228u
 
-/* Library/ABI version (major<<16 | minor). Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
+/* Library/ABI version (major<<16 | minor). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
+ * environment variable. Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
  * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. Minor 5 (round 4): cgv_search_packed_begin_f32_dev
  * / cgv_search_packed_end / cgv_merge_packed_flag_dev (the join-free exchange), cgv_host_device_alias, CGV_METRIC_COSINE_SCALAR /
  * CGV_OP_COSINE_SCALAR, CGV_ERR_BUSY from cgv_sharded_* writers / readers while a batch is in flight. */
@@ -323,6 +324,12 @@ int cgv_get_stats(cgv_index* h, cgv_stats* out);
  * record is a packet on the stream: level 2 measured ~10 us per batch on short searches. */
 int cgv_set_profiling(cgv_index* h, int enabled);
 
+/* How a search's end waits for the device: it polls the batch's stream / event for up to spin_us microseconds (default 3000,
+ * capped at 1 s) and then blocks in the driver. A batch takes 0.3-1.5 ms and the wake-up of a blocked wait costs tens of
+ * microseconds of it, so the default burns one host core for the length of the batch; a caller that runs many handles on few
+ * cores (a tokio server: call the search inside spawn_blocking either way) sets 0 = block at once. */
+int cgv_set_spin_us(cgv_index* h, uint32_t spin_us);
+
 /* Tuning knob for tests: force the exact full-scan path (1) or auto (0). */
 int cgv_set_force_exact(cgv_index* h, int enabled);
 
@@ -385,11 +392,12 @@ int cgv_sharded_search_begin_f32(cgv_sharded* s, const float* queries_host, uint
 int cgv_sharded_search_end(cgv_sharded* s, uint64_t ticket);
 uint32_t cgv_sharded_max_batches_in_flight(const cgv_sharded* s);
 /* Which exchange the handle uses (CGV_EXCHANGE_*); cgv_sharded_set_exchange forces RCCL or COPY
- * (RCCL needs distinct devices). A handle over ONE shard has nothing to exchange (CGV_EXCHANGE_NONE) unless the
- * environment holds CGV_SHARDED_FORCE_EXCHANGE=1 at cgv_sharded_create: then its batches go through pack -> one-rank
- * ncclAllGather (or the copy) -> merge as well - how the RCCL branch is executed on a single-GPU box (tests). */
+ * (RCCL needs distinct devices). A handle over ONE shard has nothing to exchange (CGV_EXCHANGE_NONE) unless
+ * cgv_sharded_force_exchange(s, 1) was called: then its batches go through pack -> one-rank ncclAllGather (or the copy when
+ * RCCL cannot be loaded) -> merge as well - how the RCCL branch is executed on a single-GPU box (tests). */
 int cgv_sharded_exchange(const cgv_sharded* s);
 int cgv_sharded_set_exchange(cgv_sharded* s, int kind);
+int cgv_sharded_force_exchange(cgv_sharded* s, int enabled);
 typedef struct cgv_sharded_stats {
     uint64_t n_rows, device_bytes, searches, queries, fallback_queries;
     uint32_t n_shards, exchange;

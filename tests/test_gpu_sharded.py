@@ -306,17 +306,18 @@ def test_one_rank_rccl_collective_executes(tmp_path, oracle):
 
 
 def test_one_shard_handle_runs_the_in_library_rccl_exchange(oracle, monkeypatch):
-    """cgv_sharded over ONE device with CGV_SHARDED_FORCE_EXCHANGE=1: ncclCommInitAll over one device, then every batch
+    """cgv_sharded over ONE device with cgv_sharded_force_exchange(1): ncclCommInitAll over one device, then every batch
     goes pack -> ncclAllGather (one rank) -> merge -> host, i.e. the RCCL branch of sharded.hip runs on a single-GPU box
     (without the switch a one-shard handle skips the exchange). Results = the oracle's; serial and two batches in flight."""
     m = pkg()
-    monkeypatch.setenv("CGV_SHARDED_FORCE_EXCHANGE", "1")
     rng = np.random.default_rng(5)
     n, d, nq, k = 3 * C + 77, 96, 130, 10
     rows = _unit(rng, n, d)
     q = _unit(rng, nq, d)
     sx = m.ShardedIndex(d, [0], dtype="bf16")
     try:
+        assert sx.exchange == "none"
+        sx.force_exchange(True)
         assert sx.exchange == "rccl"
         sx.add(rows)
         ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
@@ -583,3 +584,105 @@ def test_two_ranks_on_one_gpu_device_records_and_redo(tmp_path, oracle):
     for r in range(2):
         assert np.array_equal(np.load(f"{out}.{r}.idx.npy"), ri), r
         assert np.array_equal(np.load(f"{out}.{r}.sc.npy"), rs), r
+
+
+def test_pipelined_join_free_step_redo_while_other_batches_are_in_flight(oracle):
+    """ShardedKnn.step_packed_begin / _end (round 5): three host-in / host-out batches in flight, each on its own stream
+    (search -> pack -> merge with the redo word in line, pinned batch read in place, pinned results written in place). The
+    MIDDLE batch carries a query planted on a near-duplicate cluster: its record is PROVISIONAL, the merge raises that batch's
+    redo word, and its end re-runs the query through the exact scan and repeats the exchange - while the third batch is still
+    in flight. Every batch must equal the oracle; a fourth begin is refused; serial steps afterwards still work."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(29)
+    n, d, nq, k = 40_000, 128, 300, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[21_000:21_060] = rows[33] * (1 + 1e-4 * rng.standard_normal((60, 1)).astype(np.float32))   # near-duplicates of row 33
+    qa = rng.standard_normal((nq, d)).astype(np.float32)
+    qb = rng.standard_normal((nq, d)).astype(np.float32)
+    qb[5] = rows[33]                                   # straddles the k' boundary of its cluster -> exact scan
+    qc = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        sk = m.ShardedKnn(ix, rank=0, world=1)
+        dev = torch.device("cuda", 0)
+        want = [oracle.batch_top_k(q, rows, k, dtype=1) for q in (qa, qb, qc)]
+        qp = [torch.from_numpy(q).pin_memory() for q in (qa, qb, qc)]
+        outs = [(torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory())
+                for _ in range(3)]
+        for rounds in range(2):                        # (the second round reuses the slots and their streams)
+            hs = [sk.step_packed_begin(qp[i], k, out=outs[i], device=dev) for i in range(3)]
+            with pytest.raises(RuntimeError):
+                sk.step_packed_begin(qp[0], k, out=outs[0], device=dev)
+            before = sk.redo_batches
+            r0 = sk.step_packed_end(hs[0])
+            assert sk.redo_batches == before and r0[0] is outs[0][0]
+            sk.step_packed_end(hs[1])
+            assert sk.redo_batches == before + 1       # the planted query, and only that batch
+            sk.step_packed_end(hs[2])
+            assert sk.redo_batches == before + 1
+            for i in range(3):
+                assert np.array_equal(outs[i][0].numpy().view(np.uint64), want[i][0]), (rounds, i)
+                assert np.array_equal(outs[i][1].numpy(), want[i][1]), (rounds, i)
+        # CUDA batches through the same slots (the slot's stream waits for the producer), results as new CUDA tensors
+        h1 = sk.step_packed_begin(torch.from_numpy(qa).cuda(), k)
+        h2 = sk.step_packed_begin(torch.from_numpy(qc).cuda(), k)
+        i2, s2 = sk.step_packed_end(h2)                # (one rank: any end order)
+        i1, s1 = sk.step_packed_end(h1)
+        assert np.array_equal(i1.cpu().numpy().view(np.uint64), want[0][0]) and np.array_equal(s1.cpu().numpy(), want[0][1])
+        assert np.array_equal(i2.cpu().numpy().view(np.uint64), want[2][0]) and np.array_equal(s2.cpu().numpy(), want[2][1])
+        # a NaN batch between two good ones: fails at ITS end, the neighbours are answered, the slots come back
+        bad = qa.copy()
+        bad[9, 3] = np.nan
+        hs = [sk.step_packed_begin(qp[0], k, out=outs[0], device=dev),
+              sk.step_packed_begin(torch.from_numpy(bad).pin_memory(), k, out=outs[1], device=dev),
+              sk.step_packed_begin(qp[2], k, out=outs[2], device=dev)]
+        sk.step_packed_end(hs[0])
+        with pytest.raises(m.CgvError) as ei:
+            sk.step_packed_end(hs[1])
+        assert ei.value.code == m.cgvec.CGV_ERR_NONFINITE
+        sk.step_packed_end(hs[2])
+        for i in (0, 2):
+            assert np.array_equal(outs[i][0].numpy().view(np.uint64), want[i][0]) and np.array_equal(outs[i][1].numpy(), want[i][1])
+        oi, osc = sk.step_packed(qp[1], k, out=outs[1], device=dev)
+        assert np.array_equal(oi.numpy().view(np.uint64), want[1][0]) and np.array_equal(osc.numpy(), want[1][1])
+    finally:
+        ix.close()
+
+
+def test_host_in_host_out_batches_in_flight_on_one_index(oracle):
+    """HipKnnIndex.search_begin_pinned: cgv_search_begin_f32_dev on the device aliases of pinned host buffers - the same work
+    as cgv_search_f32 (pinned batch read in place over PCIe, results written in place), max_in_flight batches deep; a query
+    that needs the exact scan is rewritten in place by the batch's end."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(31)
+    n, d, nq, k = 30_000, 96, 270, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[12_000:12_050] = rows[5] * (1 + 1e-4 * rng.standard_normal((50, 1)).astype(np.float32))
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        qs = [rng.standard_normal((nq, d)).astype(np.float32) for _ in range(5)]
+        qs[3][7] = rows[5]
+        want = [oracle.batch_top_k(q, rows, k, dtype=1) for q in qs]
+        depth = ix.max_in_flight
+        qp = [torch.from_numpy(q).pin_memory() for q in qs]
+        outs = [(torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory())
+                for _ in range(len(qs))]
+        pend = []
+        for i in range(len(qs)):
+            if len(pend) == depth:
+                pend.pop(0).wait()
+            pend.append(ix.search_begin_pinned(qp[i], k, outs[i]))
+        for p in pend:
+            p.wait()
+        for i in range(len(qs)):
+            assert np.array_equal(outs[i][0].numpy().view(np.uint64), want[i][0]), i
+            assert np.array_equal(outs[i][1].numpy(), want[i][1]), i
+        assert ix.stats()["fallback_queries"] >= 1
+        with pytest.raises(m.CgvError):
+            ix.search_begin_pinned(torch.from_numpy(qs[0]), k, outs[0])   # pageable memory is refused
+    finally:
+        ix.close()

@@ -193,11 +193,14 @@ def test_sharded_device_exchange_single_process(oracle, monkeypatch):
         peer["rec"] = m.cgvec.pack_topk(pi, ps)
         sk = m.ShardedKnn(shards[0], rank=0, world=2)
         idx, sc = sk.search(qd, k)
-        pend = sk.search_begin(qd, k)                # pipelined form
-        idx2, sc2 = pend.wait()
+        b1 = sk.step_packed_begin(qd, k)             # the join-free packed form, two batches in flight
+        b2 = sk.step_packed_begin(qd, k)
+        idx2, sc2 = sk.step_packed_end(b1)
+        idx3, sc3 = sk.step_packed_end(b2)
         ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
         assert np.array_equal(idx.cpu().numpy().view(np.uint64), ri) and np.array_equal(sc.cpu().numpy(), rs)
-        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2) and torch.equal(idx, idx3) and torch.equal(sc, sc3)
+        assert sk.redo_batches == 0
     finally:
         for ix in shards:
             ix.close()

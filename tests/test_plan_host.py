@@ -53,10 +53,11 @@ def test_rccl_loader_failure_is_reported_not_fatal():
     code = (
         "import ctypes as C, importlib, sys; sys.path.insert(0, %r)\n"
         "m = importlib.import_module('codegraph-rust_amd'); L = m.cgvec.lib()\n"
+        "assert L.cgv_debug_rccl_lib_(b'/nonexistent/librccl-missing.so') == 1\n"
         "buf = C.create_string_buffer(512)\n"
         "ok = L.cgv_debug_rccl_probe_(buf, 512); print(ok, buf.value.decode())\n"
         "ok2 = L.cgv_debug_rccl_probe_(buf, 512); print(ok2, buf.value.decode())\n" % ROOT)
-    env = dict(os.environ, CGV_RCCL_LIB="/nonexistent/librccl-missing.so")
+    env = dict(os.environ)   # (the library reads nothing from the environment: the name is set through the internal setter)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()

@@ -38,14 +38,6 @@ class _OracleShard:
                 idx[i], sc[i] = np.uint64(2**64 - 1), -np.inf
         return torch.from_numpy(idx.view(np.int64)), torch.from_numpy(sc)
 
-    def search_begin(self, queries, k):   # same shape as HipKnnIndex.search_begin -> PendingSearch
-        outer = self
-
-        class _P:
-            def wait(self_inner):
-                return outer.search(queries, k)
-        return _P()
-
 
 def _oracle_merge(g_idx, g_score):
     from oracle import oracle as o
@@ -73,13 +65,6 @@ def _worker(rank, world, port, n, d, nq, k, out):
     lo, hi = m.shard_range(n, rank, world)
     sh = m.ShardedKnn(_OracleShard(rows[lo:hi], lo), merge=_oracle_merge)
     idx, sc = sh.search(torch.from_numpy(queries), k)
-    # the pipelined form bench.py drives (two batches begun before the first is awaited)
-    p1 = sh.search_begin(torch.from_numpy(queries), k)
-    p2 = sh.search_begin(torch.from_numpy(queries[::-1].copy()), k)
-    i1, s1 = p1.wait()
-    i2, s2 = p2.wait()
-    assert torch.equal(i1, idx) and torch.equal(s1, sc)
-    assert torch.equal(i2, torch.flip(idx, dims=[0])) and torch.equal(s2, torch.flip(sc, dims=[0]))
     if rank == 0:
         np.save(out + ".idx.npy", idx.numpy().view(np.uint64))
         np.save(out + ".sc.npy", sc.numpy())
@@ -118,31 +103,35 @@ class _PackedOracleShard(_OracleShard):
     """search_packed_begin / search_packed_end of HipKnnIndex on the CPU: the first packing marks `unproven` queries
     PROVISIONAL (as the device does for queries whose guarantee check failed), end() replaces them with final records."""
 
-    def __init__(self, rows, base, unproven=()):
+    def __init__(self, rows, base, unproven=(), fail_end=False):
         super().__init__(rows, base)
-        self.unproven, self.begun, self.ended = tuple(unproven), 0, 0
+        self.unproven, self.begun, self.ended = tuple(unproven), 0, 0   # `unproven` applies to the batches begun from now on
+        self.fail_end = fail_end          # search_packed_end raises (an error on ONE rank only) - after marking its records final
+        self._final = {}
 
     def search_packed_begin(self, queries, k, rec):
         from importlib import import_module
         sp = import_module("codegraph-rust_amd.sharded")
         idx, sc = self.search(queries, k)
-        self._final = (idx.numpy().view(np.uint64), sc.numpy(), rec)
+        self.begun += 1
+        fin = (idx.numpy().view(np.uint64), sc.numpy(), rec, self.unproven)
+        self._final[self.begun] = fin
         prov = np.zeros(queries.shape[0], dtype=bool)
         prov[list(self.unproven)] = True
-        garbage = self._final[0].copy()
+        garbage = fin[0].copy()
         garbage[prov] = np.uint64(7)                      # what an unproven query holds before the exact scan: not the answer
-        rec.copy_(torch.from_numpy(sp.pack_records_host(garbage, self._final[1], prov)))
-        self.begun += 1
+        rec.copy_(torch.from_numpy(sp.pack_records_host(garbage, fin[1], prov)))
         return self.begun
 
     def search_packed_end(self, ticket):
         from importlib import import_module
         sp = import_module("codegraph-rust_amd.sharded")
-        assert ticket == self.begun
+        i, s_, rec, unproven = self._final.pop(ticket)    # (tickets may be ended in any order; each exactly once)
         self.ended += 1
-        if not self.unproven:
+        if self.fail_end:
+            raise RuntimeError("exact rescan failed on this rank")
+        if not unproven:
             return False
-        i, s_, rec = self._final
         rec.copy_(torch.from_numpy(sp.pack_records_host(i, s_)))
         return True
 
@@ -169,6 +158,40 @@ def _packed_worker(rank, world, port, n, d, nq, k, out):
     r = shaky.step_packed(queries, k, out=(out_i, out_s))
     assert r[0] is out_i and shaky.redo_batches == 1, (rank, shaky.redo_batches)
     assert torch.equal(out_i, i1) and torch.equal(out_s, s1)
+    # ---- batches in flight (round 5): begin, begin, begin, end, end, end on every rank; the MIDDLE batch carries rank 1's
+    # provisional queries, so its redo exchange is posted (by both ranks) while batch 3 is still in flight, after batch 3's
+    # first exchange - the collectives stay matched because every rank ends its batches in the same order
+    piped = m.ShardedKnn(_PackedOracleShard(rows[lo:hi], lo))
+    q_rev = torch.flip(queries, dims=[0]).contiguous()
+    b1 = piped.step_packed_begin(queries, k)
+    piped.local.unproven = (1, 4) if rank == 1 else ()
+    b2 = piped.step_packed_begin(q_rev, k)
+    piped.local.unproven = ()
+    b3 = piped.step_packed_begin(queries, k)
+    try:
+        piped.step_packed_begin(queries, k)
+        raise AssertionError("a fourth batch in flight must be refused")
+    except RuntimeError as e:
+        assert "in flight" in str(e)
+    r1 = piped.step_packed_end(b1)
+    assert piped.redo_batches == 0
+    r2 = piped.step_packed_end(b2)
+    assert piped.redo_batches == 1, (rank, piped.redo_batches)
+    r3 = piped.step_packed_end(b3)
+    assert piped.redo_batches == 1 and piped.local.begun == 3 and piped.local.ended == 3
+    assert torch.equal(r1[0], i1) and torch.equal(r1[1], s1) and torch.equal(r3[0], i1) and torch.equal(r3[1], s1)
+    assert torch.equal(r2[0], torch.flip(i1, dims=[0])) and torch.equal(r2[1], torch.flip(s1, dims=[0]))
+    # ---- a search that fails at its end on ONE rank only: rank 1's records are provisional and its end raises;
+    # rank 0 must not hang in the redo all-gather - both ranks run it, rank 1 re-raises its error, rank 0 reports records that
+    # stayed provisional; the process group is still usable afterwards
+    bad = m.ShardedKnn(_PackedOracleShard(rows[lo:hi], lo, unproven=(2,) if rank == 1 else (), fail_end=(rank == 1)))
+    try:
+        bad.step_packed(queries, k)
+        raise AssertionError("the failed batch must raise on every rank")
+    except RuntimeError as e:
+        assert ("exact rescan failed" in str(e)) if rank == 1 else ("still provisional" in str(e)), (rank, str(e))
+    i9, s9 = clean.step_packed(queries, k)
+    assert torch.equal(i9, i1) and torch.equal(s9, s1)
     # and the packed step agrees with the unpacked exchange of the same shards
     i0, s0 = m.ShardedKnn(_OracleShard(rows[lo:hi], lo), merge=_oracle_merge).search(queries, k)
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
