@@ -451,6 +451,14 @@ def run(args, wd, world, rank, local_rank):
     for i in range(args.warmup):
         step(i)
     wd.kick("warm-up done")
+    # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection walks
+    # ~10^6 objects (tens of milliseconds) - one of them inside a 200-step region of 1.4 ms steps showed up as a mean 12 % above
+    # the median (r05 first run: 1.532 vs 1.362 ms; round 4's runs happened not to catch one). Everything allocated so far is
+    # frozen out of the collector's sight; it runs again, explicitly, between the measurements.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     sync_all()
     coarse_ms, coarse_rows, step_ms = [], 0, []
     t0 = time.perf_counter()
@@ -463,6 +471,7 @@ def run(args, wd, world, rank, local_rank):
         coarse_rows = st["coarse_rows"]
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    gc.collect()
     wd.kick("timed steps done")
     ix.set_profiling(2)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step)
     step(0)
@@ -556,11 +565,13 @@ def run(args, wd, world, rank, local_rank):
         run_piped(max(depth, min(args.warmup, 10)))
         wd.kick("pipelined_host warm")
         redo_before = searcher.redo_batches if dist is not None else 0
+        gc.collect()
         sync_all()
         tp = time.perf_counter()
         run_piped(args.pipelined_steps)
         sync_all()
         dtp = max_over_ranks(time.perf_counter() - tp)
+        gc.collect()
         wd.kick("pipelined_host timed")
         # parity of the pipelined batches: the last `depth` batches' host results against a SERIAL step on the same queries
         same = True
@@ -726,6 +737,7 @@ def run(args, wd, world, rank, local_rank):
                        "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
                        "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none"},
             "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
+            "step_ms_percentiles": {p_: round(float(np.percentile(step_ms, p_)), 4) for p_ in (1, 10, 50, 90, 99, 100)},
             "pipelined_host_qps": pipelined_host["queries_per_sec"] if pipelined_host else None,
             "pipelined_host": pipelined_host,
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
@@ -896,6 +908,7 @@ def run(args, wd, world, rank, local_rank):
             result["check"] = {"anchor": "device-exact-scan", "queries": nex, "redo_batches": multi["redo_batches"]}
 
     wd.stop()
+    gc.enable()
     if rank == 0:
         print(json.dumps(result), flush=True)
     ix.close()

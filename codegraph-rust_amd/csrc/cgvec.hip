@@ -172,10 +172,16 @@ struct SearchCtx {
     uint32_t* flags = nullptr;    // device, F_COUNT words
     uint32_t* h_flags = nullptr;  // pinned host mirror
     uint32_t* h_flags_dev = nullptr;  // ... as the device sees it (the last kernel of a search publishes the flags there)
+    // Small pageable batches (the trait-level call: ONE query in a Rust Vec<f32>, results into a Vec): the query goes through
+    // this pinned, device-mapped staging area with a host memcpy and the conversion kernel reads it in place; the last kernel
+    // writes the results into its second half and the host copies them out after the batch's one synchronisation - no
+    // copy-engine operation (H2D + 2 x D2H, ~10-20 us each for a few KB) on the path of a call that takes ~100 us in all
+    char* h_stage = nullptr;      // pinned host: [0, SMALL_Q_BYTES) queries | [SMALL_Q_BYTES, + SMALL_OUT_BYTES) ids, then scores
+    char* h_stage_dev = nullptr;  // ... as the device sees it
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -185,14 +191,17 @@ struct SearchCtx {
     float* out_score = nullptr;
     bool mfma = false, timed_coarse = false;
     bool boot_used = false;  // the search in flight used the fused sample + emit launch (its rendezvous words need clearing)
+    bool top2 = false;       // the search in flight took the small-batch form (COARSE_TOP2: one launch, no thresholds)
     bool rewrote = false;  // search_finish ran the exact scan and rewrote (some of) the outputs after its first sync
+    bool exact_enqueued = false;  // exact-scan-only batch (f32 index, forced exact, large k): the scan was enqueued by
+                                  // search_enqueue itself - ONE host synchronisation per call instead of three
     uint64_t coarse_rows = 0;
     float eps = 0.0f;
     uint32_t kprime = 0;
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace};
+                                &qshadow, &qres, &trace, &floor};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -200,12 +209,13 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace};
+                          &qshadow, &qres, &trace, &floor};
         for (DevBuf* d : bufs) d->release();
     }
 };
 
 constexpr int N_CTX = 3;
+constexpr size_t SMALL_Q_BYTES = 256u << 10, SMALL_OUT_BYTES = 128u << 10;   // SearchCtx::h_stage
 
 struct cgv_index {
     int device = 0;
@@ -240,6 +250,7 @@ struct cgv_index {
     long spin_us = 3000;  // cgv_set_spin_us: how long a search's end polls its stream before it blocks
     bool force_exact = false;
     bool wide_range = false;  // a stored row's magnitude is outside [2^-40, 2^40]: searches take the exact scan (kernels_prep.h)
+    bool last_top2 = false;   // the last finished search took the small-batch form (cgv_debug_last_top2_)
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
     cgv_index() { memset(&st, 0, sizeof(st)); }
@@ -510,6 +521,7 @@ SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t ns
     sa.kprime = kprime;
     sa.n_dense = n_dense;
     sa.tau_only = 0;
+    sa.floor_ord = nullptr;
     sa.trace = nullptr;
     // LDS key capacity: the dense boot stage needs exactly kprime + n_dense; candidate stages get
     // the full 8192 (64 KiB) so that only pathological emission counts overflow into the exact path.
@@ -578,13 +590,24 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
         uint64_t* cur = c->keysA.as<uint64_t>();
         uint64_t* nxt = c->keysB.as<uint64_t>();
         uint32_t nch = nch0;
-        hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch, g), dim3(256), 0, s, sc, (const uint64_t*)nullptr,
-                           (uint32_t)n, K, cur, c->flags + F_NAN);
+        // K <= 64 (every k <= 64: the reference's limits are 10-100): register-resident extraction instead of a 4096-key LDS
+        // bitonic sort per chunk (kernels_select.h) - the chunk reductions are the longest kernels of a single-query call
+        const bool small_k = K <= 64;
+        if (small_k)
+            hipLaunchKernelGGL(topk_chunk_small_kernel, dim3(nch, g), dim3(256), 0, s, sc, (const uint64_t*)nullptr,
+                               (uint32_t)n, K, cur, c->flags + F_NAN);
+        else
+            hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch, g), dim3(256), 0, s, sc, (const uint64_t*)nullptr,
+                               (uint32_t)n, K, cur, c->flags + F_NAN);
         while (nch > 1) {
             const uint32_t M = nch * K;
             const uint32_t nch2 = (M + TOPK_CHUNK - 1) / TOPK_CHUNK;
-            hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch2, g), dim3(256), 0, s, (const float*)nullptr,
-                               (const uint64_t*)cur, M, K, nxt, c->flags + F_NAN);
+            if (small_k)
+                hipLaunchKernelGGL(topk_chunk_small_kernel, dim3(nch2, g), dim3(256), 0, s, (const float*)nullptr,
+                                   (const uint64_t*)cur, M, K, nxt, c->flags + F_NAN);
+            else
+                hipLaunchKernelGGL(topk_chunk_kernel, dim3(nch2, g), dim3(256), 0, s, (const float*)nullptr,
+                                   (const uint64_t*)cur, M, K, nxt, c->flags + F_NAN);
             std::swap(cur, nxt);
             nch = nch2;
         }
@@ -709,6 +732,7 @@ struct Tunables {
     int zero_copy = CGV_ENV_INT("CGV_ZERO_COPY", 3);          // pinned host buffers in place: 1 queries, 2 results
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
+    int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
 };
 Tunables& tun() {
     static Tunables t;
@@ -829,6 +853,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     c->kprime = 0;
     c->published = false;
     c->boot_used = false;
+    c->top2 = false;
+    c->exact_enqueued = false;
     // flag + pacing words: zero after a search that ran to completion (its last kernel resets them), else cleared here
     if (!c->flags_clean) HIPCHK(hipMemsetAsync(c->flags, 0, CTX_FLAG_WORDS * 4, s));
     c->flags_clean = false;
@@ -938,7 +964,31 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.tau_out = c->tau.as<float>();
         a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
         a.kprime = kprime;
-        if (fuse) {
+        a.floor_ord = nullptr;
+        // Small batches (one query tile of <= 64 queries - the trait-level call is ONE query, traits.rs:14): the corpus streams at the
+        // HBM rate whatever happens to the scores, so the staged thresholds (sample launch, tau_kernel, emitting launches, select)
+        // are pure latency. COARSE_TOP2 visits all tiles in ONE launch without a threshold: per-cell top-2 + floor (kernels_coarse.h).
+        constexpr uint32_t TOP2_MAX_NQ = 64;
+        const bool top2 = tun().top2 != 0 && nq <= TOP2_MAX_NQ && kprime <= 64 && p.ntiles > BOOT_TILES && !fuse;
+        c->top2 = top2;
+        uint32_t top2_nsplit = 0;
+        if (top2) {
+            if ((rc = c->floor.ensure((size_t)TOP2_MAX_NQ * 4))) return rc;
+            HIPCHK(hipMemsetAsync(c->floor.p, 0, (size_t)nq * 4, s));
+            a.floor_ord = c->floor.as<uint32_t>();
+            a.j0 = 0;
+            a.cnt = p.ntiles;
+            a.nsplit = std::min<uint32_t>(p.ntiles, nsplit_max);
+            a.pace = nullptr;
+            top2_nsplit = a.nsplit;
+            if (h->profiling) HIPCHK(hipEventRecord(c->ev[1], s));
+            if ((rc = launch_coarse(cdt, COARSE_TOP2, a, a.nsplit, s))) return rc;
+            if (h->profiling) {
+                HIPCHK(hipEventRecord(c->ev[2], s));
+                c->timed_coarse = true;
+                c->coarse_rows = h->n;
+            }
+        } else if (fuse) {
             if ((rc = c->dump.ensure((size_t)nq * nsplit0 * fvals * 4))) return rc;
 
         } else if (p.sample_tiles > 0) {
@@ -978,9 +1028,9 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         }
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
-        uint32_t last_nsplit = 0;
-        uint64_t last_expected = 0;
-        for (size_t st = 0; st < p.counts.size(); ++st) {
+        uint32_t last_nsplit = top2_nsplit;
+        uint64_t last_expected = top2_nsplit;  // (TOP2: <= 8 candidates per (workgroup, query) list; x 8 head room in make_select_args)
+        for (size_t st = 0; st < p.counts.size() && !top2; ++st) {
             const uint32_t cnt = p.counts[st];
             a.j0 = j0;
             a.cnt = cnt;
@@ -1071,7 +1121,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             size_t work = (size_t)rpb * pitch;
             if (fused_final) {
                 size_t sel_lds = 0;
-                const SelectArgs sa = make_select_args(c, nq, nqt, last_nsplit, kprime, nullptr, 0, last_expected, &sel_lds);
+                SelectArgs sa = make_select_args(c, nq, nqt, last_nsplit, kprime, nullptr, 0, last_expected, &sel_lds);
+                sa.floor_ord = top2 ? c->floor.as<uint32_t>() : nullptr;
                 work = (std::max(work, sel_lds) + 15) / 16 * 16;
                 const uint32_t qoff = (uint32_t)work;
                 const size_t lds = work + rowb;
@@ -1101,6 +1152,24 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
                            (uint32_t)F_DONE, nq, c->boot_used ? c->flags + F_COUNT + PACE_WORDS : (uint32_t*)nullptr,
                            c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u);
+        HIPCHK(hipGetLastError());
+    }
+    // Exact-scan-only batches (the reference's own f32 layout: BASELINE config 1, one query per call; forced exact; k beyond the
+    // fast path): the scan goes onto the stream right here. Round 4 waited for the query conversion on the host first, then
+    // enqueued the scan and waited again, then copied the results and waited a third time: 385 us for one query against 10k x
+    // 384 rows, almost none of it device work. (A packed search keeps the old order: its records must be PROVISIONAL until
+    // search_finish has seen the flags - cgv_search_packed_begin_f32_dev.)
+    c->exact_enqueued = false;
+    if (!mfma && !c->on_caller) {
+        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
+        if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, out_idx, out_score, s))) return rc;
+        c->exact_enqueued = true;
+        // flags to the pinned mirror (and cleared for the next search) by a one-wave kernel, as on the MFMA path: no
+        // copy-engine launch behind the scan, no memset in front of the next one
+        c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
+        c->published = true;
+        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
+                           (uint32_t)F_DONE, nq, (uint32_t*)nullptr, 0u);
         HIPCHK(hipGetLastError());
     }
     if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
@@ -1173,7 +1242,9 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         return fail(CGV_ERR_INVALID_ARG, "fp8 index: a query's largest magnitude is outside [2^-48, 2^48]");
     uint32_t nfb = 0;
     float me = 0.0f;
-    if (!c->mfma) {
+    if (!c->mfma && c->exact_enqueued) {
+        // the scan ran behind the query conversion on the same stream: nothing left to do
+    } else if (!c->mfma) {
         c->rewrote = true;
         hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
         if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, c->out_idx, c->out_score, s))) return rc;
@@ -1204,6 +1275,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     h->st.max_observed_err = std::max(h->st.max_observed_err, me);
     h->st.fallback_queries += nfb;
     h->st.last_path = (c->mfma && h->n) ? 1u : 0u;
+    h->last_top2 = c->mfma && c->top2;
     h->st.last_kprime = c->kprime;
     h->st.last_eps = c->eps;
     h->st.last_coarse_ms = coarse_ms;
@@ -1327,10 +1399,14 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "pace")) t.pace = (int)v;
     else if (!strcmp(key, "epi")) t.epi = (int)v;
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
+    else if (!strcmp(key, "top2")) t.top2 = (int)v;
     else return -1;
     return 0;
 }
 #endif  // CGV_ABLATE_BUILD
+
+// internal (tests, scripts): 1 when the last finished search on the handle took the small-batch form (COARSE_TOP2)
+int cgv_debug_last_top2_(cgv_index* h) { return (h && h->last_top2) ? 1 : 0; }
 
 // internal (tests, scripts): the launch plan of a search over n rows with nq queries and k results on a device with
 // n_cu compute units. out[0] = tiles of the sample launch (0: dense boot stage), out[1] = number of emitting
@@ -1401,6 +1477,8 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_flags_dev, c.h_flags, 0);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_stage, SMALL_Q_BYTES + SMALL_OUT_BYTES, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_stage_dev, c.h_stage, 0);
         if (e == hipSuccess) e = hipMemset(c.flags, 0, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) c.flags_clean = true;
     }
@@ -1436,6 +1514,7 @@ int cgv_destroy(cgv_index* h) {
         c.release_all();
         if (c.flags) (void)hipFree(c.flags);
         if (c.h_flags) (void)hipHostFree(c.h_flags);
+        if (c.h_stage) (void)hipHostFree(c.h_stage);
         if (c.dep) (void)hipEventDestroy(c.dep);
         if (c.packed_done) (void)hipEventDestroy(c.packed_done);
         for (int i = 0; i < 4; ++i)
@@ -1898,18 +1977,31 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         const float* qsrc = (tun().zero_copy & 1) ? (const float*)device_alias(queries_host, (size_t)nq * h->D * 4) : nullptr;
         uint64_t* oi = (tun().zero_copy & 2) ? (uint64_t*)device_alias(out_idx_host, (size_t)nq * k * 8) : nullptr;
         float* os = oi ? (float*)device_alias(out_score_host, (size_t)nq * k * 4) : nullptr;
-        const bool direct_out = oi && os;
-        if (!qsrc && (r = c->qstage.ensure((size_t)nq * h->D * 4))) return r;
+        bool direct_out = oi && os;
+        const size_t qbytes = (size_t)nq * h->D * 4, ibytes = (size_t)nq * k * 8, sbytes = (size_t)nq * k * 4;
+        // small pageable buffers: through the context's pinned staging area by host memcpy (SearchCtx::h_stage)
+        const bool small_q = !qsrc && qbytes <= SMALL_Q_BYTES && tun().zero_copy != 0;
+        const bool small_out = !direct_out && ibytes + sbytes <= SMALL_OUT_BYTES && tun().zero_copy != 0;
+        if (small_q) {
+            memcpy(c->h_stage, queries_host, qbytes);
+            qsrc = (const float*)c->h_stage_dev;
+        }
+        if (small_out) {
+            oi = (uint64_t*)(c->h_stage_dev + SMALL_Q_BYTES);
+            os = (float*)(c->h_stage_dev + SMALL_Q_BYTES + ibytes);
+            direct_out = true;   // (for the device: the last kernel writes host memory; the copy to the caller's arrays is below)
+        }
+        if (!qsrc && (r = c->qstage.ensure(qbytes))) return r;
         if (!direct_out) {
-            if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
-            if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
+            if ((r = c->outidx.ensure(ibytes))) return r;
+            if ((r = c->outscore.ensure(sbytes))) return r;
             oi = c->outidx.as<uint64_t>();
             os = c->outscore.as<float>();
         }
         if ((r = order_after_caller(h, c))) return r;
         stamp(0);
         if (!qsrc) {
-            HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, (size_t)nq * h->D * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, qbytes, hipMemcpyHostToDevice, s));
             qsrc = c->qstage.as<float>();
         }
         stamp(1);
@@ -1919,7 +2011,7 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         // MFMA path: the results exist once the enqueued pipeline has run, so their D2H copies ride the same
         // stream and ONE host synchronisation (inside search_finish) covers flags and results; only when the
         // exact scan then rewrote some queries (fallbacks, f32 index) are they copied again.
-        const bool early = c->mfma && !direct_out;
+        const bool early = (c->mfma || c->exact_enqueued) && !direct_out;
         auto copy_out = [&]() -> int {
             HIPCHK(hipMemcpyAsync(out_idx_host, c->outidx.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(out_score_host, c->outscore.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -1932,6 +2024,10 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         if (!direct_out && (!early || c->rewrote)) {
             if ((r = copy_out())) return r;
             HIPCHK(hipStreamSynchronize(s));
+        }
+        if (small_out) {   // (every path through search_finish ends with the stream idle: the staged results are complete)
+            memcpy(out_idx_host, c->h_stage + SMALL_Q_BYTES, ibytes);
+            memcpy(out_score_host, c->h_stage + SMALL_Q_BYTES + ibytes, sbytes);
         }
         return CGV_OK;
     };

@@ -33,6 +33,7 @@ int coarse_attrs_fp8() {
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_EMIT>))) return rc;
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_DUMP>))) return rc;
     if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_SAMPLE>))) return rc;
+    if ((rc = set_lds((const void*)coarse_fp8s_kernel<COARSE_TOP2>))) return rc;
     return CGV_OK;
 }
 
@@ -45,6 +46,12 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
     if (mode == COARSE_SAMPLE) {
         hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_SAMPLE>, dim3(W), dim3(512), lds, s, a);
         return status("coarse_fp8s_kernel (sample)");
+    }
+    if (mode == COARSE_TOP2) {   // small batches (kernels_coarse.h: Top2): the 8-wave kernel, whose epilogue is tile_epilogue
+        if (a.nqt != 1 || a.nq > 64 || !a.floor_ord)
+            return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_TOP2 launched on a shape it does not serve");
+        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_TOP2>, dim3(W), dim3(512), lds, s, a);
+        return status("coarse_fp8s_kernel (top-2 cells)");
     }
     if (mode != COARSE_EMIT) return cgv_set_error_(CGV_ERR_INTERNAL, "fp8 coarse kernels: unknown launch mode");
     // one wave per SIMD (even kc >= 4) or the 8-wave kernel (CGV_COARSE=w8, other kc)

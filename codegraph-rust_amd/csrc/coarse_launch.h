@@ -14,6 +14,8 @@ constexpr int COARSE_DUMP = 1;    // dense [nq][n] coarse scores (debug / guaran
 constexpr int COARSE_SAMPLE = 2;  // per-lane maxima of every 32 x 32 block -> [nq][16 per tile] (first threshold)
 constexpr int COARSE_EMIT_BOOT = 3;  // EMIT whose first tile per workgroup is also the sample: rendezvous, thresholds computed in
                                      // the launch, then emission (bf16 / fp16, K a multiple of 4 chunks, > 1 query tile)
+constexpr int COARSE_TOP2 = 4;    // small batches (nq <= 64, one query tile): no threshold - every cell (workgroup, M-half, lane
+                                  // half) keeps its two best rows per query + the best score it left out (Top2, kernels_coarse.h)
 
 // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
 // (+ for fp8 an 8-deep ring of the tiles' 256 scale exponents)

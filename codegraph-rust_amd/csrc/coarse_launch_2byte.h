@@ -33,6 +33,8 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_DUMP>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_SAMPLE>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 2>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 0>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
@@ -55,6 +57,15 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     if (mode == COARSE_SAMPLE) {
         hipLaunchKernelGGL((coarse_kernel<DT, COARSE_SAMPLE>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (sample)");
+    }
+    if (mode == COARSE_TOP2) {  // small batches: one query tile, every corpus tile read once -> non-temporal corpus stream
+        if (a.nqt != 1 || a.nq > 64 || !a.floor_ord)
+            return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_TOP2 launched on a shape it does not serve");
+        if (a.kc >= 4 && a.kc % 4 == 0)
+            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
+        else
+            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 0>), dim3(W), dim3(512), lds, s, a);
+        return coarse_hip_status("coarse_kernel (top-2 cells)");
     }
     if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (cgvec.hip: can_fuse)
 #ifdef CGV_ABLATE_BUILD

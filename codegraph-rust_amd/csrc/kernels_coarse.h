@@ -107,6 +107,8 @@ struct CoarseArgs {
     float* tau_out;         // [nq] the first thresholds, written by the launch itself
     uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
     uint32_t kprime;        // the threshold is the k'-th largest group maximum
+    // COARSE_TOP2 (small batches, Top2 below)
+    uint32_t* floor_ord;    // [nq] f2ord of the largest coarse score any cell left OUT of its top-2 (atomicMax; zero at launch)
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -284,6 +286,58 @@ __device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, 
     return (tq >= 0.0f) ? tq * mn * (1.0f - 3.8147e-6f) : tq * mx * (1.0f + 3.8147e-6f);
 }
 
+// ---- COARSE_TOP2: threshold-free candidates for SMALL batches (nq <= 64, one query tile) -----------------------------------
+// The reference's trait-level call is ONE query (traits.rs:14 search_similar(&self, &[f32], limit); surreal_store.rs:61-85;
+// caller search.rs:114-117), and a batch of a few queries streams the corpus at the HBM rate whatever the kernel does with the
+// scores - the staged thresholds of the batched path (sample launch, tau_kernel, 1-2 emitting launches, select) are then pure
+// latency: ~45 us of launches that exist only to learn a threshold. Here every lane that owns a query column keeps, over ALL
+// the rows it sees in the launch (its CELL: one (workgroup, M-half of the wave grid, lane half) = 1/1024 of the corpus on a
+// 256-CU part), the two best coarse scores with their rows and `b`, the best score it left out. At the end of the launch the
+// cells' top-2 go to the (workgroup, query) candidate lists and max(b) over the cells to floor_ord[q]. final_kernel takes the
+// top-k' of the <= 2048 candidates of a query and checks the usual guarantee against tau = max(k'-th best candidate,
+// floor): a row outside the candidates is either in no cell's top-2 (coarse <= its cell's b <= floor) or a candidate below the
+// k'-th. Three of a query's top-(k + few) rows in ONE of 1024 cells (probability ~C(11,3) / 1024^2 = 1.6e-4 for k = 10 on
+// data without structure; a run of near-duplicates does it on purpose) raise the floor above the k-th exact score: the check
+// fails and the query is answered by the exact scan, as always - never a wrong answer. ONE launch, no threshold, no sample.
+struct Top2 {
+    float s1, s2, b;      // best, second best, best score left out (coarse / invn_q for cosine: the query's own positive factor
+    uint32_t r1, r2;      // is applied when the cell is flushed); rows of s1, s2
+};
+__device__ __forceinline__ void top2_insert(Top2& t, float v, uint32_t row) {
+    const bool g1 = v > t.s1, g2 = v > t.s2;    // (NaN: neither - an unused query column's garbage never enters)
+    t.b = fmaxf(t.b, g2 ? t.s2 : v);
+    t.r2 = g1 ? t.r1 : (g2 ? row : t.r2);
+    t.s2 = g1 ? t.s1 : (g2 ? v : t.s2);
+    t.r1 = g1 ? row : t.r1;
+    t.s1 = g1 ? v : t.s1;
+}
+// the cells of this wave -> candidate lists (through the per-query LDS counters, like block_hits) and the floor words
+template <int BN, int NB>
+__device__ inline void top2_flush(const CoarseArgs& a, const Top2 (&t)[NB], const float (&invq)[NB], int wn, int lane, uint32_t g,
+                                  uint32_t qt, uint32_t* cntq) {
+    if (wn != 0) return;   // (uniform: query columns 0..63 live in the waves with wn == 0)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t ql = (uint32_t)(nb * 32 + (lane & 31)), q = qt * (uint32_t)BN + ql;
+        if (q >= a.nq) continue;
+        const float iq = (a.metric == METRIC_DOT) ? 1.0f : invq[nb];
+        const float sv[2] = {t[nb].s1, t[nb].s2};
+        const uint32_t rv[2] = {t[nb].r1, t[nb].r2};
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (sv[e] > -INFINITY) {
+                const float sc = (a.metric == METRIC_DOT) ? sv[e] : sv[e] * iq;   // = (acc * invn_c) * invn_q, block_hits' order
+                const uint32_t p = lds_inc_rtn(&cntq[ql]);
+                if (p < CAND_CAPS) a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(sc), rv[e]);
+                else a.overflow[q] = 1u;
+            }
+        if (t[nb].b > -INFINITY) {
+            const float fb = (a.metric == METRIC_DOT) ? t[nb].b : t[nb].b * iq;   // monotone in b: bounds every left-out row
+            atomicMax(a.floor_ord + q, f2ord(fb + 0.0f));
+        }
+    }
+}
+
 // Fused top-k' epilogue of one corpus tile (shared by the coarse kernel variants).
 // Fast filter, BRANCH-FREE over all blocks of the wave tile: the maximum of each block's 16 scores (8 VALU) against a
 // conservative raw-accumulator threshold, the verdicts collected in a per-lane bit mask; one branch for the whole
@@ -291,19 +345,59 @@ __device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, 
 // tile, each a dependent chain with nothing to overlap; measured 43 % of the one-wave-per-SIMD fp8 kernel.)
 // The accumulators are NOT cleared here: the first k-step of the next tile starts from a zero C operand (free in
 // the MFMA encoding).
-template <int BM, int BN, int WTM, int WTN, int MB, int NB, int MODE /* 0 emit, 1 dump, 2 sample */, bool ACC_AGPR = false>
+template <int BM, int BN, int WTM, int WTN, int MB, int NB, int MODE /* 0 emit, 1 dump, 2 sample, 4 top-2 */, bool ACC_AGPR = false>
 __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], uint32_t tile, int wm,
                                               int wn, int lane, uint32_t g, uint32_t qt, const float (&tq)[NB],
                                               const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
                                               const float* invn_s /* LDS: inverse norms of this tile's 256 rows */,
                                               const float* stat_s /* LDS: 8 block-min + 8 block-max norms */,
-                                              uint32_t seq = 0 /* SAMPLE: position of the tile in the sample */) {
+                                              uint32_t seq = 0 /* SAMPLE: position of the tile in the sample */,
+                                              Top2* t2 = nullptr /* TOP2: the lane's NB cells */) {
     const uint32_t trow0 = tile * (uint32_t)BM + (uint32_t)(wm * WTM);
     // Opaque copy of the lane id: stops LICM from hoisting per-register row offsets out of the K loop
     // (it cost ~50 VGPRs in the first build).
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     lane = lane_o;
+    if (MODE == 4) {
+        // TOP2 (small batches): the waves that hold query columns 0..63 fold the tile into their cells. Fast skip per 32 x 32
+        // block: no lane's raw maximum reaches its cell's b (conservative raw-accumulator form of b, block_threshold) - after
+        // a few tiles that is almost every block of a batch of few queries (unused columns carry b = +inf).
+        if (wn != 0) return;   // uniform per wave
+        float mn[MB], mx[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            mn[mb] = stat_s[(wm * WTM) / 32 + mb];
+            mx[mb] = stat_s[8 + (wm * WTM) / 32 + mb];
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // vmax3 (asm) reads MFMA results: hipcc pads nothing for asm
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            Top2 st = t2[nb];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const bool blk_valid = trow0 + (uint32_t)(mb * 32) < a.n;  // uniform
+                const float t = block_threshold(a, st.b, mn[mb], mx[mb]);
+                if (blk_valid && __ballot(block_max(acc[mb][nb]) > t) != 0ull) {
+                    const uint32_t rl0 = (uint32_t)(wm * WTM + mb * 32) + 4u * (uint32_t)(lane >> 5);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        // registers 4 g4 .. 4 g4 + 3 of a block are 4 CONSECUTIVE corpus rows: one 16-byte LDS read of their norms
+                        const f32x4_t iv = *(const f32x4_t*)(invn_s + rl0 + 8 * g4);
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const uint32_t row = tile * (uint32_t)BM + rl0 + (uint32_t)(8 * g4 + r4);
+                            float v = acc[mb][nb][4 * g4 + r4];
+                            if (a.metric != METRIC_DOT) v = v * iv[r4];
+                            top2_insert(st, row < a.n ? v : -INFINITY, row);
+                        }
+                    }
+                }
+            }
+            t2[nb] = st;
+        }
+        return;
+    }
     if (MODE == 2) {
         // SAMPLE: no threshold exists yet. Every lane reduces each of its 32 x 32 blocks to the
         // maximum of its 16 coarse scores (16 distinct corpus rows); the k'-th largest of all the group maxima a query
@@ -552,7 +646,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     for (int nb = 0; nb < NB; ++nb) {
         const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
         const bool valid = q < a.nq;
-        const float tau = (MODE == 3) ? INFINITY : (valid ? a.tau[q] : INFINITY);  // MODE 3: no threshold yet (boot_block)
+        const float tau = (MODE == 3 || MODE == 4) ? INFINITY : (valid ? a.tau[q] : INFINITY);  // MODE 3: no threshold yet (boot_block); 4: none at all
         const float iq = (a.metric == METRIC_DOT) ? 1.0f : (valid ? a.invn_q[q] : 0.0f);
         tauv[nb] = tau;
         invq[nb] = iq;
@@ -570,6 +664,16 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) thr[mb][nb] = INFINITY;
+    }
+
+    // COARSE_TOP2: the lane's cells (one per N-block of the wave tile); unused query columns never take part (b = +inf)
+    Top2 t2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const bool active = MODE == 4 && wn == 0 && qt * (uint32_t)BN + (uint32_t)(nb * 32 + (lane & 31)) < a.nq;
+        t2[nb].s1 = t2[nb].s2 = -INFINITY;
+        t2[nb].b = active ? -INFINITY : INFINITY;
+        t2[nb].r1 = t2[nb].r2 = 0xFFFFFFFFu;
     }
 
     // uniform by construction; readfirstlane makes it provable (the 64-bit divisions run on the VALU and would
@@ -987,7 +1091,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         else                                                                                                       \
             tile_epilogue<BM, BN, WTM, WTN, MB, NB, (MODE == 3 ? 0 : MODE)>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,  \
                                                           invn_s + ((SEQ) & (NINV - 1)) * 256,                     \
-                                                          stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ)); \
+                                                          stat_s + ((SEQ) & (NINV - 1)) * 16, a.j0 + jlo + (SEQ), t2); \
     }
 
     // Tile-structured: [first stage of a tile: zero-C MFMAs] then KC-1 ordinary stages; at a tile
@@ -1123,6 +1227,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #undef CGV_BDMA
 #undef CGV_BDMA_A
 
+    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wn, lane, g, qt, cntq);
     __syncthreads();
     if (tid == 0) pace_done(pace);
     for (int i = tid; i < BN; i += NT) {

@@ -68,11 +68,20 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     for (int nb = 0; nb < NB; ++nb) {
         const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
         const bool valid = q < a.nq;
-        const float tau = valid ? a.tau[q] : INFINITY;
+        const float tau = MODE == 4 ? INFINITY : (valid ? a.tau[q] : INFINITY);   // COARSE_TOP2: no threshold at all
         const float iq = valid ? a.invn_q[q] : 0.0f;  // fp8 is cosine-only
         tauv[nb] = tau;
         invq[nb] = iq;
         tq[nb] = (tau == -INFINITY) ? -INFINITY : (iq == 0.0f ? INFINITY : tau / iq);
+    }
+
+    Top2 t2[NB];   // COARSE_TOP2: the lane's cells (kernels_coarse.h)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const bool active = MODE == 4 && wn == 0 && qt * (uint32_t)BN + (uint32_t)(nb * 32 + (lane & 31)) < a.nq;
+        t2[nb].s1 = t2[nb].s2 = -INFINITY;
+        t2[nb].b = active ? -INFINITY : INFINITY;
+        t2[nb].r1 = t2[nb].r2 = 0xFFFFFFFFu;
     }
 
     const uint32_t jlo = (uint32_t)(((uint64_t)split * a.cnt) / a.nsplit);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     {                                                                                                          \
         tile_epilogue<BM, BN, WTM, WTN, MB, NB, MODE>(a, acc, ptile, wm, wn, lane, g, qt, tq, tauv, invq, cntq, \
                                                       invn_s + (pj & (NINV - 1)) * 256,                        \
-                                                      stat_s + (pj & (NINV - 1)) * 16, a.j0 + jlo + pj);       \
+                                                      stat_s + (pj & (NINV - 1)) * 16, a.j0 + jlo + pj, t2);   \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)    \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;                              \
     }
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
 #undef F8_LOAD_A01
 #undef F8_LOAD
 
+    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wn, lane, g, qt, cntq);
     __syncthreads();
     for (int i = tid; i < BN; i += NT) {
         const uint32_t c = cntq[i];

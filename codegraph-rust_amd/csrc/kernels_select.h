@@ -20,6 +20,7 @@ struct SelectArgs {
     uint32_t* overflow;        // [nq]
     uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
     uint32_t tau_only;         // dense scores of a SAMPLE of the corpus: publish tau, keep no candidates
+    const uint32_t* floor_ord; // COARSE_TOP2: [nq] f2ord of the best coarse score left out of the candidate lists (0: none), or NULL
     uint64_t* trace;           // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps of the kernel's phases, or NULL
 };
 
@@ -245,6 +246,38 @@ __device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, u
     merge4(part, keep, outk, tid);
 }
 
+// The exact scan's chunk reduction for K <= 64 (kernels_exact.h: topk_chunk_kernel sorts all 4096 keys of a chunk with an
+// LDS bitonic network - 78 barrier rounds, ~25 us - to keep 16 of them): register-resident extraction instead (every lane
+// sorts its <= 16 keys in registers, K rounds of wave maximum, a 4-way merge) - the same keys, the same total order (keys are
+// unique), ~3x shorter on the latency-bound single-query path (BASELINE config 1: 10k x 384 f32, one query per call).
+// Level 0: chunk of f32 scores -> top-K keys; level > 0: chunk of keys -> top-K keys. grid = (nchunks, nql), out[qi][chunk][K].
+__global__ __launch_bounds__(256) void topk_chunk_small_kernel(const float* __restrict__ scores, const uint64_t* __restrict__ in_keys,
+                                                               uint32_t M, uint32_t K, uint64_t* __restrict__ out,
+                                                               uint32_t* __restrict__ nan_flag) {
+    __shared__ uint64_t part[4 * 64];
+    __shared__ uint64_t outk[64];
+    const int tid = threadIdx.x;
+    const uint32_t chunk = blockIdx.x, qi = blockIdx.y, nchunks = gridDim.x;
+    const uint64_t base = (uint64_t)chunk * 4096u;
+    const uint32_t cnt = (uint32_t)((M - base) < 4096u ? (M - base) : 4096u);
+    const uint32_t keep = K < cnt ? K : cnt;
+    auto load = [&](uint32_t e) -> uint64_t {
+        const uint64_t ge = base + e;
+        if (scores) {
+            const float sc = scores[(uint64_t)qi * M + ge];
+            if (sc != sc) *nan_flag = 1u;
+            return make_key(sc, (uint32_t)ge);
+        }
+        return in_keys[(uint64_t)qi * M + ge];
+    };
+    if (cnt <= 2048u)
+        extract_regs<8>(load, cnt, keep, part, tid);
+    else
+        extract_regs<16>(load, cnt, keep, part, tid);
+    merge4(part, keep, outk, tid);
+    for (uint32_t j = tid; j < K; j += 256) out[((uint64_t)qi * nchunks + chunk) * K + j] = j < keep ? outk[j] : 0ull;
+}
+
 // One workgroup (256 threads) per query: merge best[q] with the nsplit candidate
 // sub-lists written by the last coarse launch (or with the dense boot scores), keep the
 // top-k', publish tau[q] = the k'-th best coarse score seen so far (a valid lower bound of
@@ -431,7 +464,9 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         uint32_t m = a.k;
         while (m < nb && key_score(ckeys[m]) >= cut) ++m;  // uniform: every thread walks the same short list
         if (m < nb) {
-            tau_eff = key_score(ckeys[m]);
+            // (the first skipped candidate bounds the skipped ones; `tau` everything outside the list - it is the larger of the
+            // two only on the COARSE_TOP2 path, where a cell's left-out row may beat the list's tail)
+            tau_eff = fmaxf(tau, key_score(ckeys[m]));
             nb = m;
         }
     }
@@ -578,7 +613,12 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     phase_stamp(a.trace, q, 2, tid);
     for (uint32_t i = tid; i < keep; i += 256) ckeys[i] = outk[i];
     // fewer than k' keys: nothing is cut here, but the coarse launches dropped every row at or below THEIR threshold
-    const float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
+    float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
+    if (sa.floor_ord) {   // COARSE_TOP2: rows no cell kept score at most the floor; the lists hold no threshold of their own
+        if (M < sa.kprime) tau = -INFINITY;
+        const uint32_t fo = sa.floor_ord[q];
+        if (fo != 0u) tau = fmaxf(tau, ord2f(fo));
+    }
     const bool overflow = trunc || sa.overflow[q] != 0;
     __syncthreads();
     rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);

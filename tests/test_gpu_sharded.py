@@ -266,10 +266,10 @@ def _rank_main(rank, world, port, n, d, nq, k, out):
     sh = m.ShardedKnn(ix, rank=rank, world=world, force_collective=True)   # device pack -> all_gather_into_tensor -> device merge
     qd = torch.from_numpy(q).cuda()
     idx, sc = sh.search(qd, k)
-    p1 = sh.search_begin(qd, k)
-    p2 = sh.search_begin(torch.flip(qd, dims=[0]), k)
-    i1, s1 = p1.wait()
-    i2, s2 = p2.wait()
+    p1 = sh.step_packed_begin(qd, k)                                   # two join-free batches in flight (round 5): every rank
+    p2 = sh.step_packed_begin(torch.flip(qd, dims=[0]).contiguous(), k)   # begins and ends them in the same order
+    i1, s1 = sh.step_packed_end(p1)
+    i2, s2 = sh.step_packed_end(p2)
     assert torch.equal(i1, idx) and torch.equal(s1, sc)
     assert torch.equal(i2, torch.flip(idx, dims=[0])) and torch.equal(s2, torch.flip(sc, dims=[0]))
     # the join-free step the bench drives (round 4): pinned batch in place, records packed on the library's stream, RCCL

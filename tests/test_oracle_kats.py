@@ -300,8 +300,10 @@ def test_fp8_row_scaling(oracle):
 def test_scalar_host_metric_of_the_oracle(oracle):
     """Oracle metric 3 (COSINE_SCALAR) = cosine_similarity_scalar (simd_ops.rs:257-278) for every length: what
     parallel_top_k_search computes on a host without AVX2 (adaptive_cosine_similarity :291-294). Pinned by an independent
-    pure-Python restatement with one f32 rounding per operation (no FMA), at lengths on both sides of the AVX2 switch, and
-    by the reference's own scalar KAT (simd_ops.rs:462-472: [1,2,3] . [4,5,6] = 0.974631...)."""
+    pure-Python restatement with one f32 rounding per operation (no FMA), at lengths on both sides of the AVX2 switch. The
+    only vector the reference itself holds for the scalar kernel is the input pair of test_simd_cosine_similarity
+    (simd_ops.rs:429-447: a = [1..8], b = [8..1], scalar vs AVX2 within 1e-6; the true value is 120/204); the
+    [1,2,3] . [4,5,6] value below is a hand-computed one (32 / sqrt(14 * 77)), NOT a reference vector."""
     f32 = np.float32
 
     def scalar(a, b):
@@ -313,7 +315,11 @@ def test_scalar_host_metric_of_the_oracle(oracle):
         npd = f32(np.sqrt(f32(na * nb)))
         return f32(0.0) if npd == 0 else f32(dp / npd)
 
-    assert abs(float(oracle.cosine_scalar(np.array([1, 2, 3], f32), np.array([4, 5, 6], f32))) - 0.974631846) < 1e-6
+    a8, b8 = np.arange(1, 9, dtype=f32), np.arange(8, 0, -1, dtype=f32)          # the reference's inputs (simd_ops.rs:431-432)
+    assert abs(float(oracle.cosine_scalar(a8, b8)) - 120.0 / 204.0) < 1e-6
+    assert abs(float(oracle.cosine_scalar(a8, b8)) - float(oracle.cosine_avx2(a8, b8))) <= 1e-6    # its assertion (:441)
+    assert oracle.cosine_scalar(a8, b8) == scalar(a8, b8)
+    assert abs(float(oracle.cosine_scalar(np.array([1, 2, 3], f32), np.array([4, 5, 6], f32))) - 0.974631846) < 1e-6   # hand-computed
     rng = np.random.default_rng(12)
     for d in (3, 31, 32, 33, 100, 768):
         rows = rng.standard_normal((40, d)).astype(f32)
