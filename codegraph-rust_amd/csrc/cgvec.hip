@@ -181,7 +181,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -201,7 +201,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -209,7 +209,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -717,6 +717,9 @@ double env_double(const char* name, double dflt) {
 #define CGV_ENV_INT(NAME, DFLT) (DFLT)
 #define CGV_ENV_DBL(NAME, DFLT) (DFLT)
 #endif
+#ifndef CGV_LADDER_DEFAULT
+#define CGV_LADDER_DEFAULT 0
+#endif
 struct Tunables {
 #ifdef CGV_ABLATE_BUILD
     int plan_legacy = getenv("CGV_PLAN") && !strcmp(getenv("CGV_PLAN"), "legacy");
@@ -733,6 +736,8 @@ struct Tunables {
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
+    int ladder = CGV_ENV_INT("CGV_LADDER", CGV_LADDER_DEFAULT);  // threshold ladder (kernels_coarse.h): 0 = staged launches; 1 = ladder inside the
+                                                              // planned launches; 2 = ladder + ONE emitting launch behind the sample
 };
 Tunables& tun() {
     static Tunables t;
@@ -756,12 +761,48 @@ constexpr uint32_t SAMPLE_TILES_MAX = 256;  // tau_kernel takes <= 1024 group ma
                                            // 8 up to 128, 4 up to 256 (sample_vals_of)
 uint32_t sample_vals_of(uint32_t sample_tiles) { return sample_tiles <= 64 ? 16u : (sample_tiles <= 128 ? 8u : 4u); }
 constexpr uint32_t LIST_TARGET = 32;
-StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, uint32_t nsplit_max) {
+// Inverse of the standard normal distribution function (Acklam's rational approximation, |error| < 1.2e-9): the expected
+// position of the final k'-th best score relative to the sample's order statistics (plan_ladder_scale).
+double inv_norm_cdf(double p) {
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02,
+                               -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01,
+                               -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00,
+                               4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p <= 0.0) return -1e300;
+    if (p >= 1.0) return 1e300;
+    if (p < 0.02425) {
+        const double q = sqrt(-2.0 * log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    }
+    if (p > 1.0 - 0.02425) {
+        const double q = sqrt(-2.0 * log(1.0 - p));
+        return -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    }
+    const double q = p - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+}
+
+// Threshold ladder (kernels_coarse.h): delta = scale x (sample value at rank hi_rank - sample value at rank k'), four levels.
+// Under a normal tail the score at tail probability p sits at z(p) sigmas; the sample of S rows shows z(hi/S) and z(k'/S), the
+// final k'-th best of N rows is expected at z(k'/N): the ladder spans 1.25 x that distance in 4 levels. 0 = no ladder.
+float plan_ladder_scale(double S_rows, double N_rows, uint32_t kprime, uint32_t hi_rank) {
+    if (!(S_rows > 4.0 * kprime) || !(N_rows > S_rows) || hi_rank == 0 || hi_rank >= kprime) return 0.0f;
+    const double zk = -inv_norm_cdf((double)kprime / S_rows), zh = -inv_norm_cdf((double)hi_rank / S_rows),
+                 zn = -inv_norm_cdf((double)kprime / N_rows);
+    if (!(zh > zk) || !(zn > zk)) return 0.0f;
+    return (float)(1.25 * (zn - zk) / (zh - zk) / 4.0);
+}
+
+StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, uint32_t nsplit_max, int force_m = 0) {
     const Tunables& t = tun();
     StagePlan p;
     p.ntiles = (uint32_t)((n + BM - 1) / BM);
     if (t.plan_legacy || p.ntiles <= BOOT_TILES) return plan_stages_legacy(n, kprime, nsplit_max);
-    const int forced_s = t.sample_tiles, forced_m = t.plan_launches;
+    const int forced_s = t.sample_tiles, forced_m = force_m > 0 ? force_m : t.plan_launches;
     const double hit_us = t.hit_us, launch_us = t.launch_us;
     // one pass of the chip: one tile per CU, but never more than 1/8 of the corpus (it is scored again by the launches)
     uint32_t S = std::min<uint32_t>(std::max<uint32_t>(n_cu / std::max<uint32_t>(nqt, 1u), 8u), SAMPLE_TILES_MAX);
@@ -903,9 +944,11 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     if (mfma) {
         const uint32_t nqt = (nq + BN - 1) / BN;
         const uint32_t nsplit_max = std::max<uint32_t>(1u, (uint32_t)h->n_cu / nqt);
-        const StagePlan p = plan_stages(h->n, kprime, nqt, (uint32_t)h->n_cu, nsplit_max);
-        const uint32_t Wmax = nqt * nsplit_max;
         const int cdt = h->shadow ? CGV_DTYPE_BF16 : h->dtype;  // dtype the coarse pass runs in
+        // threshold ladder (kernels_coarse.h): the bf16 / fp16 emitting kernel tightens its thresholds inside the launch
+        const int lad_mode = (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) ? tun().ladder : 0;
+        const StagePlan p = plan_stages(h->n, kprime, nqt, (uint32_t)h->n_cu, nsplit_max, lad_mode >= 2 ? 1 : 0);
+        const uint32_t Wmax = nqt * nsplit_max;
         if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->nbest.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
@@ -965,6 +1008,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
         a.kprime = kprime;
         a.floor_ord = nullptr;
+        a.lad = nullptr;
+        a.ladc = nullptr;
         // Small batches (one query tile of <= 64 queries - the trait-level call is ONE query, traits.rs:14): the corpus streams at the
         // HBM rate whatever happens to the scores, so the staged thresholds (sample launch, tau_kernel, emitting launches, select)
         // are pure latency. COARSE_TOP2 visits all tiles in ONE launch without a threshold: per-cell top-2 + floor (kernels_coarse.h).
@@ -1005,8 +1050,19 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             sa.cnt = p.sample_tiles;
             sa.nsplit = std::min<uint32_t>(p.sample_tiles, nsplit_max);
             if ((rc = launch_coarse(cdt, COARSE_SAMPLE, sa, nqt * sa.nsplit, s))) return rc;
+            const uint32_t hi_rank = std::max<uint32_t>(1u, kprime / 4u);
+            const float lad_scale = lad_mode ? plan_ladder_scale((double)p.sample_tiles * BM, (double)p.ntiles * BM, kprime, hi_rank) : 0.0f;
+            // (the ladder lives in the ring-unrolled instantiations: K a multiple of 4 chunks - every headline shape)
+            const bool lad_on = lad_mode != 0 && lad_scale > 0.0f && a.kc >= 4 && a.kc % 4 == 0 && (a.epi & 25u) == 1u;
+            if (lad_on) {
+                if ((rc = c->lad.ensure((size_t)nqt * BN * 8))) return rc;
+                if ((rc = c->ladc.ensure((size_t)nqt * BN * 16))) return rc;
+                a.lad = c->lad.as<unsigned long long>();
+                a.ladc = c->ladc.as<float4>();
+            }
             hipLaunchKernelGGL(tau_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const float*)c->dump.as<float>(), M, M, nq,
-                               kprime, c->tau.as<float>(), c->nbest.as<uint32_t>());
+                               kprime, c->tau.as<float>(), c->nbest.as<uint32_t>(), lad_on ? c->ladc.as<float4>() : (float4*)nullptr,
+                               lad_on ? c->lad.as<unsigned long long>() : (unsigned long long*)nullptr, lad_scale, hi_rank);
             HIPCHK(hipGetLastError());
         } else {
             // boot rows: a sample of 32-row groups when coarse launches follow (the ragged last group may be one of
@@ -1057,7 +1113,11 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                 c->coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }
             // expected emissions per query of this launch: k' * rows / rows seen before it
-            const uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)(p.sample_tiles ? p.sample_tiles : p.T1) + j0) + 1;
+            uint64_t expected = (uint64_t)kprime * cnt / std::max<uint64_t>(1, (uint64_t)(p.sample_tiles ? p.sample_tiles : p.T1) + j0) + 1;
+            if (a.lad) {   // the ladder tightens inside the launch: ~k' ln(rows / seen), doubled for the width of its levels
+                const double seen_t = (double)std::max<uint64_t>(1, (uint64_t)p.sample_tiles + j0);
+                expected = std::min<uint64_t>(expected, (uint64_t)(2.0 * kprime * (log(((double)cnt + seen_t) / seen_t) + 1.0)) + 1);
+            }
             if (dominant && fused_final) {  // the last selection happens inside final_kernel
                 last_nsplit = a.nsplit;
                 last_expected = expected;
@@ -1400,6 +1460,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "epi")) t.epi = (int)v;
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
+    else if (!strcmp(key, "ladder")) t.ladder = (int)v;
     else return -1;
     return 0;
 }

@@ -19,7 +19,9 @@ constexpr int COARSE_TOP2 = 4;    // small batches (nq <= 64, one query tile): n
 
 // 4 stages of (256 + 256) rows x 64 B, per-query counters, 8-deep ring of per-tile inverse norms + bounds
 // (+ for fp8 an 8-deep ring of the tiles' 256 scale exponents)
-constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(256 + 256) * 64 + (size_t)256 * 4 + 8 * 256 * 4 + 8 * 16 * 4 + 8 * 256;
+// (+ the threshold ladder of the bf16 / fp16 emitting kernel: the queries' {tau0, delta} and a 2-deep ring of counter words)
+constexpr size_t COARSE_LDS_BYTES = 4 * (size_t)(256 + 256) * 64 + (size_t)256 * 4 + 8 * 256 * 4 + 8 * 16 * 4 + 8 * 256 +
+                                    (size_t)256 * 16 + 2 * (size_t)256 * 8;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: called once per device by ensure_kernel_attrs()
 int coarse_attrs_bf16();

@@ -423,8 +423,10 @@ __device__ inline void cmpx_desc32(uint32_t& x, uint32_t& y) {
 // COHERENT: the values were written by OTHER workgroups of the same launch with agent-scope (sc1, write-through) stores and
 // are read here with agent-scope loads, which never hit a stale line of this CU's L1 or this XCD's L2 - no acquire fence
 // (MI355X_MICROARCH.md: a buffer_inv / buffer_wbl2 pair per hand-off is what makes a fenced hand-off 2-3x dearer).
+// hi_rank / hi_val (optional): the value at rank hi_rank <= k of the same descending order (the threshold ladder's spread)
 template <bool COHERENT = false>
-__device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k, int lane) {
+__device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k, int lane, uint32_t hi_rank = 0,
+                                         float* hi_val = nullptr) {
     uint32_t r[16];
     // lane l owns elements 4l..4l+3 of every 256-element slab (16-byte loads, coalesced); M <= 1024
 #pragma unroll
@@ -464,11 +466,14 @@ __device__ inline float kth_largest_wave(const float* d, uint32_t M, uint32_t k,
             }
     const uint32_t none = f2ord(-INFINITY);   // "no value" entries never count
     uint32_t cnt = 0, last = 0;
+    if (hi_val) *hi_val = -INFINITY;
     while (cnt < k) {
         const uint32_t w = wave_max_u32(r[0]);
         if (w <= none) break;  // fewer than k values
         const bool own = (r[0] == w);
+        const uint32_t before = cnt;
         cnt += (uint32_t)__popcll(__ballot(own));  // equal values in several lanes count once each
+        if (hi_val && before < hi_rank && cnt >= hi_rank) *hi_val = ord2f(w);
         last = w;
         if (own) {
 #pragma unroll

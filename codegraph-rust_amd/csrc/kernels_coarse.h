@@ -107,6 +107,9 @@ struct CoarseArgs {
     float* tau_out;         // [nq] the first thresholds, written by the launch itself
     uint32_t* boot_sync;    // [4 * nqt] rendezvous words of the query-tile groups (zero at launch)
     uint32_t kprime;        // the threshold is the k'-th largest group maximum
+    // Threshold ladder (COARSE_EMIT, bf16 / fp16 kernel; Ladder below): wait-free in-launch tightening of the thresholds
+    unsigned long long* lad;   // [nqt * 256] four 16-bit cumulative counters per query: candidates emitted at or above level j; NULL = off
+    const float4* ladc;     // [nqt * 256] {tau0, delta, 1 / delta, -}: level j (1..4) of a query starts at tau0 + j * delta; delta <= 0: no ladder
     // COARSE_TOP2 (small batches, Top2 below)
     uint32_t* floor_ord;    // [nq] f2ord of the largest coarse score any cell left OUT of its top-2 (atomicMax; zero at launch)
 };
@@ -234,6 +237,22 @@ __device__ __forceinline__ float block_max(const f32x16_t& v) {
     return vmax2(m5, m6);
 }
 
+// ---- Threshold ladder: wait-free tightening of the per-query thresholds INSIDE an emitting launch (round 5) ------------------
+// A launch's thresholds come from what was seen BEFORE it (the sample, earlier launches): a launch over N rows with a threshold
+// learnt from `seen` rows sends k' * N / seen scores per query down the slow path, which is why round 3 splits the corpus into
+// staged launches (sample -> 112 k rows -> the rest at C2) - each with its ramp, a select launch and a hit-heavy start. Round 4
+// tried to fuse them with a rendezvous and broke even because every form WAITS. Thresholds are monotone lower bounds, so nobody
+// has to wait: every query owns four score levels tau0 + j * delta above its first threshold (tau_kernel spaces them with the
+// sample's own spread, scaled to where the final k'-th best is expected) and four 16-bit counters packed into one 64-bit word
+// of global memory; a lane that appends a candidate with score s adds 1 to every level at or below s with ONE non-returning
+// 64-bit atomic (no return value: the hit path never waits for memory); the word of each of the workgroup's 256 queries
+// reaches LDS with the tile's side data (2 x 1 KiB DMA per tile), and at the tile boundary every lane raises its queries'
+// thresholds to the highest level whose counter has reached k' - at least k' DISTINCT rows at or above that level are in the
+// candidate lists, so it is a valid lower bound of the final k'-th best coarse score, however stale the read. One emitting
+// launch straight behind the sample then tightens itself as the staged plan did, without its launches.
+constexpr int LADDER_LEVELS = 4;
+__device__ __forceinline__ float ladder_level_score(float tau0, float delta, int j) { return tau0 + (float)j * delta; }
+
 // Slow path of one 32 x 32 block (some lane holds a score above its conservative threshold t): lanes with a score
 // above t compute the precise coarse score acc * invn_c * invn_q and append (score, row) to their (workgroup,
 // query) candidate list through an LDS counter. MFMA C layout: the lane owns query column lane&31 of the N-block
@@ -242,7 +261,8 @@ template <int BM, int BN>
 __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& v, float t, float tau, float iq,
                                            uint32_t rl0 /* first row of the block within the tile */, uint32_t ql,
                                            uint32_t tile, int lane, uint32_t g, uint32_t qt, uint32_t* cntq,
-                                           const float* invn_s) {
+                                           const float* invn_s, const float4* ladc_s = nullptr /* LDS: the queries' {tau0, delta, 1/delta} */) {
+    unsigned long long lad_add = 0ull;   // this lane's ladder increments of the block (Ladder above): ONE atomic at the end
     // row numbers are formed HERE, behind the branch, from an opaque base (32-bit: a device index holds < 2^32
     // rows): hoisted, they were 16 64-bit additions per tile on the path every block takes
     uint32_t rbase = rl0 + 4u * (uint32_t)(lane >> 5);
@@ -266,16 +286,28 @@ __device__ __forceinline__ void block_hits(const CoarseArgs& a, const f32x16_t& 
                         const float s = (a.metric == METRIC_DOT) ? av : av * invn_s[rl] * iq;
                         if (s > tau) {
                             const uint32_t p = lds_inc_rtn(&cntq[ql]);
-                            if (p < CAND_CAPS)
+                            if (p < CAND_CAPS) {
                                 a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(s), row);
-                            else
+                                if (ladc_s) {   // the candidate is in a list: count it on the query's ladder (Ladder above)
+                                    const float4 lc = ladc_s[ql];
+                                    int lv = (int)fminf((s - lc.x) * lc.z, (float)LADDER_LEVELS);   // (1 / delta = 0: no ladder)
+                                    // the reader forms a level's score with exactly this expression: a candidate counts at level
+                                    // lv only if it is at or above the score the reader will use as the threshold (the quotient
+                                    // can overshoot an integer by a rounding error: one step down then)
+                                    lv -= (lv > 0 && !(s >= ladder_level_score(lc.x, lc.y, lv))) ? 1 : 0;
+                                    if (lv > 0) lad_add += 0x0001000100010001ull >> (16 * (LADDER_LEVELS - lv));
+                                }
+                            } else {
                                 a.overflow[qt * BN + ql] = 1u;
+                            }
                         }
                     }
                 }
             }
         }
     }
+    if (ladc_s && lad_add != 0ull)   // non-returning: nothing waits for it
+        (void)__hip_atomic_fetch_add(a.lad + (uint64_t)qt * BN + ql, lad_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // conservative per-block threshold in raw-accumulator units: tq = tau / invn_q; a row of norm n scores
@@ -502,7 +534,7 @@ template <int BM, int BN, int WTM, int WTN, int MB, int NB>
 __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (&acc)[MB][NB], const float (&thr)[MB][NB],
                                                  uint32_t tile, int wm, int wn, int lane, uint32_t g, uint32_t qt,
                                                  const float (&tauv)[NB], const float (&invq)[NB], uint32_t* cntq,
-                                                 const float* invn_s) {
+                                                 const float* invn_s, const float4* ladc_s = nullptr) {
     int lane_o = lane;  // opaque copy: no hoisting of per-register row offsets out of the K loop (see tile_epilogue)
     asm volatile("" : "+v"(lane_o));
     lane = lane_o;
@@ -523,7 +555,7 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
             for (int nb = 0; nb < NB; ++nb)
                 if (__ballot(block_max(acc[mb][nb]) > thr[mb][nb]) != 0ull)
                     block_hits<BM, BN>(a, acc[mb][nb], thr[mb][nb], tauv[nb], invq[nb], (uint32_t)(wm * WTM + mb * 32),
-                                       (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane, g, qt, cntq, invn_s);
+                                       (uint32_t)(wn * WTN + nb * 32 + (lane & 31)), tile, lane, g, qt, cntq, invn_s, ladc_s);
     }
 }
 
@@ -611,7 +643,8 @@ __device__ inline bool boot_wait(uint32_t* counter, uint32_t* degraded, uint32_t
 // tests, no 64-bit chunk offset: the ring position and the chunk offset are two running scalars. Past its last tile the stream
 // simply runs on into the next tile of the visiting order (valid corpus memory) instead of re-reading the last stage. ~8 fewer
 // SALU per stage of ~100 instructions per SIMD - the stage loop sits at the issue limit of ~5 fillers per MFMA gap.
-template <int DT, int MODE, int ABL = 0, int EPI = 1, bool NTA = false, int SI = 0>
+// LAD: the threshold ladder (Ladder above) - its own instantiations, so that the kernel without it is exactly what it was.
+template <int DT, int MODE, int ABL = 0, int EPI = 1, bool NTA = false, int SI = 0, bool LAD = false>
 __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     constexpr int BM = 256, BN = 256, WN = 4, NT = 512;
     constexpr int WTM = 128, WTN = 64, MB = 4, NB = 2;
@@ -624,6 +657,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     uint32_t* cntq = (uint32_t*)(smem + NSTAGE * STAGE);
     float* invn_s = (float*)(smem + NSTAGE * STAGE + BN * 4);  // [NINV][256], by tile sequence number
     float* stat_s = invn_s + NINV * 256;                        // [NINV][16]: 8 block-min + 8 block-max norms
+    // threshold ladder (behind the fp8 kernels' exponent ring, which this kernel does not use): the queries' {tau0, delta} and
+    // a 2-deep ring of their counter words, refreshed with every tile's side data
+    float4* ladc_s = (float4*)((char*)(stat_s + NINV * 16) + NINV * 256);   // [256]
+    unsigned long long* lad_s = (unsigned long long*)(ladc_s + BN);         // [2][256]
+    const bool lad_on = LAD && EMIT && EPI != 0 && a.lad != nullptr;         // uniform
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -790,6 +828,32 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             const float* sp = ((lane & 2) ? a.blk_max : a.blk_min) + (uint64_t)(a.T1 + tt) * 8 + (lane & 1) * 4;
             glds16((const char*)sp, (char*)(stat_s + (seq & (NINV - 1)) * 16));
         }
+        if (lad_on && wave == 2) {   // the counter words of the workgroup's 256 queries as they stand now: read one tile later
+            const char* src = (const char*)(a.lad + (uint64_t)qt * BN) + lane * 16;
+            char* dst = (char*)(lad_s + (seq & 1u) * BN) + lane * 16;
+            glds16(src, dst);
+            glds16(src + 1024, dst + 1024);
+        }
+    };
+    // every lane: its queries' thresholds up to the highest ladder level whose counter has reached k' (words of ring slot `slot`)
+    auto ladder_raise = [&](uint32_t slot) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const uint32_t ql = (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
+            const unsigned long long w = lad_s[slot * BN + ql];
+            const float4 lc = ladc_s[ql];
+            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32), kp = a.kprime;
+            const int j = (hi >> 16) >= kp ? 4 : ((hi & 0xffffu) >= kp ? 3 : ((lo >> 16) >= kp ? 2 : ((lo & 0xffffu) >= kp ? 1 : 0)));
+            const float nt = ladder_level_score(lc.x, lc.y, j);
+            if (j > 0 && lc.y > 0.0f && nt > tauv[nb]) {   // (never lowers a threshold; padding queries keep +inf)
+                const float iq = invq[nb];
+                tauv[nb] = nt;
+                tq[nb] = (iq == 0.0f) ? INFINITY : nt / iq;
+                tone[nb] = (a.metric == METRIC_DOT) || !(fabsf(tq[nb]) < INFINITY);
+                tneg[nb] = tq[nb] < 0.0f;
+                ta[nb] = tone[nb] ? tq[nb] : (tneg[nb] ? tq[nb] * (1.0f + 3.8147e-6f) : tq[nb] * (1.0f - 3.8147e-6f));
+            }
+        }
     };
     auto side_wait = [&]() {  // uniform: short tiles only (D <= 64 elements per 64-byte chunk x 2)
         if (KC < 3) {
@@ -939,7 +1003,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             asm volatile("" : "+v"(acc[MBI][NBI])::"memory");
             if (__builtin_expect(__ballot(block_max(acc[MBI][NBI]) > thr[MBI][NBI]) != 0ull, 0))  // cold, out of line
                 block_hits<BM, BN>(a, acc[MBI][NBI], thr[MBI][NBI], tauv[NBI], invq[NBI], (uint32_t)(wm * WTM + MBI * 32),
-                                   (uint32_t)(wn * WTN + NBI * 32 + (lane & 31)), ftile, lane, g, qt, cntq, finv);
+                                   (uint32_t)(wn * WTN + NBI * 32 + (lane & 31)), ftile, lane, g, qt, cntq, finv,
+                                   lad_on ? ladc_s : (const float4*)nullptr);
         }
     };
 #define CGV_FILT(MBI, NBI) filt_block(IntC<MBI>{}, IntC<NBI>{});
@@ -1057,6 +1122,11 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         }
         return;
     }
+    if (lad_on && wave == 3) {   // the queries' {tau0, delta, 1 / delta}: constant for the launch, landed with the first stage
+        const char* src = (const char*)(a.ladc + (uint64_t)qt * BN) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + i * 1024, (char*)ladc_s + i * 1024 + lane * 16);
+    }
     issue_side(t_first, 0);
 #pragma unroll 1
     for (int i = 0; i < NSTAGE - 1; ++i) {
@@ -1087,7 +1157,8 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     if (!(ABL & 1)) {                                                                                              \
         if (EMIT && EPI != 0)                                                                                      \
             tile_filter_emit<BM, BN, WTM, WTN, MB, NB>(a, acc, thr, TILE, wm, wn, lane, g, qt, tauv, invq, cntq,     \
-                                                       invn_s + ((SEQ) & (NINV - 1)) * 256);                       \
+                                                       invn_s + ((SEQ) & (NINV - 1)) * 256,                        \
+                                                       lad_on ? ladc_s : (const float4*)nullptr);                  \
         else                                                                                                       \
             tile_epilogue<BM, BN, WTM, WTN, MB, NB, (MODE == 3 ? 0 : MODE)>(a, acc, TILE, wm, wn, lane, g, qt, tq, tauv, invq, cntq,  \
                                                           invn_s + ((SEQ) & (NINV - 1)) * 256,                     \
@@ -1163,6 +1234,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
                 CGV_LOAD_FRAGS(fa0, fb0, sb, 0);   // the starting tile's first fragments (not read early, see above)
             }
             if (EMIT && EPI != 0) {
+                // ladder words DMA'd at the previous boundary (with the side data of the tile that just ended): landed for the
+                // same reason its inverse norms have. The thresholds formed from now on - the next tile's - use the raised values;
+                // the filters below still run on this tile's (lower, valid) ones.
+                if (lad_on) ladder_raise((tl - 1) & 1u);
                 ftile = a.T1 + ct;
                 finv = invn_s + ((tl - 1) & (NINV - 1)) * 256;
                 issue_side(nt, tl);  // the tile that starts here (another slot of the side-data ring)

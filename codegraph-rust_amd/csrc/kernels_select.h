@@ -347,15 +347,28 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
 // one - with M / 16 >> k' groups the k' best rows of the sample almost surely sit in k' different groups.
 // ONE WAVE per query, values only (32-bit ordered keys, no row ids): <= 16 keys per lane sorted in registers, then
 // k' rounds of wave maximum + pop. Also clears nbest / overflow of the query (the launches that follow append).
+// Threshold ladder (kernels_coarse.h): also the query's {tau0, delta} and a cleared counter word. delta = lad_scale x (value at
+// rank hi_rank of the sample's maxima - tau0): the sample's own spread between two of its order statistics, scaled by the host
+// to a quarter of 1.25 x the distance at which the final k'-th best is expected under a normal tail (plan_ladder_scale, cgvec.hip)
+// - only the tightness of the thresholds depends on that guess, never their validity. Spread 0 / no sample: delta 0, no ladder.
 __global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
-                                                  uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest) {
+                                                  uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest,
+                                                  float4* __restrict__ ladc = nullptr, unsigned long long* __restrict__ lad = nullptr,
+                                                  float lad_scale = 0.0f, uint32_t hi_rank = 0) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (q >= nq) return;
-    const float t = kth_largest_wave(dense + (uint64_t)q * ld, M, kprime, lane);   // common.h
+    float hi = -INFINITY;
+    const float t = kth_largest_wave(dense + (uint64_t)q * ld, M, kprime, lane, hi_rank, ladc ? &hi : nullptr);   // common.h
     if (lane == 0) {
         tau[q] = t;
         nbest[q] = 0u;
+        if (ladc) {
+            const float spread = hi - t;
+            const float delta = (t > -INFINITY && spread > 0.0f && spread < INFINITY) ? lad_scale * spread : 0.0f;
+            ladc[q] = make_float4(t, delta, delta > 0.0f ? 1.0f / delta : 0.0f, 0.0f);
+            lad[q] = 0ull;
+        }
     }
 }
 
