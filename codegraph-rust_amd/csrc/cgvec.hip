@@ -192,6 +192,7 @@ struct SearchCtx {
     bool mfma = false, timed_coarse = false;
     bool boot_used = false;  // the search in flight used the fused sample + emit launch (its rendezvous words need clearing)
     bool top2 = false;       // the search in flight took the small-batch form (COARSE_TOP2: one launch, no thresholds)
+    bool floor_clean = false;  // the TOP2 floor words are known to be zero (final_kernel clears the ones it read)
     bool rewrote = false;  // search_finish ran the exact scan and rewrote (some of) the outputs after its first sync
     bool exact_enqueued = false;  // exact-scan-only batch (f32 index, forced exact, large k): the scan was enqueued by
                                   // search_enqueue itself - ONE host synchronisation per call instead of three
@@ -551,6 +552,11 @@ int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
     return CGV_OK;
 }
 
+__global__ void iota_kernel(uint32_t* p, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
 template <int DT>
 void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint32_t nql, float* scores, int op, hipStream_t s) {
     uint64_t gx = ((uint64_t)h->n + 31) / 32;
@@ -576,9 +582,14 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
     const uint32_t nch0 = (uint32_t)((n + TOPK_CHUNK - 1) / TOPK_CHUNK);
     if ((rc = c->keysA.ensure((size_t)qg * nch0 * K * 8))) return rc;
     if ((rc = c->keysB.ensure((size_t)qg * ((size_t)nch0 * K / TOPK_CHUNK + 1) * K * 8))) return rc;
+    if (!qlist_dev && nql > qg) {   // several groups of queries: the kernels index a group's queries through a list
+        if ((rc = c->qlist.ensure((size_t)nql * 4))) return rc;
+        hipLaunchKernelGGL(iota_kernel, dim3((nql + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nql);
+        qlist_dev = c->qlist.as<uint32_t>();
+    }
     for (uint32_t q0 = 0; q0 < nql; q0 += (uint32_t)qg) {
         const uint32_t g = (uint32_t)std::min<uint64_t>(qg, nql - q0);
-        const uint32_t* ql = qlist_dev + q0;
+        const uint32_t* ql = qlist_dev ? qlist_dev + q0 : nullptr;   // NULL (one group): the queries 0 .. nql - 1 themselves
         float* sc = c->scores.as<float>();
         switch (h->dtype) {
             case CGV_DTYPE_F32: launch_exact_scores<DT_F32>(h, c, ql, g, sc, op, s); break;
@@ -616,11 +627,6 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
         HIPCHK(hipGetLastError());
     }
     return CGV_OK;
-}
-
-__global__ void iota_kernel(uint32_t* p, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
 }
 
 __global__ void pad_out_kernel(uint64_t* idx, float* sc, uint64_t n) {
@@ -717,9 +723,6 @@ double env_double(const char* name, double dflt) {
 #define CGV_ENV_INT(NAME, DFLT) (DFLT)
 #define CGV_ENV_DBL(NAME, DFLT) (DFLT)
 #endif
-#ifndef CGV_LADDER_DEFAULT
-#define CGV_LADDER_DEFAULT 0
-#endif
 struct Tunables {
 #ifdef CGV_ABLATE_BUILD
     int plan_legacy = getenv("CGV_PLAN") && !strcmp(getenv("CGV_PLAN"), "legacy");
@@ -736,8 +739,9 @@ struct Tunables {
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
-    int ladder = CGV_ENV_INT("CGV_LADDER", CGV_LADDER_DEFAULT);  // threshold ladder (kernels_coarse.h): 0 = staged launches; 1 = ladder inside the
-                                                              // planned launches; 2 = ladder + ONE emitting launch behind the sample
+    // threshold ladder (kernels_coarse.h; MEASUREMENT FLAVOUR ONLY - a measured negative result, profiles/r05_tau_ladder_ab.txt):
+    // 0 = staged launches; 1 = ladder inside the planned launches; 2 = ladder + ONE emitting launch behind the sample
+    int ladder = CGV_ENV_INT("CGV_LADDER", 0);
 };
 Tunables& tun() {
     static Tunables t;
@@ -1018,8 +1022,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         c->top2 = top2;
         uint32_t top2_nsplit = 0;
         if (top2) {
+            if (c->floor.bytes < (size_t)TOP2_MAX_NQ * 4) c->floor_clean = false;
             if ((rc = c->floor.ensure((size_t)TOP2_MAX_NQ * 4))) return rc;
-            HIPCHK(hipMemsetAsync(c->floor.p, 0, (size_t)nq * 4, s));
+            if (!c->floor_clean) HIPCHK(hipMemsetAsync(c->floor.p, 0, (size_t)TOP2_MAX_NQ * 4, s));
+            c->floor_clean = false;   // (true again once this search's final kernel has run: search_finish)
             a.floor_ord = c->floor.as<uint32_t>();
             a.j0 = 0;
             a.cnt = p.ntiles;
@@ -1221,8 +1227,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     // search_finish has seen the flags - cgv_search_packed_begin_f32_dev.)
     c->exact_enqueued = false;
     if (!mfma && !c->on_caller) {
-        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
-        if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, out_idx, out_score, s))) return rc;
+        if ((rc = exact_search(h, c, nullptr, nq, k, out_idx, out_score, s))) return rc;   // (no query list: all of them, in order)
         c->exact_enqueued = true;
         // flags to the pinned mirror (and cleared for the next search) by a one-wave kernel, as on the MFMA path: no
         // copy-engine launch behind the scan, no memset in front of the next one
@@ -1306,8 +1311,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         // the scan ran behind the query conversion on the same stream: nothing left to do
     } else if (!c->mfma) {
         c->rewrote = true;
-        hipLaunchKernelGGL(iota_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nq);
-        if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nq, k, c->out_idx, c->out_score, s))) return rc;
+        if ((rc = exact_search(h, c, nullptr, nq, k, c->out_idx, c->out_score, s))) return rc;   // (all queries, in order)
         if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
         HIPCHK(hipStreamSynchronize(s));
     } else {
@@ -1331,6 +1335,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     }
     // the last kernel reset the flag words - unless the exact scan ran afterwards (its kernels use them too)
     c->flags_clean = c->published && !c->rewrote;
+    if (c->mfma && c->top2) c->floor_clean = true;   // final_kernel ran for every query and cleared the floor words it read
     std::lock_guard<std::mutex> lk(h->mu);
     h->st.max_observed_err = std::max(h->st.max_observed_err, me);
     h->st.fallback_queries += nfb;

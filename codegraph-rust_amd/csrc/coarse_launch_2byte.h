@@ -40,9 +40,10 @@ int coarse_attrs_2byte() {
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>))) return rc;
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>))) return rc;
-    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2, true>))) return rc;    // + threshold ladder
-    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2, true>))) return rc;
-#ifdef CGV_ABLATE_BUILD   // the fused sample + emit launch: a measured negative result, kept for A/B in the measurement flavour only
+#ifdef CGV_ABLATE_BUILD
+    // the threshold ladder (kernels_coarse.h): a measured negative result (profiles/r05_tau_ladder_ab.txt), measurement flavour only
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2, true>))) return rc;
+    if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2, true>))) return rc;   // the fused sample + emit launch: a measured negative result, kept for A/B in the measurement flavour only
     if ((rc = coarse_set_lds((const void*)coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>))) return rc;
 #endif
     return CGV_OK;
@@ -149,13 +150,15 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
             return coarse_hip_status("coarse_kernel (reads in the barrier gap)");
         }
     }
-    if (u4 && a.lad && a.ladc) {   // the threshold ladder: the ring-unrolled form only (every headline shape)
+#ifdef CGV_ABLATE_BUILD
+    if (u4 && a.lad && a.ladc) {   // the threshold ladder: the ring-unrolled form only (every headline shape); knob `ladder`
         if (nt)
             hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2, true>), dim3(W), dim3(512), lds, s, a);
         else
             hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2, true>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (si, ring-unrolled, ladder)");
     }
+#endif
     if (u4) {
         if (nt)
             hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);

@@ -20,7 +20,8 @@ struct SelectArgs {
     uint32_t* overflow;        // [nq]
     uint32_t nq, nqt, nsplit, bn, kprime, n_dense, lds_keys;
     uint32_t tau_only;         // dense scores of a SAMPLE of the corpus: publish tau, keep no candidates
-    const uint32_t* floor_ord; // COARSE_TOP2: [nq] f2ord of the best coarse score left out of the candidate lists (0: none), or NULL
+    uint32_t* floor_ord;       // COARSE_TOP2: [nq] f2ord of the best coarse score left out of the candidate lists (0: none), or NULL;
+                               // final_kernel reads its query's word and clears it for the next search (no memset launch per call)
     uint64_t* trace;           // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps of the kernel's phases, or NULL
 };
 
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     }
     const bool overflow = trunc || sa.overflow[q] != 0;
     __syncthreads();
+    if (sa.floor_ord && tid == 0) sa.floor_ord[q] = 0u;   // (every thread has read it: the barrier above)
     rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);
 }
 
