@@ -696,6 +696,7 @@ def run(args, wd, world, rank, local_rank):
             # under MFMA load the part runs at 1.5-1.8 GHz (power), so where the two nominal fractions are close (C4) the
             # comparison is made at the MEASURED clock: cycles per launch from the stamped PMC pass / this run's launch time
             # (C4's launch ran at 1.50 GHz with MFMA busy 0.74 - the matrix pipe, not HBM, binds it).
+            # (cycles per launch are a property of the kernel and its data; this run's duration turns them into this run's clock)
             clock_ghz = (cycles_xcd / (cms * 1e-3) / 1e9) if cycles_xcd else None
             mfma_at_clock = (mfma_frac * 2.4 / clock_ghz) if clock_ghz else None
             hbm_achievable = hbm_frac * 8.0 / 6.3     # MI355X_MICROARCH.md: ~6.3 TB/s is what a streaming kernel reaches

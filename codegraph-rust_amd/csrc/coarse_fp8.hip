@@ -79,6 +79,14 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
             return status("coarse_fp8s_w4_kernel (ablation)");
         }
 #endif
+#ifdef CGV_ABLATE_BUILD
+        if (a.kc % 4 == 0 && (a.epi & 512u) != 0) {   // A/B: the epilogue spread over two k-steps (EPI2; knob epi = 513)
+            auto k2 = coarse_fp8s_w4_kernel<0, 2, true>;
+            if (int rc = set_lds((const void*)k2)) return rc;
+            hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);
+            return status("coarse_fp8s_w4_kernel (si, epi2)");
+        }
+#endif
         if (a.kc % 4 == 0 && (a.epi & 8u) == 0) {   // static issue side, ring-unrolled (epi bit 3 = the dynamic form, for A/B)
             hipLaunchKernelGGL((coarse_fp8s_w4_kernel<0, 2>), dim3(W), dim3(256), lds, s, a);
             return status("coarse_fp8s_w4_kernel (si)");

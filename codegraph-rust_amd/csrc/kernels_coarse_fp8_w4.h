@@ -27,7 +27,14 @@ namespace cgv {
 // SI = 2 (kc % 4 == 0): static issue side + loop unrolled by the ring size, as in kernels_coarse.h - the DMA stream's ring slot
 // and the fragment reads' LDS addresses are constants of the unrolled iteration, the chunk offset one running scalar, the tile
 // switch of the stream happens in a known iteration (the last body of a tile); 0 = the dynamic form (any even kc >= 4).
-template <int ABL = 0, int SI = 0>
+// EPI2 (round 5): the epilogue spread over TWO k-steps. v_accvgpr_read_b32 issues at 6 cycles per wave64 instruction on this part
+// (scripts/ubench/accread.hip: 16 reads = 96 cycles), so one 32 x 32 block's epilogue - 16 reads + ~13 VALU of filter - is
+// ~148 cycles against the 64-cycle MFMA it sits in front of: the EPI k-step runs VALU-bound, ~1340 exposed cycles per tile (the
+// no-epilogue ablation: MFMA busy 0.675 -> 0.882). A block's accumulators are final once its MFMA of the tile's LAST k-step has
+// run, so blocks 0..7 (serpentine order) are read and filtered in the gaps of that k-step already - read in gap 2i + 1, filtered
+// in gap 2i + 2, two 16-register copies alternating - and blocks 8..15 in the zero-C k-step, each read at least one gap before
+// the MFMA that overwrites it: one read (96 cycles) or one filter (~52) per gap instead of both.
+template <int ABL = 0, int SI = 0, bool EPI2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void coarse_fp8s_w4_kernel(const CoarseArgs a) {
     constexpr bool DUMP = false;
     constexpr int BM = 256, BN = 256, WN = 2, NT = 256;
@@ -293,6 +300,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         CGV_EPI_READ(3, 1) CGV_MMAZ(3, 1, FA, FB) CGV_EGAP(3, 1, FB[0], CGV_DMAS(15, Q0))                       \
         CGV_EPI_READ(3, 0) CGV_MMAZ(3, 0, FA, FB) CGV_EGAP(3, 0, NA[0], CGV_DMAS(16, Q0))                       \
     }
+    // ---- EPI2: the same epilogue over the tile's last k-step + the zero-C k-step (two alternating copies etmp / etmp2) ----
+    f32x16_t etmp2;
+#define CGV_E2_READ(SLOT, MBI, NBI)                     \
+    if (!(ABL & 1)) {                                   \
+        SLOT = acc[MBI][NBI];                           \
+        asm volatile("" : "+v"(SLOT)::"memory");        \
+    }
+#define CGV_E2_TEST(SLOT, MBI, NBI)                                                                                   \
+    if (!(ABL & 1)) {                                                                                                 \
+        const float t_ = block_threshold(a, tq[NBI], emn[MBI], emx[MBI]);                                             \
+        if (__builtin_expect(ep_row0 + (uint32_t)((MBI) * 32) < a.n && block_max(SLOT) > t_, 0))                      \
+            block_hits<BM, BN>(a, SLOT, t_, tauv[NBI], invq[NBI], (uint32_t)(wm * WTM + (MBI) * 32),                  \
+                               (uint32_t)(wn * WTN + (NBI) * 32 + (lane & 31)), ep_tile, lane, g, qt, cntq, ep_invn); \
+    }
+    // the tile's LAST k-step (a B phase: fa1 / fb1 -> fa0 / fb0 from NBASE): block b_i final after MFMA i; R(b_i) in gap 2i + 1,
+    // T(b_i) in gap 2i + 2 for i = 0..7 (T(b_7) in the first gap of the zero-C k-step)
+#define CGV_KSTEP_LASTF(FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                          \
+    {                                                                                                                    \
+        CGV_PIN_ALL(FA, FB)                                                                                              \
+        CGV_MMA(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LDA(NA, 0, NBASE, NKK))                                    \
+        CGV_MMA(0, 1, FA, FB) CGV_GAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK); CGV_E2_READ(etmp, 0, 0))                 \
+        CGV_MMA(0, 2, FA, FB) CGV_GAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK); CGV_E2_TEST(etmp, 0, 0))                 \
+        CGV_MMA(0, 3, FA, FB) CGV_GAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK); CGV_E2_READ(etmp2, 0, 1))                \
+        CGV_MMA(1, 3, FA, FB) CGV_GAP(1, 3, FB[2], CGV_LDB(NB_, 3, NBASE, NKK); CGV_E2_TEST(etmp2, 0, 1))                \
+        CGV_MMA(1, 2, FA, FB) CGV_GAP(1, 2, FB[1], CGV_LDA(NA, 1, NBASE, NKK); CGV_E2_READ(etmp, 0, 2))                  \
+        CGV_MMA(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], CGV_LDA(NA, 2, NBASE, NKK); CGV_E2_TEST(etmp, 0, 2))                  \
+        CGV_MMA(1, 0, FA, FB) CGV_GAP(1, 0, FA[2], CGV_LDA(NA, 3, NBASE, NKK); CGV_E2_READ(etmp2, 0, 3))                 \
+        CGV_MMA(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_DMAS(9, Q0); CGV_E2_TEST(etmp2, 0, 3))                            \
+        CGV_MMA(2, 1, FA, FB) CGV_GAP(2, 1, FB[2], CGV_DMAS(10, Q0); CGV_E2_READ(etmp, 1, 3))                            \
+        CGV_MMA(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_DMAS(11, Q0); CGV_E2_TEST(etmp, 1, 3))                            \
+        CGV_MMA(2, 3, FA, FB) CGV_GAP(2, 3, FA[3], CGV_DMAS(12, Q0); CGV_E2_READ(etmp2, 1, 2))                           \
+        CGV_MMA(3, 3, FA, FB) CGV_GAP(3, 3, FB[2], CGV_DMAS(13, Q0); CGV_E2_TEST(etmp2, 1, 2))                           \
+        CGV_MMA(3, 2, FA, FB) CGV_GAP(3, 2, FB[1], CGV_DMAS(14, Q0); CGV_E2_READ(etmp, 1, 1))                            \
+        CGV_MMA(3, 1, FA, FB) CGV_GAP(3, 1, FB[0], CGV_DMAS(15, Q0); CGV_E2_TEST(etmp, 1, 1))                            \
+        CGV_MMA(3, 0, FA, FB) CGV_GAP(3, 0, NA[0], CGV_DMAS(16, Q0); CGV_E2_READ(etmp2, 1, 0))                           \
+    }
+    // the zero-C k-step behind it: T(b_7), then blocks 8..15, each READ at least one gap before the MFMA that overwrites it
+#define CGV_KSTEP_EPI2(FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                           \
+    {                                                                                                                    \
+        CGV_PIN_ALL(FA, FB)                                                                                              \
+        CGV_MMAZ(0, 0, FA, FB) CGV_GAP(0, 0, FB[1], FIRST; CGV_LDA(NA, 0, NBASE, NKK); CGV_E2_TEST(etmp2, 1, 0))         \
+        CGV_MMAZ(0, 1, FA, FB) CGV_GAP(0, 1, FB[2], CGV_LDB(NB_, 0, NBASE, NKK); CGV_E2_READ(etmp, 2, 0))                \
+        CGV_MMAZ(0, 2, FA, FB) CGV_GAP(0, 2, FB[3], CGV_LDB(NB_, 1, NBASE, NKK); CGV_E2_TEST(etmp, 2, 0))                \
+        CGV_MMAZ(0, 3, FA, FB) CGV_GAP(0, 3, FA[1], CGV_LDB(NB_, 2, NBASE, NKK); CGV_E2_READ(etmp2, 2, 1))               \
+        CGV_MMAZ(1, 3, FA, FB) CGV_GAP(1, 3, FB[2], CGV_LDB(NB_, 3, NBASE, NKK); CGV_E2_TEST(etmp2, 2, 1))               \
+        CGV_MMAZ(1, 2, FA, FB) CGV_GAP(1, 2, FB[1], CGV_LDA(NA, 1, NBASE, NKK); CGV_E2_READ(etmp, 2, 2))                 \
+        CGV_MMAZ(1, 1, FA, FB) CGV_GAP(1, 1, FB[0], CGV_LDA(NA, 2, NBASE, NKK); CGV_E2_TEST(etmp, 2, 2))                 \
+        CGV_MMAZ(1, 0, FA, FB) CGV_GAP(1, 0, FA[2], CGV_LDA(NA, 3, NBASE, NKK); CGV_E2_READ(etmp2, 2, 3))                \
+        CGV_MMAZ(2, 0, FA, FB) CGV_GAP(2, 0, FB[1], CGV_DMAS(9, Q0); CGV_E2_TEST(etmp2, 2, 3))                           \
+        CGV_MMAZ(2, 1, FA, FB) CGV_GAP(2, 1, FB[2], CGV_DMAS(10, Q0); CGV_E2_READ(etmp, 3, 3))                           \
+        CGV_MMAZ(2, 2, FA, FB) CGV_GAP(2, 2, FB[3], CGV_DMAS(11, Q0); CGV_E2_TEST(etmp, 3, 3))                           \
+        CGV_MMAZ(2, 3, FA, FB) CGV_GAP(2, 3, FA[3], CGV_DMAS(12, Q0); CGV_E2_READ(etmp2, 3, 2))                          \
+        CGV_MMAZ(3, 3, FA, FB) CGV_GAP(3, 3, FB[2], CGV_DMAS(13, Q0); CGV_E2_TEST(etmp2, 3, 2))                          \
+        CGV_MMAZ(3, 2, FA, FB) CGV_GAP(3, 2, FB[1], CGV_DMAS(14, Q0); CGV_E2_READ(etmp, 3, 1))                           \
+        CGV_MMAZ(3, 1, FA, FB) CGV_GAP(3, 1, FB[0], CGV_DMAS(15, Q0); CGV_E2_TEST(etmp, 3, 1); CGV_E2_READ(etmp2, 3, 0)) \
+        CGV_MMAZ(3, 0, FA, FB) CGV_GAP(3, 0, NA[0], CGV_DMAS(16, Q0); CGV_E2_TEST(etmp2, 3, 0))                          \
+    }
     // counted wait: the DMA instructions of the stage behind the one being published may stay in flight
     // (one stage = 8; the phase's own 8 pieces are issued after the wait)
 #define CGV_STAGE_SYNC                                  \
@@ -375,7 +439,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (uint32_t tl = 1; tl < ntl; ++tl) {
         {
             si_slot = (uint32_t)(2 * STAGE);
-            if constexpr (SI != 0) {
+            if constexpr (EPI2) {   // the ending tile's epilogue starts inside its last k-step: its constants first
+                ep_tile = a.T1 + ct;
+                ep_row0 = ep_tile * (uint32_t)BM + (uint32_t)(wm * WTM);
+                ep_invn = invn_s + ((tl - 1) & (NINV - 1)) * 256;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    emn[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + (wm * WTM) / 32 + mb];
+                    emx[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + 8 + (wm * WTM) / 32 + mb];
+                }
+                if constexpr (SI != 0) {
+                    CGV_KSTEP_LASTF(fa1, fb1, fa0, fb0, smem, 0, 0, CGV_STAGE_SYNC);
+                } else {
+                    CGV_KSTEP_LASTF(fa1, fb1, fa0, fb0, stage_b(s), 0, 0, CGV_STAGE_SYNC);
+                }
+            } else if constexpr (SI != 0) {
                 CGV_B_PHASE(smem);
             } else {
                 CGV_B_PHASE(stage_b(s));
@@ -385,18 +463,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             issue_side(nt, tl);                   // the tile that starts here
             issue_rexp(next_tile(nt), tl + 1);    // exponents of the one after it
             // epilogue of tile ct (sequence number tl - 1), folded into the zero-C k-step of tile nt
-            ep_tile = a.T1 + ct;
-            ep_row0 = ep_tile * (uint32_t)BM + (uint32_t)(wm * WTM);
-            ep_invn = invn_s + ((tl - 1) & (NINV - 1)) * 256;
+            if constexpr (!EPI2) {
+                ep_tile = a.T1 + ct;
+                ep_row0 = ep_tile * (uint32_t)BM + (uint32_t)(wm * WTM);
+                ep_invn = invn_s + ((tl - 1) & (NINV - 1)) * 256;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                emn[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + (wm * WTM) / 32 + mb];
-                emx[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + 8 + (wm * WTM) / 32 + mb];
+                for (int mb = 0; mb < MB; ++mb) {
+                    emn[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + (wm * WTM) / 32 + mb];
+                    emx[mb] = stat_s[((tl - 1) & (NINV - 1)) * 16 + 8 + (wm * WTM) / 32 + mb];
+                }
             }
             ct = nt;
             load_sa(tl);  // issued at the previous boundary: a whole tile of counted waits + barriers ago
             si_slot = (uint32_t)(3 * STAGE);
-            if constexpr (SI != 0) {
+            if constexpr (EPI2) {
+                if constexpr (SI != 0) {
+                    CGV_KSTEP_EPI2(fa0, fb0, fa1, fb1, smem + STAGE, 1, 4, CGV_STAGE_SYNC);
+                } else {
+                    CGV_KSTEP_EPI2(fa0, fb0, fa1, fb1, stage_a(s), 1, 4, CGV_STAGE_SYNC);
+                }
+            } else if constexpr (SI != 0) {
                 CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, smem + STAGE, 1, 4, CGV_STAGE_SYNC);
             } else {
                 CGV_KSTEP_EPI(fa0, fb0, fa1, fb1, stage_a(s), 1, 4, CGV_STAGE_SYNC);
@@ -433,6 +519,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CGV_STAGE_SYNC
 #undef CGV_KSTEP
 #undef CGV_KSTEP_EPI
+#undef CGV_KSTEP_EPI2
+#undef CGV_KSTEP_LASTF
+#undef CGV_E2_TEST
+#undef CGV_E2_READ
 #undef CGV_EGAP
 #undef CGV_EPI_TEST
 #undef CGV_EPI_READ

@@ -32,6 +32,22 @@ if g('FETCH_SIZE'):
 if g('TCC_REQ_sum'):
     print("-- TCC hit rate %.3f" % (g('TCC_HIT_sum', 0) / (g('TCC_HIT_sum', 0) + g('TCC_MISS_sum', 1))))
 
+# duration of the same dispatch in the pass that carried GRBM_GUI_ACTIVE (the PMC passes run with --kernel-trace): the clock the
+# launch ran at = cycles per XCD / duration (say what limits the launch - the nominal peaks assume 2.4 GHz)
+dur_ns = None
+for f in sorted(glob.glob(os.path.join(d, 'p1_kernel_trace.csv'))):
+    rows = [r for r in csv.DictReader(open(f)) if 'coarse' in r.get('Kernel_Name', '')]
+    if rows:
+        last = max(rows, key=lambda r: int(r['Dispatch_Id']))
+        dur_ns = int(last['End_Timestamp']) - int(last['Start_Timestamp'])
+if dur_ns and g('GRBM_GUI_ACTIVE'):
+    clk = g('GRBM_GUI_ACTIVE') / 8 / dur_ns
+    print("-- profiled duration %.1f us ; clock %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration)" % (dur_ns / 1e3, clk))
+    allc['profiled_duration_us'] = dur_ns / 1e3
+    allc['clock_ghz'] = clk
+    if g('SQ_VALU_MFMA_BUSY_CYCLES'):
+        allc['mfma_busy'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024 / (g('GRBM_GUI_ACTIVE') / 8)
+
 import json
 out = {k: allc[k] for k in allc if not k.startswith('_')}
 if g('FETCH_SIZE'):
