@@ -181,7 +181,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -202,7 +202,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor, &lad, &ladc};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -210,7 +210,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor, &lad, &ladc};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -1161,6 +1161,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
+        if ((rc = c->qstat.ensure((size_t)nq * 8))) return rc;
+        r.qstat = c->qstat.as<uint2>();   // per-query statistics, folded into the flag words by publish_flags_kernel
         c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
         c->published = true;     // publish_flags_kernel behind the last kernel, below
 #ifdef CGV_ABLATE_BUILD
@@ -1215,9 +1217,10 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             }
         }
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
+        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(256), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
                            (uint32_t)F_DONE, nq, c->boot_used ? c->flags + F_COUNT + PACE_WORDS : (uint32_t*)nullptr,
-                           c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u);
+                           c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u, (const uint2*)c->qstat.as<uint2>(), nq,
+                           (uint32_t)F_MAXERR, (uint32_t)(h->shadow ? F_MAXEPS : F_COUNT));
         HIPCHK(hipGetLastError());
     }
     // Exact-scan-only batches (the reference's own f32 layout: BASELINE config 1, one query per call; forced exact; k beyond the

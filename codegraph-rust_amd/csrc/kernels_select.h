@@ -396,6 +396,11 @@ struct RescoreArgs {
     float res_rel_c;        // max over the corpus of |dc| / min(|c|, |c^|)
     float res_abs_c;        // max over the corpus of |dc|
     uint32_t* stat_maxeps;  // [1] f2ord-free max of the eps actually used (non-negative float bits)
+    uint2* qstat;           // [nq] {max |coarse - exact| bits, eps bits} of each query, or NULL. Round 5: the batch-wide maxima used
+                            // to be raised with one atomicMax per workgroup on ONE word - all 1024 workgroups of a C2 batch start
+                            // within a microsecond, so every one of them saw the cleared word, and the atomics serialised at ~12 ns
+                            // apiece: the slowest workgroup ended 14 us behind the median (phase stamps, r05). Now a plain store
+                            // per query; publish_flags_kernel folds the maxima into the flag words.
     uint64_t* trace;        // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps (100 MHz) of the phases, or NULL
 };
 
@@ -404,13 +409,36 @@ struct RescoreArgs {
 // so the host needs neither a flags D2H copy after the pipeline (a copy-engine launch on the critical path) nor a
 // memset before the next one. host[done_word] = marker tells the host the mirror is current. (A ticket counter in
 // the last kernel instead - 1024 returning atomics on one word - cost 25 us: r03b.)
+// qstat (optional): the per-query {max observed error, eps} words of the final kernel ([nq]; RescoreArgs::qstat): their maxima
+// are folded into flag words err_word / eps_word here (both are bit patterns of non-negative floats: unsigned order = float order).
 __global__ void publish_flags_kernel(uint32_t* __restrict__ flags, uint32_t* __restrict__ host, uint32_t n_flags,
                                      uint32_t done_word, uint32_t marker, uint32_t* __restrict__ extra = nullptr,
-                                     uint32_t n_extra = 0u) {
+                                     uint32_t n_extra = 0u, const uint2* __restrict__ qstat = nullptr, uint32_t nq = 0u,
+                                     uint32_t err_word = 0u, uint32_t eps_word = 0u) {
+    __shared__ uint32_t red[2];
     const uint32_t i = threadIdx.x;
+    if (i < 2) red[i] = 0u;
+    __syncthreads();
+    if (qstat) {
+        uint32_t me = 0u, mp = 0u;
+        for (uint32_t q = i; q < nq; q += blockDim.x) {
+            const uint2 v = qstat[q];
+            me = v.x > me ? v.x : me;
+            mp = v.y > mp ? v.y : mp;
+        }
+        me = wave_max_u32(me);
+        mp = wave_max_u32(mp);
+        if ((i & 63u) == 0u) {
+            atomicMax(&red[0], me);
+            atomicMax(&red[1], mp);
+        }
+    }
+    __syncthreads();
     for (uint32_t j = i; j < n_extra; j += blockDim.x) extra[j] = 0u;  // rendezvous words of a fused sample + emit launch
     if (i < n_flags) {
-        const uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (qstat && i == err_word) v = v > red[0] ? v : red[0];
+        if (qstat && i == eps_word) v = v > red[1] ? v : red[1];
         host[i] = (i == done_word) ? marker : v;
         __hip_atomic_store(flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -461,7 +489,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     const float trip = 0.5f * eps;
     // the batch-wide statistics words, looked at before they are raised (below): fetched now, used ~20 us later
     uint32_t seen_maxerr = 0, seen_maxeps = 0;
-    if (tid == 0) {
+    if (tid == 0 && !a.qstat) {
         seen_maxerr = __hip_atomic_load(a.stat_maxerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.stat_maxeps) seen_maxeps = __hip_atomic_load(a.stat_maxeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -476,6 +504,12 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     if (nb > a.k && a.k > 0) {
         const float cut = key_score(ckeys[a.k - 1]) - 2.0f * eps;
         uint32_t m = a.k;
+        if (nb <= 64) {   // the list is sorted: the prefix at or above the cut = k + the number of later entries at or above it -
+            // one LDS read per lane and a ballot instead of a dependent walk of up to k' LDS round trips in every thread
+            const uint32_t l = (uint32_t)tid & 63u;
+            const bool in = l >= a.k && l < nb && key_score(ckeys[l]) >= cut;
+            m = a.k + (uint32_t)__popcll(__ballot(in));
+        } else
         while (m < nb && key_score(ckeys[m]) >= cut) ++m;  // uniform: every thread walks the same short list
         if (m < nb) {
             // (the first skipped candidate bounds the skipped ones; `tau` everything outside the list - it is the larger of the
@@ -572,10 +606,11 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         // statistics: one word for the whole batch. An unconditional atomicMax from each of the 1024 workgroups
         // serialises at ~12 ns apiece on that word; almost none of them raises the maximum, so look first (a stale
         // read only costs a redundant atomic).
-        if (maxerr > seen_maxerr) atomicMax(a.stat_maxerr, maxerr);
+        if (a.qstat) a.qstat[q] = make_uint2(maxerr, tau_eff > -INFINITY ? __float_as_uint(eps) : 0u);
+        else if (maxerr > seen_maxerr) atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
         if (tau_eff > -INFINITY) {  // rows at or below tau_eff were dropped / not re-scored: check the guarantee
-            if (a.stat_maxeps && __float_as_uint(eps) > seen_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
+            if (!a.qstat && a.stat_maxeps && __float_as_uint(eps) > seen_maxeps) atomicMax(a.stat_maxeps, __float_as_uint(eps));
             if (nres < a.k && nres < nb_all) fb = true;  // (cannot happen: the re-scored prefix holds >= k candidates)
             if (nb_all < a.k) fb = true;                 // (the corpus has more rows than candidates survived)
             else if (!(key_score(ekeys[a.k - 1]) > tau_eff + eps)) fb = true;
