@@ -37,3 +37,17 @@ for f in sorted(glob.glob('gpurun_out/profiles_'"$TAG"'/*_bench.json')):
           'pipelined_host', (d.get('pipelined_host') or {}).get('ms_per_batch'), 'pipelined', (d.get('pipelined') or {}).get('ms_per_batch'), 'exact_check', (d.get('exact_check') or {}).get('ordered_match_rate'), 'resident', (d.get('hbm_resident_serial') or {}).get('ms_per_step'),
           'xch', (d.get('multi_gpu') or {}).get('exchange_ms'), d.get('last_exchange_ms'), 'recall', d.get('recall_at_10'), 'cpu', (d.get('cpu_baseline') or {}).get('value'))
 PY
+# the small-batch path: kernel timeline of single-query calls + counters of its one coarse launch (COARSE_TOP2) on C2
+cd /tmp
+for wl in c2shard8 c1 c2; do
+  it=300; [ $wl = c2 ] && it=60
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O -o lat_$wl -- python $R/scripts/lat_loop.py --workload $wl --nq 1 --iters $it > $R/$O/lat_$wl.log 2>&1
+  tail -1 $R/$O/lat_$wl.log; rm -f $R/$O/lat_${wl}_kernel_trace.csv
+done
+t2() { name=$1; shift
+  timeout 200 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "coarse_kernel" --output-format csv -d $R/$O/top2 -o $name -- python $R/scripts/lat_loop.py --workload c2 --nq 1 --iters 5 > $R/$O/top2_$name.log 2>&1; }
+t2 p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+t2 p2 FETCH_SIZE TCC_HIT_sum
+t2 p3 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
+cd $R; python scripts/pmc_summary.py $O/top2 > $O/c2_top2_pmc_summary.txt 2>&1; tail -8 $O/c2_top2_pmc_summary.txt
+rm -rf $O/top2 $O/*_agent_info.csv $O/*_domain_stats.csv $O/top2_*.log
