@@ -149,6 +149,10 @@ def lib():
     L.cgv_sharded_force_exchange.restype = i32
     L.cgv_set_spin_us.argtypes = [vp, u32]
     L.cgv_set_spin_us.restype = i32
+    L.cgv_alloc_pinned.argtypes = [C.c_size_t]
+    L.cgv_alloc_pinned.restype = vp
+    L.cgv_free_pinned.argtypes = [vp]
+    L.cgv_free_pinned.restype = i32
     L.cgv_debug_rccl_lib_.argtypes = [C.c_char_p]
     L.cgv_debug_rccl_lib_.restype = i32
     L.cgv_sharded_get_stats.argtypes = [vp, C.POINTER(ShardedStats)]

@@ -2330,6 +2330,27 @@ int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* scor
 
 uint32_t cgv_packed_width(uint32_t k) { return packed_width(k); }
 
+void* cgv_alloc_pinned(size_t bytes) {
+    if (cgv_device_count() == 0) {
+        (void)fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
+        return nullptr;
+    }
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)fail(e == hipErrorOutOfMemory ? CGV_ERR_OOM : CGV_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+int cgv_free_pinned(void* p) {
+    if (!p) return CGV_OK;
+    HIPCHK(hipHostFree(p));
+    return CGV_OK;
+}
+
 void* cgv_host_device_alias(int device_id, const void* host_ptr, size_t bytes) {
     if (!host_ptr || hipSetDevice(device_id) != hipSuccess) {
         (void)hipGetLastError();

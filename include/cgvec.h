@@ -90,7 +90,7 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_FAST_MAX_K 228u
 
 /* Library/ABI version (major<<16 | minor). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
- * environment variable. Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
+ * environment variable; cgv_alloc_pinned / cgv_free_pinned. Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
  * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. Minor 5 (round 4): cgv_search_packed_begin_f32_dev
  * / cgv_search_packed_end / cgv_merge_packed_flag_dev (the join-free exchange), cgv_host_device_alias, CGV_METRIC_COSINE_SCALAR /
  * CGV_OP_COSINE_SCALAR, CGV_ERR_BUSY from cgv_sharded_* writers / readers while a batch is in flight. */
@@ -262,6 +262,14 @@ int cgv_merge_packed_dev(int device_id, const uint32_t* rec_dev, uint32_t g, uin
  * memory, possibly different for hipHostRegister-ed memory), or NULL when [host_ptr, host_ptr + bytes) is not WHOLLY such
  * memory mapping to one contiguous device range. What cgv_search_f32 uses to decide "in place or staged" per buffer. */
 void* cgv_host_device_alias(int device_id, const void* host_ptr, size_t bytes);
+
+/* Pinned (page-locked, device-mapped) host memory for a caller without the HIP runtime in its own link line (a Rust shim, a C
+ * program): query batches and result arrays in such memory are used IN PLACE by cgv_search_f32 and - through their device
+ * alias (cgv_host_device_alias) - by cgv_search_begin_f32_dev / cgv_search_packed_begin_f32_dev: a worker that keeps one pinned
+ * staging buffer saves two copies per batch (hipHostMalloc(hipHostMallocPortable | hipHostMallocMapped) / hipHostFree).
+ * cgv_alloc_pinned returns NULL on failure (message in cgv_last_error()). */
+void* cgv_alloc_pinned(size_t bytes);
+int cgv_free_pinned(void* p);
 
 /* ---- one rank's share of a batch WITHOUT a host join between the shard search and the exchange -------------------------
  * (row-sharded deployment, one process per GPU; the reference has no counterpart - its "batch" is B

@@ -94,6 +94,62 @@ int main(int argc, char** argv) {
     if (cgv_get_row_f32(h, (uint64_t)n + 5, back) != CGV_ERR_OUT_OF_RANGE || !strlen(cgv_last_error())) return 2;
     if ((rc = cgv_get_row_f32(h, 1, back))) return die("cgv_get_row_f32", rc);
 
+    /* the trait-level call is ONE query (traits.rs:14): every query again, alone, through pageable buffers - the same rows */
+    {
+        uint64_t* i1 = (uint64_t*)malloc((size_t)k * 8);
+        float* s1 = (float*)malloc((size_t)k * 4);
+        for (uint32_t i = 0; i < nq && i < 12; ++i) {
+            if ((rc = cgv_search_f32(h, q + (size_t)i * dim, 1, k, i1, s1))) return die("cgv_search_f32 (one query)", rc);
+            if (memcmp(i1, idx + (size_t)i * k, (size_t)k * 8) || memcmp(s1, sc + (size_t)i * k, (size_t)k * 4)) {
+                fprintf(stderr, "single-query call %u differs from the batch's answer\n", i);
+                return 2;
+            }
+        }
+        free(i1);
+        free(s1);
+    }
+    /* host in / host out with batches in flight, from plain C: pinned staging buffers from the library, their device aliases
+     * into cgv_search_begin_f32_dev, cgv_search_end in order - the results land in the pinned arrays in place */
+    {
+        const uint32_t depth = cgv_max_batches_in_flight(h) < 2 ? 1 : 2;
+        const size_t qb = (size_t)nq * dim * 4, ib = (size_t)nq * k * 8, sb = (size_t)nq * k * 4;
+        float* pq[2] = {NULL, NULL};
+        uint64_t* pi[2] = {NULL, NULL};
+        float* ps[2] = {NULL, NULL};
+        uint64_t t[2] = {0, 0};
+        for (uint32_t j = 0; j < depth; ++j) {
+            pq[j] = (float*)cgv_alloc_pinned(qb);
+            pi[j] = (uint64_t*)cgv_alloc_pinned(ib);
+            ps[j] = (float*)cgv_alloc_pinned(sb);
+            if (!pq[j] || !pi[j] || !ps[j]) return die("cgv_alloc_pinned", CGV_ERR_HIP);
+            memcpy(pq[j], q, qb);
+            memset(pi[j], 0, ib);
+        }
+        for (uint32_t j = 0; j < depth; ++j) {
+            const float* dq = (const float*)cgv_host_device_alias(0, pq[j], qb);
+            uint64_t* di = (uint64_t*)cgv_host_device_alias(0, pi[j], ib);
+            float* ds = (float*)cgv_host_device_alias(0, ps[j], sb);
+            if (!dq || !di || !ds) return die("cgv_host_device_alias", CGV_ERR_HIP);
+            if ((rc = cgv_search_begin_f32_dev(h, dq, nq, k, di, ds, &t[j]))) return die("cgv_search_begin_f32_dev", rc);
+        }
+        for (uint32_t j = 0; j < depth; ++j)
+            if ((rc = cgv_search_end(h, t[j]))) return die("cgv_search_end", rc);
+        for (uint32_t j = 0; j < depth; ++j) {
+            if (memcmp(pi[j], idx, ib) || memcmp(ps[j], sc, sb)) {
+                fprintf(stderr, "pipelined batch %u differs from the blocking call's answer\n", j);
+                return 2;
+            }
+            /* and the blocking call uses pinned buffers in place too */
+            memset(pi[j], 0, ib);
+            if ((rc = cgv_search_f32(h, pq[j], nq, k, pi[j], ps[j]))) return die("cgv_search_f32 (pinned)", rc);
+            if (memcmp(pi[j], idx, ib) || memcmp(ps[j], sc, sb)) return 2;
+            if ((rc = cgv_free_pinned(pq[j])) || (rc = cgv_free_pinned(pi[j])) || (rc = cgv_free_pinned(ps[j]))) return die("cgv_free_pinned", rc);
+        }
+        if ((rc = cgv_set_spin_us(h, 0))) return die("cgv_set_spin_us", rc);   /* block at once: same answer */
+        if ((rc = cgv_search_f32(h, q, nq, k, idx, sc))) return die("cgv_search_f32 (no spin)", rc);
+        if ((rc = cgv_set_spin_us(h, 3000))) return die("cgv_set_spin_us", rc);
+    }
+
     cgv_stats st;
     if ((rc = cgv_get_stats(h, &st))) return die("cgv_get_stats", rc);
     printf("rows=%llu device_bytes=%llu path=%u fallback=%llu\n", (unsigned long long)st.n_rows,

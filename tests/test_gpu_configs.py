@@ -197,6 +197,18 @@ def test_c2_full_size_anchored_and_strong_scaling_shards(oracle):
         _anchored_check(full, oracle, qh, gi, gs, "cosine", 1, sampled, rng)
         # exact scans of the sampled queries over all rows: the reference for every shard below
         exact = {qi: full.batch_similarity(qh[qi], "cosine") for qi in sampled}
+        # the same queries as SMALL batches at full size (round 5: COARSE_TOP2 - the whole 1M-row corpus in one launch without
+        # thresholds, per-cell top-2 + floor): bit-equal to their rows of the 1024-query batch's answer (oracle-anchored
+        # above), pageable host buffers in and out, no fallback on random data
+        import ctypes as C
+        L = m.cgvec.lib()
+        L.cgv_debug_last_top2_.argtypes = [C.c_void_p]
+        L.cgv_debug_last_top2_.restype = C.c_int
+        for lo, hi in ((0, 1), (255, 256), (0, 8), (500, 532), (960, 1024)):
+            si, ss = full.search(qh[lo:hi], k)
+            assert L.cgv_debug_last_top2_(full._h) == 1
+            assert np.array_equal(si, gi[lo:hi]) and np.array_equal(ss, gs[lo:hi]), (lo, hi)
+        assert full.stats()["fallback_queries"] == 0
     finally:
         full.close()
     for rows, base in ((500_000, 0), (250_000, 250_000), (125_000, 875_000)):
