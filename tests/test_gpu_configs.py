@@ -208,7 +208,10 @@ def test_c2_full_size_anchored_and_strong_scaling_shards(oracle):
             si, ss = full.search(qh[lo:hi], k)
             assert L.cgv_debug_last_top2_(full._h) == 1
             assert np.array_equal(si, gi[lo:hi]) and np.array_equal(ss, gs[lo:hi]), (lo, hi)
-        assert full.stats()["fallback_queries"] == 0
+        # a small batch sends a query to the exact scan when three of its top-(k + 1) rows share one of the launch's
+        # 1024 cells: measured 5e-4 per query on this corpus (scripts/top2_fallback_rate.py, 3 of 6000); the answers
+        # above are equal either way, so the count is only bounded here
+        assert full.stats()["fallback_queries"] <= 2
     finally:
         full.close()
     for rows, base in ((500_000, 0), (250_000, 250_000), (125_000, 875_000)):
