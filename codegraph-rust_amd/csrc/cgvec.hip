@@ -952,7 +952,18 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         // threshold ladder (kernels_coarse.h): the bf16 / fp16 emitting kernel tightens its thresholds inside the launch
         const int lad_mode = (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) ? tun().ladder : 0;
         const StagePlan p = plan_stages(h->n, kprime, nqt, (uint32_t)h->n_cu, nsplit_max, lad_mode >= 2 ? 1 : 0);
-        const uint32_t Wmax = nqt * nsplit_max;
+        // emitting launches: workgroups per query tile. Measurement flavour, knob `epi` bit 10: two 4-wave workgroups per CU
+        // (kernels_coarse_wg2.h; the select kernels take up to 256 lists per query)
+        uint32_t nsplit_emit = nsplit_max;
+#ifdef CGV_ABLATE_BUILD
+        {
+            const uint32_t kc_ = (h->shadow ? h->lds : h->ld) / kchunk_of(cdt);
+            if ((tun().epi & 1024) != 0 && nqt >= 2 && (cdt == CGV_DTYPE_BF16 || cdt == CGV_DTYPE_FP16) && kc_ >= 3 && kc_ % 3 == 0 &&
+                2 * nsplit_max <= 256)
+                nsplit_emit = 2 * nsplit_max;
+        }
+#endif
+        const uint32_t Wmax = nqt * nsplit_emit;
         if ((rc = c->tau.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->nbest.ensure((size_t)nq * 4))) return rc;
         if ((rc = c->overflow.ensure((size_t)nq * 4))) return rc;
@@ -1096,7 +1107,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             const uint32_t cnt = p.counts[st];
             a.j0 = j0;
             a.cnt = cnt;
-            a.nsplit = std::min<uint32_t>(cnt, nsplit_max);
+            a.nsplit = std::min<uint32_t>(cnt, nsplit_emit);
             // Soft lockstep pays where the workgroups of a group can drift apart: launches of 100+ tiles per workgroup
             // (C5: 1000+). On short walks (C2: 55 tiles) the group stays together by itself and the per-tile poll only
             // costs (r03b: C2 step 1.458 -> 1.453 ms, the 125 k-row shard 0.381 -> 0.378 without it).

@@ -1,6 +1,7 @@
 // coarse_launch_2byte.h — launchers of the bf16 / fp16 coarse kernels (included by coarse_bf16.hip and
 // coarse_fp16.hip only: one translation unit per dtype).
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -10,6 +11,7 @@
 #include "coarse_launch.h"
 #ifdef CGV_ABLATE_BUILD
 #include "kernels_coarse_w4.h"   // one wave per SIMD, 128 x 128 per wave (A/B against the 8-wave kernel; epi bit 7)
+#include "kernels_coarse_wg2.h"  // two workgroups of 4 waves per CU, 128 x 256 tiles (A/B; epi bit 10)
 #endif
 
 extern "C" int cgv_set_error_(int code, const char* msg);
@@ -116,6 +118,20 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         }
     }
 #ifdef CGV_ABLATE_BUILD
+    if ((a.epi & 1024u) != 0 && a.kc >= 3 && a.kc % 3 == 0 && a.nqt >= 2 && !a.lad) {  // A/B: two workgroups per CU (kernels_coarse_wg2.h)
+        auto kw = coarse_wg2_kernel<DT, false>;
+        const hipError_t e = hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_WG2_LDS_BYTES);
+        if (e != hipSuccess) return cgv_set_error_(CGV_ERR_HIP, (std::string("hipFuncSetAttribute(coarse_wg2_kernel): ") + hipGetErrorString(e)).c_str());
+        static const int per_cu = [&] {   // (measurement flavour: say once what the runtime will co-schedule)
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kw, 256, COARSE_WG2_LDS_BYTES) != hipSuccess) nb = -1;
+            fprintf(stderr, "coarse_wg2_kernel: %d workgroups of 4 waves per CU (%zu B of LDS each)\n", nb, (size_t)COARSE_WG2_LDS_BYTES);
+            return nb;
+        }();
+        (void)per_cu;
+        hipLaunchKernelGGL(kw, dim3(W), dim3(256), COARSE_WG2_LDS_BYTES, s, a);
+        return coarse_hip_status("coarse_wg2_kernel");
+    }
     if ((a.epi & 128u) != 0 && a.kc >= 4) {  // A/B: one wave per SIMD with the folded epilogue (bit 8 = its boundary-block form)
         if ((a.epi & 256u) != 0) {
             auto kw = coarse_w4_kernel<DT, false>;
