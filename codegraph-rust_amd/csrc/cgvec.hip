@@ -39,6 +39,7 @@
 #include "coarse_launch.h"
 #include "kernels_coarse.h"
 #include "kernels_exact.h"
+#include "kernels_exact_small.h"
 #include "kernels_prep.h"
 #include "kernels_select.h"
 
@@ -181,7 +182,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     std::thread::id owner;
@@ -565,9 +566,13 @@ void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint
                        c->qrows.as<char>(), qlist, nql, (uint32_t)h->n, h->D, h->ld, op, scores);
 }
 
+bool exact_small_enabled();   // (Tunables, below)
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
+// publish (optional): the caller wants the context's flag words published to the pinned mirror behind the scan (marker = the
+// value of the F_DONE word); *publish is set to false when the scan's own kernel did it (kernels_exact_small.h).
 int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t nql, uint32_t k, uint64_t* out_idx,
-                 float* out_score, hipStream_t s, int op = -1, bool local_ids = false) {
+                 float* out_score, hipStream_t s, int op = -1, bool local_ids = false, bool* publish = nullptr,
+                 uint32_t marker = 0u) {
     const IdMap idmap = local_ids ? IdMap{0, 0, 1, 0, 0} : h->idmap;
     if (op < 0)
         op = (h->metric == CGV_METRIC_DOT) ? OP_DOT
@@ -586,6 +591,49 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
         if ((rc = c->qlist.ensure((size_t)nql * 4))) return rc;
         hipLaunchKernelGGL(iota_kernel, dim3((nql + 255) / 256), dim3(256), 0, s, c->qlist.as<uint32_t>(), nql);
         qlist_dev = c->qlist.as<uint32_t>();
+    }
+    // A few queries (the trait-level call is ONE): scores, both reductions and the results in ONE kernel (kernels_exact_small.h)
+    {
+        const uint32_t G = (uint32_t)std::min<uint64_t>(256, (n + 31) / 32);   // workgroups per query: 32 rows per pass each
+        if (K <= 64 && nql <= EXACT_SMALL_MAX_Q && G >= 1 && n <= (uint64_t)EXACT_SMALL_ROWS * G && n < (1ull << 32) && exact_small_enabled()) {
+            if ((rc = c->keysA.ensure((size_t)nql * G * K * 8))) return rc;
+            if (c->xdone.bytes < (EXACT_SMALL_MAX_Q + 1) * 4) {   // arrival counters: zero once, the kernel leaves them zero
+                if ((rc = c->xdone.ensure((EXACT_SMALL_MAX_Q + 1) * 4))) return rc;
+                HIPCHK(hipMemsetAsync(c->xdone.p, 0, c->xdone.bytes, s));
+            }
+            ExactSmallArgs xa;
+            xa.rows = h->rows;
+            xa.qrows = c->qrows.as<char>();
+            xa.qlist = qlist_dev;
+            xa.nql = nql;
+            xa.n = (uint32_t)n;
+            xa.D = h->D;
+            xa.ld = h->ld;
+            xa.op = op;
+            xa.K = K;
+            xa.k = k;
+            xa.part = c->keysA.as<uint64_t>();
+            xa.done = c->xdone.as<uint32_t>();
+            xa.idmap = idmap;
+            xa.out_idx = out_idx;
+            xa.out_score = out_score;
+            xa.nan_flag = c->flags + F_NAN;
+            xa.pub_flags = c->flags;
+            xa.pub_host = (publish && *publish) ? c->h_flags_dev : nullptr;
+            xa.pub_n = (uint32_t)F_COUNT;
+            xa.pub_done_word = (uint32_t)F_DONE;
+            xa.pub_marker = marker;
+            if (xa.pub_host) *publish = false;
+            switch (h->dtype) {
+                case CGV_DTYPE_F32: hipLaunchKernelGGL(exact_small_kernel<DT_F32>, dim3(G, nql), dim3(256), 0, s, xa); break;
+                case CGV_DTYPE_BF16: hipLaunchKernelGGL(exact_small_kernel<DT_BF16>, dim3(G, nql), dim3(256), 0, s, xa); break;
+                case CGV_DTYPE_FP16: hipLaunchKernelGGL(exact_small_kernel<DT_FP16>, dim3(G, nql), dim3(256), 0, s, xa); break;
+                case CGV_DTYPE_FP8E4M3: hipLaunchKernelGGL(exact_small_kernel<DT_FP8>, dim3(G, nql), dim3(256), 0, s, xa); break;
+                default: return fail(CGV_ERR_INTERNAL, "exact path: unsupported dtype");
+            }
+            HIPCHK(hipGetLastError());
+            return CGV_OK;
+        }
     }
     for (uint32_t q0 = 0; q0 < nql; q0 += (uint32_t)qg) {
         const uint32_t g = (uint32_t)std::min<uint64_t>(qg, nql - q0);
@@ -739,6 +787,7 @@ struct Tunables {
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
+    int exact_small = CGV_ENV_INT("CGV_EXACT_SMALL", 1);      // exact scan of <= 8 queries as ONE kernel (kernels_exact_small.h; A/B: 0)
     // threshold ladder (kernels_coarse.h; MEASUREMENT FLAVOUR ONLY - a measured negative result, profiles/r05_tau_ladder_ab.txt):
     // 0 = staged launches; 1 = ladder inside the planned launches; 2 = ladder + ONE emitting launch behind the sample
     int ladder = CGV_ENV_INT("CGV_LADDER", 0);
@@ -747,6 +796,7 @@ Tunables& tun() {
     static Tunables t;
     return t;
 }
+bool exact_small_enabled() { return tun().exact_small != 0; }
 
 // Round-3 plan. The first threshold comes from a SAMPLE LAUNCH of the coarse kernel itself
 // (COARSE_SAMPLE: the first S tiles of the visiting order, one tile per CU, block maxima -> tau_kernel): as many
@@ -1241,15 +1291,19 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     // search_finish has seen the flags - cgv_search_packed_begin_f32_dev.)
     c->exact_enqueued = false;
     if (!mfma && !c->on_caller) {
-        if ((rc = exact_search(h, c, nullptr, nq, k, out_idx, out_score, s))) return rc;   // (no query list: all of them, in order)
-        c->exact_enqueued = true;
-        // flags to the pinned mirror (and cleared for the next search) by a one-wave kernel, as on the MFMA path: no
-        // copy-engine launch behind the scan, no memset in front of the next one
+        // flags to the pinned mirror (and cleared for the next search) by the scan's own kernel when it is the one-kernel form
+        // (a few queries), else by a one-wave kernel behind it, as on the MFMA path: no copy-engine launch behind the scan, no
+        // memset in front of the next one
         c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
+        bool publish = true;
+        if ((rc = exact_search(h, c, nullptr, nq, k, out_idx, out_score, s, -1, false, &publish, nq))) return rc;   // (no query list: all of them, in order)
+        c->exact_enqueued = true;
         c->published = true;
-        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
-                           (uint32_t)F_DONE, nq, (uint32_t*)nullptr, 0u);
-        HIPCHK(hipGetLastError());
+        if (publish) {
+            hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
+                               (uint32_t)F_DONE, nq, (uint32_t*)nullptr, 0u);
+            HIPCHK(hipGetLastError());
+        }
     }
     if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
     if (!c->published) HIPCHK(hipMemcpyAsync(c->h_flags, c->flags, F_COUNT * 4, hipMemcpyDeviceToHost, s));
@@ -1479,6 +1533,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "epi")) t.epi = (int)v;
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
+    else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
     else if (!strcmp(key, "ladder")) t.ladder = (int)v;
     else return -1;
     return 0;

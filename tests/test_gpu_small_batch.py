@@ -154,3 +154,38 @@ def test_single_query_calls_through_pageable_and_pinned_buffers(oracle, dtype, o
         assert np.array_equal(gi, r2i) and np.array_equal(gs, r2s)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt,metric", [("f32", 0, "cosine"), ("f32", 0, "dot"), ("bf16", 1, "cosine"), ("fp8", 3, "cosine")])
+def test_exact_scan_as_one_kernel_on_every_side_of_its_switches(oracle, dtype, odt, metric):
+    """The exact scan of <= 8 queries is ONE kernel (csrc/kernels_exact_small.h: scores, per-workgroup top-K by counting or by
+    register extraction, the last workgroup's merge over the lists with the K largest heads, results, flags). Every size class:
+    fewer rows than a pass of one workgroup, fewer than k, ragged last pass, > 256 keys per workgroup (extraction instead of
+    counting), K = 2 .. 64 (K x K = 4096 candidate keys in the merge), 8 | 9 queries (one kernel | the staged reduction),
+    duplicate rows (ties broken by the row index), a zero row and a zero query. Bit-exact against the oracle everywhere."""
+    m = pkg()
+    rng = np.random.default_rng(61)
+    d = 72                                                # not a multiple of 64 (blocked layouts pad), a multiple of 8
+    omet = oracle.COSINE if metric == "cosine" else oracle.DOT
+    for n in (5, 31, 32, 33, 1000, 8193, 70_001):
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        if n > 40:
+            rows[7] = 0.0
+            rows[n - 1] = rows[3]                         # an exact tie across two workgroups' rows
+            rows[n // 2] = rows[3]
+        ix = m.HipKnnIndex(d, dtype=dtype, metric=metric)
+        try:
+            ix.add(rows)
+            ix.set_force_exact(True)                      # (bf16 / fp8 indexes: the same scan the guarantee falls back to)
+            for nq, k in ((1, 10), (1, 1), (3, 2), (8, 16), (9, 16), (2, 17), (1, 64), (4, 50)):
+                q = rng.standard_normal((nq, d)).astype(np.float32)
+                if nq >= 3:
+                    q[1] = 0.0
+                q[0] = rows[3] if n > 3 else q[0]
+                gi, gs = ix.search(q, k)
+                ri, rs = oracle.batch_top_k(q, rows, k, metric=omet, dtype=odt)
+                assert np.array_equal(gi, ri), (dtype, metric, n, nq, k)
+                assert np.array_equal(gs, rs), (dtype, metric, n, nq, k)
+                assert ix.stats()["last_path"] == 0
+        finally:
+            ix.close()
