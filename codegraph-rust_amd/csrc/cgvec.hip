@@ -567,6 +567,15 @@ void launch_exact_scores(cgv_index* h, SearchCtx* c, const uint32_t* qlist, uint
 }
 
 bool exact_small_enabled();   // (Tunables, below)
+// Arrival counters of the kernels that finish a small search themselves (kernels_exact_small.h: [0, 8) per query, [8] finished
+// queries; rescore_body: [9]): zeroed once, every kernel leaves them zero.
+constexpr uint32_t XDONE_WORDS = 16, XDONE_PUBLISH = 9;
+int ensure_xdone(SearchCtx* c, hipStream_t s) {
+    if (c->xdone.bytes >= XDONE_WORDS * 4) return CGV_OK;
+    if (int rc = c->xdone.ensure(XDONE_WORDS * 4)) return rc;
+    HIPCHK(hipMemsetAsync(c->xdone.p, 0, c->xdone.bytes, s));
+    return CGV_OK;
+}
 // Exact full scan for the queries in qlist_dev[0..nql) (device array of query slots).
 // publish (optional): the caller wants the context's flag words published to the pinned mirror behind the scan (marker = the
 // value of the F_DONE word); *publish is set to false when the scan's own kernel did it (kernels_exact_small.h).
@@ -597,10 +606,7 @@ int exact_search(cgv_index* h, SearchCtx* c, const uint32_t* qlist_dev, uint32_t
         const uint32_t G = (uint32_t)std::min<uint64_t>(256, (n + 31) / 32);   // workgroups per query: 32 rows per pass each
         if (K <= 64 && nql <= EXACT_SMALL_MAX_Q && G >= 1 && n <= (uint64_t)EXACT_SMALL_ROWS * G && n < (1ull << 32) && exact_small_enabled()) {
             if ((rc = c->keysA.ensure((size_t)nql * G * K * 8))) return rc;
-            if (c->xdone.bytes < (EXACT_SMALL_MAX_Q + 1) * 4) {   // arrival counters: zero once, the kernel leaves them zero
-                if ((rc = c->xdone.ensure((EXACT_SMALL_MAX_Q + 1) * 4))) return rc;
-                HIPCHK(hipMemsetAsync(c->xdone.p, 0, c->xdone.bytes, s));
-            }
+            if ((rc = ensure_xdone(c, s))) return rc;
             ExactSmallArgs xa;
             xa.rows = h->rows;
             xa.qrows = c->qrows.as<char>();
@@ -788,6 +794,7 @@ struct Tunables {
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
     int exact_small = CGV_ENV_INT("CGV_EXACT_SMALL", 1);      // exact scan of <= 8 queries as ONE kernel (kernels_exact_small.h; A/B: 0)
+    int self_publish = CGV_ENV_INT("CGV_SELF_PUBLISH", 1);    // <= 64 queries: the final kernel's last workgroup publishes the flags (A/B: 0)
     // threshold ladder (kernels_coarse.h; MEASUREMENT FLAVOUR ONLY - a measured negative result, profiles/r05_tau_ladder_ab.txt):
     // 0 = staged launches; 1 = ladder inside the planned launches; 2 = ladder + ONE emitting launch behind the sample
     int ladder = CGV_ENV_INT("CGV_LADDER", 0);
@@ -1224,6 +1231,17 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.stat_maxeps = c->flags + F_MAXEPS;
         if ((rc = c->qstat.ensure((size_t)nq * 8))) return rc;
         r.qstat = c->qstat.as<uint2>();   // per-query statistics, folded into the flag words by publish_flags_kernel
+        // ... or, for a small batch, by the last workgroup of the final kernel itself (RescoreArgs::pub_*)
+        const bool self_publish = nq <= 64 && !c->boot_used && tun().self_publish;
+        r.pub_flags = c->flags;
+        r.pub_host = nullptr;
+        r.pub_count = nullptr;
+        r.pub_words = (uint32_t)F_COUNT | ((uint32_t)F_DONE << 8) | ((uint32_t)F_MAXERR << 16) | ((uint32_t)(h->shadow ? F_MAXEPS : F_COUNT) << 24);
+        if (self_publish) {
+            if ((rc = ensure_xdone(c, s))) return rc;
+            r.pub_host = c->h_flags_dev;
+            r.pub_count = c->xdone.as<uint32_t>() + XDONE_PUBLISH;
+        }
         c->h_flags[F_DONE] = 0;  // (no kernel of this context is in flight: the host may write its mirror)
         c->published = true;     // publish_flags_kernel behind the last kernel, below
 #ifdef CGV_ABLATE_BUILD
@@ -1278,11 +1296,13 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             }
         }
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(256), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
-                           (uint32_t)F_DONE, nq, c->boot_used ? c->flags + F_COUNT + PACE_WORDS : (uint32_t*)nullptr,
-                           c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u, (const uint2*)c->qstat.as<uint2>(), nq,
-                           (uint32_t)F_MAXERR, (uint32_t)(h->shadow ? F_MAXEPS : F_COUNT));
-        HIPCHK(hipGetLastError());
+        if (!self_publish) {
+            hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(256), 0, s, c->flags, c->h_flags_dev, (uint32_t)F_COUNT,
+                               (uint32_t)F_DONE, nq, c->boot_used ? c->flags + F_COUNT + PACE_WORDS : (uint32_t*)nullptr,
+                               c->boot_used ? std::min<uint32_t>(nqt * 4u, BOOT_WORDS) : 0u, (const uint2*)c->qstat.as<uint2>(), nq,
+                               (uint32_t)F_MAXERR, (uint32_t)(h->shadow ? F_MAXEPS : F_COUNT));
+            HIPCHK(hipGetLastError());
+        }
     }
     // Exact-scan-only batches (the reference's own f32 layout: BASELINE config 1, one query per call; forced exact; k beyond the
     // fast path): the scan goes onto the stream right here. Round 4 waited for the query conversion on the host first, then
@@ -1534,6 +1554,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
     else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
+    else if (!strcmp(key, "self_publish")) t.self_publish = (int)v;
     else if (!strcmp(key, "ladder")) t.ladder = (int)v;
     else return -1;
     return 0;

@@ -161,26 +161,31 @@ __device__ inline void extract_regs(LOAD load, uint32_t M, uint32_t keep, uint64
     }
 }
 
-// 4-way merge of the four sorted per-wave lists part[4][64] -> outk[0..keep), by one lane
+// 4-way merge of the four sorted per-wave lists part[4][64] -> outk[0..keep): every thread owns one entry (list tid / 64,
+// position tid % 64) and finds its rank = its position + the number of larger entries in the other three lists (a binary search
+// each: keys are unique, 0 = empty, the lists are sorted descending with the empties last) - ~20 dependent LDS reads per thread,
+// all in parallel, instead of `keep` serial rounds of four reads by one lane (round 5; the single-lane form took ~4 us of a
+// single-query call's final kernel).
 __device__ inline void merge4(const uint64_t* part, uint32_t keep, uint64_t* outk, int tid) {
     __syncthreads();
-    if (tid == 0) {
-        uint32_t h[4] = {0, 0, 0, 0};
-        for (uint32_t rd = 0; rd < keep; ++rd) {
-            uint64_t best = 0ull;
-            int bi = 0;
+    const uint32_t w = (uint32_t)tid >> 6, i = (uint32_t)tid & 63u;
+    const uint64_t v = i < keep ? part[w * 64u + i] : 0ull;
+    uint32_t rank = i;
+    if (v != 0ull) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint64_t v = h[i] < keep ? part[i * 64 + h[i]] : 0ull;
-                if (v > best) {
-                    best = v;
-                    bi = i;
-                }
+        for (uint32_t d = 1; d < 4; ++d) {
+            const uint64_t* lst = part + ((w + d) & 3u) * 64u;
+            uint32_t lo = 0, hi = keep;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (lst[mid] > v) lo = mid + 1; else hi = mid;
             }
-            h[bi]++;
-            outk[rd] = best;
+            rank += lo;
         }
     }
+    if ((uint32_t)tid < keep) outk[tid] = 0ull;
+    __syncthreads();
+    if (v != 0ull && rank < keep) outk[rank] = v;
     __syncthreads();
 }
 
@@ -402,6 +407,13 @@ struct RescoreArgs {
                             // apiece: the slowest workgroup ended 14 us behind the median (phase stamps, r05). Now a plain store
                             // per query; publish_flags_kernel folds the maxima into the flag words.
     uint64_t* trace;        // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps (100 MHz) of the phases, or NULL
+    // Small batches (<= 64 queries = <= 64 workgroups): the LAST workgroup to finish does publish_flags_kernel's job itself - one
+    // launch boundary and a 4 us kernel less on a call that is all latency (pub_host == NULL: the caller launches the kernel).
+    // (Not for large batches: 1024 returning atomics on one word cost 25 us, r03b.)
+    uint32_t* pub_flags;    // device flag words
+    uint32_t* pub_host;     // their pinned, device-mapped mirror
+    uint32_t* pub_count;    // arrival counter: zero at launch, zero again at exit
+    uint32_t pub_words;     // n_flags | done word << 8 | error word << 16 | eps word << 24; the done word's marker is nq
 };
 
 // End-of-search publication (one wave, launched behind the last kernel of a search): the flag words (fallback count,
@@ -606,7 +618,11 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         // statistics: one word for the whole batch. An unconditional atomicMax from each of the 1024 workgroups
         // serialises at ~12 ns apiece on that word; almost none of them raises the maximum, so look first (a stale
         // read only costs a redundant atomic).
-        if (a.qstat) a.qstat[q] = make_uint2(maxerr, tau_eff > -INFINITY ? __float_as_uint(eps) : 0u);
+        if (a.qstat && a.pub_host)   // (read by another workgroup of this launch: written through)
+            __hip_atomic_store((unsigned long long*)(a.qstat + q),
+                               (unsigned long long)maxerr | ((unsigned long long)(tau_eff > -INFINITY ? __float_as_uint(eps) : 0u) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (a.qstat) a.qstat[q] = make_uint2(maxerr, tau_eff > -INFINITY ? __float_as_uint(eps) : 0u);
         else if (maxerr > seen_maxerr) atomicMax(a.stat_maxerr, maxerr);
         bool fb = overflow;
         if (tau_eff > -INFINITY) {  // rows at or below tau_eff were dropped / not re-scored: check the guarantee
@@ -620,6 +636,34 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         if (fb) atomicAdd(a.fb_count, 1u);
     }
     phase_stamp(a.trace, q, 7, tid);
+    if (a.pub_host) {   // uniform: a small batch publishes its own flags (RescoreArgs::pub_*)
+        __shared__ uint32_t pub_last;
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this query's statistics / fallback count have left
+            pub_last = (__hip_atomic_fetch_add(a.pub_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.nq - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (pub_last != 0u && tid < 64) {   // nq <= 64: one statistics word pair per lane
+            uint32_t me = 0u, mp = 0u;
+            if (a.qstat && (uint32_t)tid < a.nq) {
+                const unsigned long long v = __hip_atomic_load((const unsigned long long*)(a.qstat + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                me = (uint32_t)v;
+                mp = (uint32_t)(v >> 32);
+            }
+            me = wave_max_u32(me);
+            mp = wave_max_u32(mp);
+            const uint32_t pub_n = a.pub_words & 255u, done_word = (a.pub_words >> 8) & 255u, err_word = (a.pub_words >> 16) & 255u,
+                           eps_word = a.pub_words >> 24;
+            if ((uint32_t)tid < pub_n) {
+                uint32_t v = __hip_atomic_load(a.pub_flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.qstat && (uint32_t)tid == err_word) v = v > me ? v : me;
+                if (a.qstat && (uint32_t)tid == eps_word) v = v > mp ? v : mp;
+                a.pub_host[tid] = ((uint32_t)tid == done_word) ? a.nq : v;
+                __hip_atomic_store(a.pub_flags + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) __hip_atomic_store(a.pub_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Dynamic LDS of rescore_kernel / final_kernel: [work region: staged candidate rows (and, in final_kernel, the
