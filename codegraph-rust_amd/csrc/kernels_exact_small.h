@@ -18,7 +18,7 @@
 namespace cgv {
 
 constexpr uint32_t EXACT_SMALL_ROWS = 4096;   // rows one workgroup scores at most (their keys live in LDS)
-constexpr uint32_t EXACT_SMALL_MAX_Q = 8;     // queries per launch (grid.y); larger groups keep the staged reduction
+constexpr uint32_t EXACT_SMALL_MAX_Q = 64;    // queries per launch (grid.y) at most; larger groups keep the staged reduction (host: exact_search)
 
 struct ExactSmallArgs {
     const char* rows;

@@ -161,7 +161,7 @@ def test_exact_scan_as_one_kernel_on_every_side_of_its_switches(oracle, dtype, o
     """The exact scan of <= 8 queries is ONE kernel (csrc/kernels_exact_small.h: scores, per-workgroup top-K by counting or by
     register extraction, the last workgroup's merge over the lists with the K largest heads, results, flags). Every size class:
     fewer rows than a pass of one workgroup, fewer than k, ragged last pass, > 256 keys per workgroup (extraction instead of
-    counting), K = 2 .. 64 (K x K = 4096 candidate keys in the merge), 8 | 9 queries (one kernel | the staged reduction),
+    counting), K = 2 .. 64 (K x K = 4096 candidate keys in the merge), 8 | 9 queries (one kernel | the staged reduction), 64 | 65 queries,
     duplicate rows (ties broken by the row index), a zero row and a zero query. Bit-exact against the oracle everywhere."""
     m = pkg()
     rng = np.random.default_rng(61)
@@ -177,7 +177,7 @@ def test_exact_scan_as_one_kernel_on_every_side_of_its_switches(oracle, dtype, o
         try:
             ix.add(rows)
             ix.set_force_exact(True)                      # (bf16 / fp8 indexes: the same scan the guarantee falls back to)
-            for nq, k in ((1, 10), (1, 1), (3, 2), (8, 16), (9, 16), (2, 17), (1, 64), (4, 50)):
+            for nq, k in ((1, 10), (1, 1), (3, 2), (8, 16), (9, 16), (2, 17), (1, 64), (4, 50), (64, 10), (65, 10)):
                 q = rng.standard_normal((nq, d)).astype(np.float32)
                 if nq >= 3:
                     q[1] = 0.0
