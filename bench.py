@@ -586,12 +586,14 @@ def run(args, wd, world, rank, local_rank):
                           "ms_per_batch": round(1e3 * dtp / args.pipelined_steps, 4), "batches_in_flight": depth,
                           "batches": args.pipelined_steps, "same_results_as_serial_step": same,
                           "redo_batches": (searcher.redo_batches - redo_before) if dist is not None else None,
-                          "note": ("the same work as `value` - pinned host batch read in place over PCIe, shard search, packed "
-                                   "records, all-gather, merge into pinned host arrays - with batches in flight on their own "
-                                   "streams (ShardedKnn.step_packed_begin / _end); the host waits for the oldest batch only")
+                          "note": ("the same work as `value` - pinned host batch in (fetched by the copy engine while the batches before "
+                                   "it compute), shard search, packed records, all-gather, merge into pinned host arrays - with batches in "
+                                   "flight on their own streams (ShardedKnn.step_packed_begin / _end); the host waits for the oldest "
+                                   "batch only")
                           if dist is not None else
-                          ("the same work as `value` - pinned host batch read in place over PCIe, host results written in place - "
-                           "with batches in flight (cgv_search_begin_f32_dev on the buffers' device aliases / cgv_search_end)")}
+                          ("the same work as `value` - pinned host batch in (fetched by the copy engine while the batches before it "
+                           "compute), host results written in place - with batches in flight (cgv_search_begin_f32_dev on the "
+                           "buffers' device aliases / cgv_search_end)")}
 
     # side measurement: device-resident queries and results, `depth` batches in flight (round 1's headline); N = 1 only
     pipelined = None

@@ -185,6 +185,7 @@ struct SearchCtx {
         keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
+    hipEvent_t copied = nullptr;   // batches in flight: the copy engine has fetched this batch's host queries (fetch_host_queries)
     std::thread::id owner;
     // state of the search in flight (between begin and end)
     uint32_t gen = 0, nq = 0, k = 0;
@@ -242,6 +243,7 @@ struct cgv_index {
     float* max_norm_dev = nullptr;
     uint32_t* h_flags = nullptr;  // pinned host mirror (F_COUNT words + 1 float)
     hipStream_t own_stream = nullptr, stream = nullptr;  // ingest / caller-ordering stream
+    hipStream_t copy_stream = nullptr;   // H2D of the queries of batches in flight (fetch_host_queries)
     int n_cu = 256;
     float max_norm_c = 0.0f;
     DevBuf addstage;
@@ -796,6 +798,7 @@ struct Tunables {
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
     int exact_small = CGV_ENV_INT("CGV_EXACT_SMALL", 1);      // exact scan of <= 8 queries as ONE kernel (kernels_exact_small.h; A/B: 0)
+    int fetch_queries = CGV_ENV_INT("CGV_FETCH_QUERIES", 1);  // batches in flight: host queries fetched by the copy engine (A/B: 0 = converted in place)
     int self_publish = CGV_ENV_INT("CGV_SELF_PUBLISH", 1);    // <= 64 queries: the final kernel's last workgroup publishes the flags (A/B: 0)
     // threshold ladder (kernels_coarse.h; MEASUREMENT FLAVOUR ONLY - a measured negative result, profiles/r05_tau_ladder_ab.txt):
     // 0 = staged launches; 1 = ladder inside the planned launches; 2 = ladder + ONE emitting launch behind the sample
@@ -1514,6 +1517,35 @@ int order_after_caller(cgv_index* h, SearchCtx* c) {
     return CGV_OK;
 }
 
+// Batches in flight (cgv_search_begin_f32_dev / cgv_search_packed_begin_f32_dev) whose queries sit in pinned HOST memory (the
+// caller passed the device alias): the conversion kernel reading them in place holds its waves on the CUs for the length of
+// the PCIe transfer (3 MB: 63 us) - fine for a serial call, where nothing else wants the device, but with batches in flight that
+// conversion runs beside the other batches' kernels or, worse, while nothing computes (profiles/r05_batches_in_flight_traces.txt).
+// Here the copy engine fetches the batch on the handle's copy stream, issued at once (it runs under whatever the device is
+// computing), and the batch's stream waits for it: the conversion then reads HBM (5 us). Returns the pointer to convert from
+// (the staging copy, or q itself: device memory, small batches, A/B knob off).
+constexpr size_t FETCH_MIN_BYTES = 256u << 10;
+const float* fetch_host_queries(cgv_index* h, SearchCtx* c, const float* q, uint32_t nq, hipStream_t s, int* rc) {
+    *rc = CGV_OK;
+    const size_t bytes = (size_t)nq * h->D * 4;
+    if (bytes < FETCH_MIN_BYTES || !tun().fetch_queries) return q;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+        (void)hipGetLastError();
+        return q;
+    }
+    if (at.type != hipMemoryTypeHost || !at.hostPointer) return q;
+    if ((*rc = c->qstage.ensure(bytes))) return q;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && *rc == CGV_OK) *rc = fail(CGV_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    chk(hipMemcpyAsync(c->qstage.p, at.hostPointer, bytes, hipMemcpyHostToDevice, h->copy_stream), "hipMemcpyAsync(queries)");
+    chk(hipEventRecord(c->copied, h->copy_stream), "hipEventRecord");
+    chk(hipStreamWaitEvent(s, c->copied, 0), "hipStreamWaitEvent");
+    return *rc ? q : c->qstage.as<float>();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1557,6 +1589,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
     else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
     else if (!strcmp(key, "self_publish")) t.self_publish = (int)v;
+    else if (!strcmp(key, "fetch_queries")) t.fetch_queries = (int)v;
     else if (!strcmp(key, "ladder")) t.ladder = (int)v;
     else return -1;
     return 0;
@@ -1622,6 +1655,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         h->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->flags, F_COUNT * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&h->max_norm_dev, 4);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, (F_COUNT + 3) * 4);
@@ -1631,6 +1665,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.packed_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.copied, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
@@ -1675,6 +1710,7 @@ int cgv_destroy(cgv_index* h) {
         if (c.h_stage) (void)hipHostFree(c.h_stage);
         if (c.dep) (void)hipEventDestroy(c.dep);
         if (c.packed_done) (void)hipEventDestroy(c.packed_done);
+        if (c.copied) (void)hipEventDestroy(c.copied);
         for (int i = 0; i < 4; ++i)
             if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1683,6 +1719,7 @@ int cgv_destroy(cgv_index* h) {
     if (h->max_norm_dev) (void)hipFree(h->max_norm_dev);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
     return CGV_OK;
 }
@@ -1973,9 +2010,12 @@ int cgv_search_begin_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq
     if (!c)
         return fail(CGV_ERR_BUSY, "this thread already holds all " + std::to_string(N_CTX) +
                                       " search contexts of the handle: call cgv_search_end on one of its tickets first");
-    if ((rc = order_after_caller(h, c)) == CGV_OK)
-        rc = search_enqueue(h, c, queries_dev, nq, k, out_idx_dev, out_score_dev);
+    if ((rc = order_after_caller(h, c)) == CGV_OK) {
+        const float* qsrc = fetch_host_queries(h, c, queries_dev, nq, c->stream, &rc);
+        if (rc == CGV_OK) rc = search_enqueue(h, c, qsrc, nq, k, out_idx_dev, out_score_dev);
+    }
     if (rc) {
+        (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamSynchronize(c->stream);
         c->busy = false;
         dev_inflight_add(h, -1);
@@ -2045,7 +2085,9 @@ int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint
             HIPCHK(hipEventRecord(c->dep, h->stream));
             HIPCHK(hipStreamWaitEvent(c->run, c->dep, 0));
         }
-        if ((r = search_enqueue(h, c, queries_dev, nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>()))) return r;
+        const float* qsrc = fetch_host_queries(h, c, queries_dev, nq, c->run, &r);
+        if (r) return r;
+        if ((r = search_enqueue(h, c, qsrc, nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>()))) return r;
         // exact-scan-only batches (f32 index, forced exact, k beyond the fast path) are produced by search_finish: every
         // record is provisional. An empty index pads its results at enqueue time: final.
         const bool all_prov = !c->mfma;
@@ -2058,6 +2100,7 @@ int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint
     };
     rc = body();
     if (rc) {
+        (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamSynchronize(c->run);
         c->on_caller = false;
         c->busy = false;
