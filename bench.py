@@ -43,8 +43,30 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# Hardware queues of the HIP runtime (read when the runtime starts: before torch is imported). Its default of 4 is shared by every
+# stream of the process - torch's, RCCL's, the library's - and with batches in flight on ONE index two of the handle's three context
+# streams then share a queue: their batches run one after the other (kernel traces: profiles/r05_batches_in_flight_traces.txt; 125 k-row
+# shard, `pipelined_host` 0.259 -> 0.23 ms with 8 queues). The rank program of the N > 1 form keeps the default: its batches run on torch
+# streams beside the collective's, and there 8 queues measured WORSE (one rank over RCCL, same box: 0.225 -> 0.252 ms). An
+# application-level setting like HSA_ENABLE_IPC_MODE_LEGACY; the serial `value` does not depend on it; reported in config.runtime_env.
+# (setdefault: an operator's own value wins.)
+
+
+def _rank_program():
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or "--force-dist" in sys.argv:
+        return True
+    for i, a in enumerate(sys.argv):
+        v = a.split("=", 1)[1] if a.startswith("--gpus=") else (sys.argv[i + 1] if a == "--gpus" and i + 1 < len(sys.argv) else None)
+        if v is not None and v.isdigit() and int(v) > 1:
+            return True
+    return False
+
+
+if not _rank_program():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -738,7 +760,8 @@ def run(args, wd, world, rank, local_rank):
                                    f"batch={batch}, k={k}", "rows": n_total, "dim": dim, "batch": batch, "k": k,
                        "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
                        "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
-                       "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none"},
+                       "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none",
+                       "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}},
             "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
             "step_ms_percentiles": {p_: round(float(np.percentile(step_ms, p_)), 4) for p_ in (1, 10, 50, 90, 99, 100)},
             "pipelined_host_qps": pipelined_host["queries_per_sec"] if pipelined_host else None,

@@ -80,8 +80,9 @@ def main():
               f"{med(tb):.1f} us, of end (wait) {med(te):.1f} us; begin -> end of wait {med(tot):.1f} us")
 
     ix.use_own_stream()
-    L.cgv_debug_set_.argtypes = [C.c_char_p, C.c_double]
-    knob = os.environ.get("PROBE_KNOB")          # measurement flavour (CGV_LIB_PATH=..._ablate.so): A/B of one 0 / 1 knob
+    knob = os.environ.get("PROBE_KNOB")
+    if knob:
+        L.cgv_debug_set_.argtypes = [C.c_char_p, C.c_double]          # measurement flavour (CGV_LIB_PATH=..._ablate.so): A/B of one 0 / 1 knob
     for v in ((1, 0, 1, 0) if knob else (None, None)):
         if knob:
             assert L.cgv_debug_set_(knob.encode(), float(v)) == 0, knob
