@@ -651,14 +651,16 @@ def test_pipelined_join_free_step_redo_while_other_batches_are_in_flight(oracle)
         ix.close()
 
 
-def test_host_in_host_out_batches_in_flight_on_one_index(oracle):
+@pytest.mark.parametrize("nq", [270, 700])
+def test_host_in_host_out_batches_in_flight_on_one_index(oracle, nq):
     """HipKnnIndex.search_begin_pinned: cgv_search_begin_f32_dev on the device aliases of pinned host buffers - the same work
-    as cgv_search_f32 (pinned batch read in place over PCIe, results written in place), max_in_flight batches deep; a query
-    that needs the exact scan is rewritten in place by the batch's end."""
+    as cgv_search_f32 (results written in place), max_in_flight batches deep; a query that needs the exact scan is rewritten in
+    place by the batch's end. 270 queries x 96 x 4 B = 104 KB: read in place over PCIe by the conversion kernel; 700 = 269 KB
+    (>= 256 KB): fetched by the copy engine on the handle's copy stream while the batches before it compute (fetch_host_queries)."""
     import torch
     m = pkg()
     rng = np.random.default_rng(31)
-    n, d, nq, k = 30_000, 96, 270, 10
+    n, d, k = 30_000, 96, 10
     rows = rng.standard_normal((n, d)).astype(np.float32)
     rows[12_000:12_050] = rows[5] * (1 + 1e-4 * rng.standard_normal((50, 1)).astype(np.float32))
     ix = m.HipKnnIndex(d, dtype="bf16")
