@@ -270,6 +270,10 @@ def main():
                          "work as a step (pinned host batch in, host results out, exchange + merge included when N > 1) with "
                          "`--depth` batches in flight; N = 1 also `pipelined` = device-resident batches, the round-1 headline")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight of the pipelined side measurements (<= 3)")
+    ap.add_argument("--callers", type=int, default=3,
+                    help="N = 1 side measurement `concurrent_callers`: this many host THREADS, each issuing serial cgv_search_f32 calls on its "
+                         "own pinned buffers against the one index (the reference's threading model: a Send + Sync store called from a "
+                         "multi-thread runtime); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--cpu-max-queries", type=int, default=128)
     ap.add_argument("--check-queries", type=int, default=32,
@@ -634,6 +638,58 @@ def run(args, wd, world, rank, local_rank):
         pipelined = {"queries_per_sec": round(batch * args.pipelined_steps / dtp, 1),
                      "ms_per_batch": round(1e3 * dtp / args.pipelined_steps, 4), "batches_in_flight": depth,
                      "note": "queries and results stay in HBM (cgv_search_begin_f32_dev / cgv_search_end)"}
+    # side measurement: several host threads, each in its own serial cgv_search_f32 loop on the ONE index - what a server built on
+    # the reference's traits does (VectorStore is Send + Sync, called from a multi-thread tokio runtime through spawn_blocking;
+    # SURVEY.md section 8(b) threading): the handle's three search contexts overlap the callers' batches on the device
+    concurrent = None
+    if dist is None and args.callers > 1 and args.pipelined_steps > 0:
+        import threading
+        T = min(args.callers, ix.max_in_flight)
+        per = max(10, args.pipelined_steps // T)
+        tb = [(qhost[t % npool], torch.empty((batch, k), dtype=torch.int64).pin_memory(),
+               torch.empty((batch, k), dtype=torch.float32).pin_memory()) for t in range(T)]
+        gate = threading.Barrier(T + 1)
+        errs = []
+
+        def caller(t):
+            q_, oi_, os__ = tb[t]
+            try:
+                for _ in range(3):
+                    ix.search_host_ptr(q_.data_ptr(), batch, k, oi_.data_ptr(), os__.data_ptr())
+                gate.wait()
+                for _ in range(per):
+                    ix.search_host_ptr(q_.data_ptr(), batch, k, oi_.data_ptr(), os__.data_ptr())
+            except Exception as e:   # noqa: BLE001 - reported in the line
+                errs.append(f"{type(e).__name__}: {e}")
+                try:
+                    gate.abort()
+                except Exception:   # noqa: BLE001
+                    pass
+
+        ths = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+        for th in ths:
+            th.start()
+        try:
+            gate.wait()
+        except threading.BrokenBarrierError:
+            pass
+        tp = time.perf_counter()
+        for th in ths:
+            th.join()
+        sync_all()
+        dtc = time.perf_counter() - tp
+        same_c = not errs
+        for t in range(T):     # each caller's last results against a lone serial step on the same queries
+            step(t % npool)
+            same_c = same_c and bool(torch.equal(tb[t][1], out_i) and torch.equal(tb[t][2], out_s))
+        concurrent = {"threads": T, "calls_per_thread": per, "queries_per_sec": round(batch * T * per / dtc, 1),
+                      "ms_per_batch": round(1e3 * dtc / (T * per), 4), "same_results_as_serial_step": same_c,
+                      "errors": errs or None,
+                      "note": "host threads in serial cgv_search_f32 loops on one index (pinned host batch in, host results out: the same "
+                              "work as `value` per call); the library fetches a caller's batch with the copy engine while other callers' "
+                              "batches compute"}
+        wd.kick("concurrent callers")
+
     # side measurement: latency of SMALL calls through the host boundary - what a Rust caller swapping this backend in issues
     # from SemanticSearch::search_by_embedding (search.rs:114-117 -> surreal_store.rs:61-85 -> traits.rs:14): ONE query per call.
     # Median microseconds of cgv_search_f32 at nq = 1 / 8 / 32 with pageable buffers (a Rust Vec<f32>; what host/store.cpp hands
@@ -766,6 +822,7 @@ def run(args, wd, world, rank, local_rank):
             "step_ms_percentiles": {p_: round(float(np.percentile(step_ms, p_)), 4) for p_ in (1, 10, 50, 90, 99, 100)},
             "pipelined_host_qps": pipelined_host["queries_per_sec"] if pipelined_host else None,
             "pipelined_host": pipelined_host,
+            "concurrent_callers": concurrent,
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
             "pipelined": pipelined,
             "hbm_resident_serial": resident,

@@ -2204,6 +2204,16 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
         if (!qsrc) {
             HIPCHK(hipMemcpyAsync(c->qstage.p, queries_host, qbytes, hipMemcpyHostToDevice, s));
             qsrc = c->qstage.as<float>();
+        } else if (!small_q) {
+            // several threads in cgv_search_f32 at once (a Send + Sync store called from a multi-thread runtime): other batches are
+            // computing, so this one's pinned queries come by the copy engine instead of holding conversion waves on the CUs
+            // for the length of the PCIe transfer (fetch_host_queries); a lone call reads them in place
+            int busy = 0;
+            for (const SearchCtx& o : h->ctx) busy += o.busy ? 1 : 0;
+            if (busy > 1) {
+                qsrc = fetch_host_queries(h, c, qsrc, nq, s, &r);
+                if (r) return r;
+            }
         }
         stamp(1);
         if ((r = search_enqueue(h, c, qsrc, nq, k, oi, os))) return r;
