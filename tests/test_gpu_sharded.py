@@ -688,3 +688,51 @@ def test_host_in_host_out_batches_in_flight_on_one_index(oracle, nq):
             ix.search_begin_pinned(torch.from_numpy(qs[0]), k, outs[0])   # pageable memory is refused
     finally:
         ix.close()
+
+
+def test_concurrent_callers_with_pinned_batches(oracle):
+    """The reference's threading model (traits are Send + Sync, called from a multi-thread runtime): several host threads, each in
+    its own serial cgv_search_f32 loop on ONE index, pinned host buffers in and out. While another caller's batch is computing,
+    a call's batch (>= 256 KB) is fetched by the copy engine instead of being read in place (cgv_search_f32 -> fetch_host_queries);
+    every call of every thread returns the oracle's answer, fallback queries included."""
+    import threading
+
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(37)
+    n, d, nq, k, T, calls = 30_000, 96, 700, 10, 3, 12
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[9_000:9_040] = rows[11] * (1 + 1e-4 * rng.standard_normal((40, 1)).astype(np.float32))
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        qs = [rng.standard_normal((nq, d)).astype(np.float32) for _ in range(T)]
+        qs[1][5] = rows[11]                                   # a query the device cannot prove: answered by the exact scan
+        want = [oracle.batch_top_k(q, rows, k, dtype=1) for q in qs]
+        qp = [torch.from_numpy(q).pin_memory() for q in qs]
+        outs = [(torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory())
+                for _ in range(T)]
+        bad = []
+        gate = threading.Barrier(T)
+
+        def caller(t):
+            try:
+                gate.wait()
+                for c in range(calls):
+                    outs[t][0].zero_()
+                    ix.search_host_ptr(qp[t].data_ptr(), nq, k, outs[t][0].data_ptr(), outs[t][1].data_ptr())
+                    if not (np.array_equal(outs[t][0].numpy().view(np.uint64), want[t][0]) and
+                            np.array_equal(outs[t][1].numpy(), want[t][1])):
+                        bad.append((t, c))
+            except Exception as e:   # noqa: BLE001
+                bad.append((t, repr(e)))
+
+        ths = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not bad, bad[:4]
+        assert ix.stats()["fallback_queries"] >= calls
+    finally:
+        ix.close()
