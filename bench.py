@@ -460,6 +460,17 @@ def run(args, wd, world, rank, local_rank):
             searcher.step_packed(qhost[i % npool], k, out=(out_i, out_s), device=dev)
             exchange_ms.append(searcher.last_exchange_ms)
 
+    # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection walks
+    # ~10^6 objects (tens of milliseconds) - one of them inside a 200-step region of 1.4 ms steps showed up as a mean 12 % above
+    # the median (r05 first run: 1.532 vs 1.362 ms; round 4's runs happened not to catch one). Everything allocated so far is
+    # frozen out of the collector's sight; it runs again, explicitly, between the measurements. It is done HERE, in front of the
+    # settle loop and the warm-up, not between the warm-up and the timed steps: the collection idles the GPU for tens of
+    # milliseconds, the clocks drop, and the first ~20 steps behind it run 5-20 % slow - invisible in 200 steps, but a driver run
+    # of `--steps 20` measured 696 k q/s where 200 steps gave 749 k on the same box.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     if args.settle_ms > 0:   # steady-state clocks before anything is measured (setup, like the index build)
         ts = time.perf_counter()
         i = 0
@@ -477,14 +488,6 @@ def run(args, wd, world, rank, local_rank):
     for i in range(args.warmup):
         step(i)
     wd.kick("warm-up done")
-    # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection walks
-    # ~10^6 objects (tens of milliseconds) - one of them inside a 200-step region of 1.4 ms steps showed up as a mean 12 % above
-    # the median (r05 first run: 1.532 vs 1.362 ms; round 4's runs happened not to catch one). Everything allocated so far is
-    # frozen out of the collector's sight; it runs again, explicitly, between the measurements.
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
     sync_all()
     coarse_ms, coarse_rows, step_ms = [], 0, []
     t0 = time.perf_counter()
@@ -588,10 +591,10 @@ def run(args, wd, world, rank, local_rank):
                     hend(pend.popleft())
             while pend:
                 hend(pend.popleft())
+        gc.collect()     # (in front of the warm batches: nothing idles the device between them and the timed ones)
         run_piped(max(depth, min(args.warmup, 10)))
         wd.kick("pipelined_host warm")
         redo_before = searcher.redo_batches if dist is not None else 0
-        gc.collect()
         sync_all()
         tp = time.perf_counter()
         run_piped(args.pipelined_steps)
