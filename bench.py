@@ -501,6 +501,8 @@ def run(args, wd, world, rank, local_rank):
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     gc.collect()
+    if os.environ.get("BENCH_DEBUG_STEPS"):   # (diagnostics: where in the timed region the slow steps sit)
+        print("step_ms:", " ".join(f"{x:.3f}" for x in step_ms), file=sys.stderr, flush=True)
     wd.kick("timed steps done")
     ix.set_profiling(2)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step)
     step(0)
