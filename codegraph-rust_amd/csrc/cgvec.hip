@@ -1523,12 +1523,17 @@ int order_after_caller(cgv_index* h, SearchCtx* c) {
 // conversion runs beside the other batches' kernels or, worse, while nothing computes (profiles/r05_batches_in_flight_traces.txt).
 // Here the copy engine fetches the batch on the handle's copy stream, issued at once (it runs under whatever the device is
 // computing), and the batch's stream waits for it: the conversion then reads HBM (5 us). Returns the pointer to convert from
-// (the staging copy, or q itself: device memory, small batches, A/B knob off).
+// (the staging copy, or q itself: device memory, small batches, no other batch in flight, A/B knob off).
 constexpr size_t FETCH_MIN_BYTES = 256u << 10;
 const float* fetch_host_queries(cgv_index* h, SearchCtx* c, const float* q, uint32_t nq, hipStream_t s, int* rc) {
     *rc = CGV_OK;
     const size_t bytes = (size_t)nq * h->D * 4;
     if (bytes < FETCH_MIN_BYTES || !tun().fetch_queries) return q;
+    // only while another batch of the handle is in flight (caller holds mu): a lone batch has nothing to run under, and the copy's
+    // launch + the event hop cost it 4-10 us (serial begin / end pairs on the 125 k-row shard: 0.3135 -> 0.320 ms with the fetch)
+    int busy = 0;
+    for (const SearchCtx& o : h->ctx) busy += o.busy ? 1 : 0;
+    if (busy <= 1) return q;
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
     if (hipPointerGetAttributes(&at, q) != hipSuccess) {
@@ -2208,12 +2213,8 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
             // several threads in cgv_search_f32 at once (a Send + Sync store called from a multi-thread runtime): other batches are
             // computing, so this one's pinned queries come by the copy engine instead of holding conversion waves on the CUs
             // for the length of the PCIe transfer (fetch_host_queries); a lone call reads them in place
-            int busy = 0;
-            for (const SearchCtx& o : h->ctx) busy += o.busy ? 1 : 0;
-            if (busy > 1) {
-                qsrc = fetch_host_queries(h, c, qsrc, nq, s, &r);
-                if (r) return r;
-            }
+            qsrc = fetch_host_queries(h, c, qsrc, nq, s, &r);
+            if (r) return r;
         }
         stamp(1);
         if ((r = search_enqueue(h, c, qsrc, nq, k, oi, os))) return r;
