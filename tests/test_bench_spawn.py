@@ -24,3 +24,27 @@ def test_bench_under_launcher_uses_the_given_world():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert json.loads(p.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_hardware_queue_setting_is_for_the_single_index_form_only():
+    """bench.py asks the HIP runtime for 8 hardware queues (GPU_MAX_HW_QUEUES, before torch is imported) in the single-index form
+    and leaves the rank program - any WORLD_SIZE > 1, --gpus N > 1, --force-dist - on the runtime's default, where 8 measured
+    worse; an operator's own value always wins."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.argv = ['bench.py'] + {argv!r}; import bench; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+
+    def run(argv, **env):
+        e = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code.format(argv=argv)], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        return out.stdout.strip().splitlines()[-1]
+
+    assert run([]) == "8"
+    assert run(["--gpus", "1", "--steps", "20"]) == "8"
+    assert run(["--gpus", "8"]) == "None"
+    assert run(["--gpus=2"]) == "None"
+    assert run(["--gpus", "1", "--force-dist"]) == "None"
+    assert run(["--gpus", "1"], WORLD_SIZE="4") == "None"
+    assert run([], GPU_MAX_HW_QUEUES="2") == "2"
