@@ -136,6 +136,41 @@ def storage_values(x, dtype):
     return torch.ldexp(x, e).to(torch.float8_e4m3fn).float()
 
 
+def load_callers_lib(m):
+    """tests/c_client/callers.c as a shared library: T NATIVE caller threads, each in a serial loop of small cgv_search_f32 calls
+    (a Rust host's spawn_blocking threads; Python threads would serialise on the interpreter lock between their calls).
+    Measurement infrastructure: built by __graft_entry__.build(), or here on demand."""
+    import ctypes as C
+    src = os.path.join(ROOT, "tests", "c_client", "callers.c")
+    so = os.path.join(ROOT, "tests", "c_client", "libcgv_callers.so")
+    libdir = os.path.dirname(m.cgvec.LIB_PATH)
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"),
+                               src, "-o", so, "-L", libdir, "-lcgvec_hip", "-Wl,-rpath,$ORIGIN/../../codegraph-rust_amd/lib"])
+    m.cgvec.lib()
+    L = C.CDLL(so)
+    L.cgv_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_char_p]
+    L.cgv_callers_run.restype = C.c_int
+    return L
+
+
+def run_native_callers(CL, ix, q, k, threads, calls, warm=3, nq_per_call=1):
+    """-> (ids [threads*calls, nq_per_call, k], scores, per-call latency in us, wall seconds)"""
+    import ctypes as C
+    ncalls = threads * calls
+    oi = np.empty((ncalls, nq_per_call, k), dtype=np.uint64)
+    os_ = np.empty((ncalls, nq_per_call, k), dtype=np.float32)
+    lat = np.zeros(ncalls, dtype=np.float64)
+    wall = C.c_double(0)
+    err = C.create_string_buffer(256)
+    rc = CL.cgv_callers_run(ix._h, q.ctypes.data, q.shape[0], q.shape[1], k, threads, calls, warm, nq_per_call, oi.ctypes.data,
+                            os_.ctypes.data, lat.ctypes.data, C.byref(wall), err)
+    if rc:
+        raise RuntimeError(f"cgv_callers_run: status {rc}: {err.value.decode(errors='replace')}")
+    return oi, os_, lat, wall.value
+
+
 def gen_chunk(c, rows, dim, device):
     g = torch.Generator(device=device).manual_seed(SEED_CORPUS + c)
     x = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
@@ -300,6 +335,12 @@ def main():
     ap.add_argument("--dist-timeout", type=float, default=180.0,
                     help="seconds: process-group timeout AND the no-progress limit of the watchdog - a hung collective ends the "
                          "run with a JSON line carrying an `error` field instead of hanging the launcher")
+    ap.add_argument("--coalesced-threads", type=int, default=64,
+                    help="N = 1 side measurement `coalesced_callers`: this many NATIVE host threads (tests/c_client/callers.c), each in a "
+                         "serial loop of SINGLE-query cgv_search_f32 calls on the one index - the reference's trait-level call shape "
+                         "(traits.rs:14; search.rs:358-361 issues B of them concurrently); the library merges concurrent callers into "
+                         "shared device batches (csrc/coalesce.h). 0 = skip")
+    ap.add_argument("--coalesced-calls", type=int, default=0, help="calls per thread of `coalesced_callers` (0 = sized for ~0.3 s)")
     ap.add_argument("--latency", type=int, default=1,
                     help="N = 1: side fields with the median latency of nq = 1 / 8 / 32 searches through cgv_search_f32 (pageable "
                          "and pinned buffers) on this workload's index (0 = skip)")
@@ -695,6 +736,57 @@ def run(args, wd, world, rank, local_rank):
                               "batches compute"}
         wd.kick("concurrent callers")
 
+    # side measurement: the reference's call shape at scale - T native threads, each in a serial loop of SINGLE-query calls on
+    # the one index (VectorStore::search_similar is one query, traits.rs:14; multi_vector_search issues B concurrent single-query
+    # searches, search.rs:358-361). A lone call streams the whole corpus for one query column; concurrent callers are merged into
+    # shared device batches of up to 64 queries by the library (csrc/coalesce.h) - `lone` is the same loop with ONE thread.
+    coalesced = None
+    if dist is None and args.coalesced_threads > 1 and st["last_path"] in (0, 1):
+        try:
+            CL = load_callers_lib(m)
+            T = args.coalesced_threads
+            qall = np.ascontiguousarray(torch.cat(qpool).cpu().numpy())[: max(64, min(4096, npool * batch))]
+            lone_calls = 200 if n_total <= 2_000_000 else 30
+            _, _, lat1, wall1 = run_native_callers(CL, ix, qall, k, 1, lone_calls)
+            lone_p50 = float(np.median(lat1))
+            calls = args.coalesced_calls or int(max(30, min(2000, 0.3 / max(lone_p50 * 1e-6, 1e-6) * 40.0 / T)))
+            cs0 = ix.coalesce_stats()
+            gc.collect()
+            ci, csc, latc, wallc = run_native_callers(CL, ix, qall, k, T, calls)
+            cs1 = ix.coalesce_stats()
+            # every 37th call (and each thread's last one) against a LONE call of the same query (merging switched off)
+            ix.set_coalesce(0, 0, 0)
+            sample = sorted(set(range(0, T * calls, 37)) | {t * calls + calls - 1 for t in range(T)})[:400]
+            same_cc = True
+            li, ls = np.empty((1, k), dtype=np.uint64), np.empty((1, k), dtype=np.float32)
+            for c_ in sample:
+                ix.search_host_ptr(qall[c_ % qall.shape[0]].ctypes.data, 1, k, li.ctypes.data, ls.ctypes.data)
+                same_cc = same_cc and bool(np.array_equal(li[0], ci[c_, 0]) and np.array_equal(ls[0], csc[c_, 0]))
+            ix.set_coalesce(64, 2, 0)
+            nb = max(1, cs1["batches"] - cs0["batches"])
+            coalesced = {
+                "threads": T, "calls_per_thread": calls, "nq_per_call": 1,
+                "queries_per_sec": round(T * calls / wallc, 1),
+                "call_us": {"p50": round(float(np.percentile(latc, 50)), 1), "p90": round(float(np.percentile(latc, 90)), 1),
+                            "p99": round(float(np.percentile(latc, 99)), 1), "max": round(float(latc.max()), 1)},
+                "lone": {"queries_per_sec": round(lone_calls / wall1, 1), "p50_us": round(lone_p50, 1),
+                         "p99_us": round(float(np.percentile(lat1, 99)), 1), "calls": lone_calls},
+                "p50_vs_lone_p50": round(float(np.percentile(latc, 50)) / lone_p50, 3),
+                "speedup_vs_lone_caller": round((T * calls / wallc) / (lone_calls / wall1), 1),
+                "device_batches": cs1["batches"] - cs0["batches"],
+                "avg_queries_per_batch": round((cs1["batched_queries"] - cs0["batched_queries"]) / nb, 1),
+                "calls_that_ran_alone": cs1["lone_calls"] - cs0["lone_calls"],
+                "retried_alone": cs1["retried_alone"] - cs0["retried_alone"],
+                "same_results_as_lone_calls": same_cc, "checked_calls": len(sample),
+                "corpus_stream_gb_per_s": round(float(n_total) * dim * ESIZE[dtype] * nb / wallc / 1e9, 1),
+                "note": "native threads (tests/c_client/callers.c), each in a serial loop of single-query cgv_search_f32 calls with "
+                        "pageable buffers; concurrent callers share device batches (group commit, csrc/coalesce.h: <= 64 queries per "
+                        "batch, <= 2 batches on the device, no time window); `lone` = the same loop with one thread; checked calls are "
+                        "compared bit for bit with lone calls of the same queries"}
+        except Exception as e:   # noqa: BLE001 - a side measurement never takes the line down
+            coalesced = {"error": f"{type(e).__name__}: {e}"}
+        wd.kick("coalesced callers")
+
     # side measurement: latency of SMALL calls through the host boundary - what a Rust caller swapping this backend in issues
     # from SemanticSearch::search_by_embedding (search.rs:114-117 -> surreal_store.rs:61-85 -> traits.rs:14): ONE query per call.
     # Median microseconds of cgv_search_f32 at nq = 1 / 8 / 32 with pageable buffers (a Rust Vec<f32>; what host/store.cpp hands
@@ -828,6 +920,7 @@ def run(args, wd, world, rank, local_rank):
             "pipelined_host_qps": pipelined_host["queries_per_sec"] if pipelined_host else None,
             "pipelined_host": pipelined_host,
             "concurrent_callers": concurrent,
+            "coalesced_callers": coalesced,
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
             "pipelined": pipelined,
             "hbm_resident_serial": resident,

@@ -149,6 +149,10 @@ def lib():
     L.cgv_sharded_force_exchange.restype = i32
     L.cgv_set_spin_us.argtypes = [vp, u32]
     L.cgv_set_spin_us.restype = i32
+    L.cgv_set_coalesce.argtypes = [vp, u32, u32, u32]
+    L.cgv_set_coalesce.restype = i32
+    L.cgv_get_coalesce_stats.argtypes = [vp, C.POINTER(u64)]
+    L.cgv_get_coalesce_stats.restype = i32
     L.cgv_alloc_pinned.argtypes = [C.c_size_t]
     L.cgv_alloc_pinned.restype = vp
     L.cgv_free_pinned.argtypes = [vp]
@@ -260,6 +264,16 @@ class HipKnnIndex:
     def set_spin_us(self, us):
         """How long the end of a search polls its stream before it blocks (cgv_set_spin_us; default 3000, 0 = block at once)."""
         _check(lib().cgv_set_spin_us(self._h, int(us)))
+
+    def set_coalesce(self, max_batch_queries=64, max_batches_in_flight=2, window_us=0):
+        """Group commit of concurrent small search calls (cgv_set_coalesce); max_batch_queries = 0 switches it off."""
+        _check(lib().cgv_set_coalesce(self._h, int(max_batch_queries), int(max_batches_in_flight), int(window_us)))
+
+    def coalesce_stats(self):
+        out = (C.c_uint64 * 8)()
+        _check(lib().cgv_get_coalesce_stats(self._h, out))
+        names = ("batches", "batched_requests", "batched_queries", "lone_calls", "retried_alone", "max_batch_queries", "window_waits")
+        return {n: int(out[i]) for i, n in enumerate(names)}
 
     def synchronize(self):
         _check(lib().cgv_synchronize(self._h))

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/cgvec.h"
+#include "coalesce.h"
 #include "common.h"
 #include "coarse_launch.h"
 #include "kernels_coarse.h"
@@ -158,6 +159,7 @@ uint32_t kprime_of(uint32_t k) {
 struct SearchCtx {
     hipStream_t stream = nullptr;  // owned, non-blocking
     hipEvent_t dep = nullptr;      // ordering after the caller's stream (ingest, query producer)
+    hipEvent_t dep_run = nullptr;  // packed searches: ordering of the copy-engine fetch after earlier work on the consumer's stream
     uint32_t* rec_out = nullptr;   // cgv_search_packed_begin_f32_dev: the caller's record buffer of the batch in flight (NULL: not a packed search)
     // cgv_search_packed_begin_f32_dev runs the WHOLE batch on the consumer's stream (no hop onto `stream` and back: two
     // cross-stream event waits, ~7 us each on this part, per batch of the N > 1 step): `run` is that stream while `on_caller`
@@ -204,7 +206,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -212,7 +214,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -257,7 +259,12 @@ struct cgv_index {
     bool last_top2 = false;   // the last finished search took the small-batch form (cgv_debug_last_top2_)
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
-    cgv_index() { memset(&st, 0, sizeof(st)); }
+    Coalescer co;   // group commit of concurrent small cgv_search_f32 calls (coalesce.h)
+    cgv_index() {
+        memset(&st, 0, sizeof(st));
+        co.max_q_bytes = SMALL_Q_BYTES;
+        co.max_out_bytes = SMALL_OUT_BYTES;
+    }
 };
 
 namespace {
@@ -1545,6 +1552,14 @@ const float* fetch_host_queries(cgv_index* h, SearchCtx* c, const float* q, uint
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && *rc == CGV_OK) *rc = fail(CGV_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
+    // the copy is ordered like the conversion kernel it replaces: after what the caller queued on the handle's stream (c->dep,
+    // recorded by order_after_caller / the packed begin) and after earlier work on the stream the batch runs on - a query batch
+    // produced asynchronously (a non-blocking D2H into the pinned buffer, say) must not be fetched stale
+    chk(hipStreamWaitEvent(h->copy_stream, c->dep, 0), "hipStreamWaitEvent(copy, dep)");
+    if (c->on_caller) {
+        chk(hipEventRecord(c->dep_run, s), "hipEventRecord(dep_run)");
+        chk(hipStreamWaitEvent(h->copy_stream, c->dep_run, 0), "hipStreamWaitEvent(copy, dep_run)");
+    }
     chk(hipMemcpyAsync(c->qstage.p, at.hostPointer, bytes, hipMemcpyHostToDevice, h->copy_stream), "hipMemcpyAsync(queries)");
     chk(hipEventRecord(c->copied, h->copy_stream), "hipEventRecord");
     chk(hipStreamWaitEvent(s, c->copied, 0), "hipStreamWaitEvent");
@@ -1555,7 +1570,7 @@ const float* fetch_host_queries(cgv_index* h, SearchCtx* c, const float* q, uint
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 6u; }  // 0.6: + cgv_set_spin_us, cgv_sharded_force_exchange (no environment reads)
+uint32_t cgv_version(void) { return (0u << 16) | 7u; }  // 0.7: + cgv_set_coalesce, cgv_get_coalesce_stats
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
@@ -1669,6 +1684,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
     for (SearchCtx& c : h->ctx) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.dep_run, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.packed_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.copied, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
@@ -1714,6 +1730,7 @@ int cgv_destroy(cgv_index* h) {
         if (c.h_flags) (void)hipHostFree(c.h_flags);
         if (c.h_stage) (void)hipHostFree(c.h_stage);
         if (c.dep) (void)hipEventDestroy(c.dep);
+        if (c.dep_run) (void)hipEventDestroy(c.dep_run);
         if (c.packed_done) (void)hipEventDestroy(c.packed_done);
         if (c.copied) (void)hipEventDestroy(c.copied);
         for (int i = 0; i < 4; ++i)
@@ -2086,10 +2103,9 @@ int cgv_search_packed_begin_f32_dev(cgv_index* h, const float* queries_dev, uint
         int r;
         if ((r = c->outidx.ensure((size_t)nq * k * 8))) return r;
         if ((r = c->outscore.ensure((size_t)nq * k * 4))) return r;
-        if (h->stream != c->run) {   // what the caller queued on the handle's stream (ingest, a query producer) comes first
-            HIPCHK(hipEventRecord(c->dep, h->stream));
+        HIPCHK(hipEventRecord(c->dep, h->stream));   // (also what a copy-engine fetch of the queries waits for: fetch_host_queries)
+        if (h->stream != c->run)   // what the caller queued on the handle's stream (ingest, a query producer) comes first
             HIPCHK(hipStreamWaitEvent(c->run, c->dep, 0));
-        }
         const float* qsrc = fetch_host_queries(h, c, queries_dev, nq, c->run, &r);
         if (r) return r;
         if ((r = search_enqueue(h, c, qsrc, nq, k, c->outidx.as<uint64_t>(), c->outscore.as<float>()))) return r;
@@ -2154,12 +2170,10 @@ int cgv_search_f32_dev(cgv_index* h, const float* queries_dev, uint32_t nq, uint
     return cgv_search_end(h, t);
 }
 
-int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
-                   float* out_score_host) {
-    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
-    if (nq == 0 || k == 0) return CGV_OK;
-    int rc = check_search_args(h, queries_host, k, out_idx_host, out_score_host);
-    if (rc) return rc;
+// One cgv_search_f32 call by itself: host queries in, host results out, one search context.
+static int search_host_plain(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
+                             float* out_score_host) {
+    int rc;
     std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     SearchCtx* c = acquire_ctx(h, lk);
@@ -2245,9 +2259,140 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     };
     rc = body();
     if (lk.owns_lock()) lk.unlock();
-    if (rc) (void)hipStreamSynchronize(s);
+    if (rc) {   // nothing of this call may still be in flight when the context goes back to the pool (the copy stream too)
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamSynchronize(s);
+    }
     release_ctx(h, c);
     return rc;
+}
+
+// ---- group commit of concurrent small calls (coalesce.h) ---------------------------------------------------------------
+// k class of a request: batches carry one class, so that a caller asking for a few neighbours is never dragged onto the path
+// a large-k neighbour of the queue needs (0: one COARSE_TOP2 launch; 1: the staged MFMA path; 2: the exact scan).
+static uint32_t coalesce_kclass(const cgv_index* h, uint32_t k) {
+    const uint32_t kp = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
+    if (kp <= 64) return 0u;
+    return (k <= CGV_FAST_MAX_K && kp <= CAND_CAPS && (!h->shadow || k <= 60)) ? 1u : 2u;
+}
+
+// ONE device batch for the requests of several callers: queries gathered into the context's pinned staging area, one search
+// with k = kmax, every caller's first k results scattered to its own buffers. Sets DONE / ALONE on every request.
+static void search_coalesced(cgv_index* h, std::vector<CoReq*>& batch, uint32_t kmax) {
+    const size_t row_bytes = (size_t)h->D * 4;
+    // (outcome, not state: the owner of a request reads `state` under the coalescer's mutex - coalesce.h)
+    for (CoReq* r : batch) r->outcome = CoReq::TAKEN;
+    auto all_alone = [&]() {
+        for (CoReq* r : batch) r->outcome = CoReq::ALONE;
+    };
+    // (1) isolation: a query the device would reject for the whole batch (NaN / Inf: the reference panics, simd_ops.rs:379;
+    // fp8: largest magnitude outside [2^-48, 2^48]) sends ITS caller to the plain path, which reports it exactly as a lone call
+    uint32_t nq_total = 0;
+    for (CoReq* r : batch) {
+        bool ok = true;
+        for (uint32_t j = 0; j < r->nq && ok; ++j) {
+            const float* v = r->q + (size_t)j * h->D;
+            float amax = 0.0f;
+            bool finite = true;
+            for (uint32_t i = 0; i < h->D; ++i) {
+                const float a = fabsf(v[i]);
+                finite = finite && (a <= 3.402823466e38f);
+                amax = a > amax ? a : amax;
+            }
+            ok = finite;
+            if (ok && h->dtype == CGV_DTYPE_FP8E4M3 && amax > 0.0f) {
+                const int e = fp8_row_exponent(amax);
+                ok = e >= FP8_EXP_MIN && e <= FP8_EXP_MAX;
+            }
+        }
+        if (!ok) {
+            r->outcome = CoReq::ALONE;
+            continue;
+        }
+        r->off = nq_total;
+        nq_total += r->nq;
+    }
+    if (nq_total == 0) return;
+    // (2) the batch
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (hipSetDevice(h->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return all_alone();
+    }
+    SearchCtx* c = acquire_ctx(h, lk);
+    if (!c) return all_alone();   // (this thread holds every context as begin tickets: each caller's own call reports it)
+    hipStream_t s = c->stream;
+    const size_t ibytes = (size_t)nq_total * kmax * 8, sbytes = (size_t)nq_total * kmax * 4;
+    for (CoReq* r : batch)
+        if (r->outcome == CoReq::TAKEN) memcpy(c->h_stage + (size_t)r->off * row_bytes, r->q, (size_t)r->nq * row_bytes);
+    uint64_t* oi = (uint64_t*)(c->h_stage_dev + SMALL_Q_BYTES);
+    float* os = (float*)(c->h_stage_dev + SMALL_Q_BYTES + ibytes);
+    int rc = order_after_caller(h, c);
+    if (rc == CGV_OK) rc = search_enqueue(h, c, (const float*)c->h_stage_dev, nq_total, kmax, oi, os);
+    lk.unlock();
+    if (rc == CGV_OK) rc = search_finish(h, c);   // (every path through it ends with the stream idle: the staged results are complete)
+    if (rc != CGV_OK) {   // whatever it was, nobody inherits another caller's failure: every request runs again on its own
+        (void)hipStreamSynchronize(s);
+        release_ctx(h, c);
+        return all_alone();
+    }
+    const uint64_t* ri = (const uint64_t*)(c->h_stage + SMALL_Q_BYTES);
+    const float* rs = (const float*)(c->h_stage + SMALL_Q_BYTES + ibytes);
+    (void)sbytes;
+    for (CoReq* r : batch) {
+        if (r->outcome != CoReq::TAKEN) continue;
+        for (uint32_t j = 0; j < r->nq; ++j) {
+            memcpy(r->out_idx + (size_t)j * r->k, ri + (size_t)(r->off + j) * kmax, (size_t)r->k * 8);
+            memcpy(r->out_score + (size_t)j * r->k, rs + (size_t)(r->off + j) * kmax, (size_t)r->k * 4);
+        }
+        r->rc = CGV_OK;
+        r->outcome = CoReq::DONE;
+    }
+    release_ctx(h, c);
+}
+
+int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k, uint64_t* out_idx_host,
+                   float* out_score_host) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (nq == 0 || k == 0) return CGV_OK;
+    int rc = check_search_args(h, queries_host, k, out_idx_host, out_score_host);
+    if (rc) return rc;
+    // A few queries per call - the reference's trait-level call is ONE (traits.rs:14; surreal_store.rs:61-85), its multi-query
+    // caller is B concurrent single-query searches (search.rs:358-361): concurrent callers share one device batch (coalesce.h).
+    if (!h->co.eligible(nq, k, h->D)) return search_host_plain(h, queries_host, nq, k, out_idx_host, out_score_host);
+    CoReq r;
+    r.q = queries_host;
+    r.nq = nq;
+    r.k = k;
+    r.kclass = coalesce_kclass(h, k);
+    r.out_idx = out_idx_host;
+    r.out_score = out_score_host;
+    return h->co.submit(
+        r, h->D, [&]() { return search_host_plain(h, queries_host, nq, k, out_idx_host, out_score_host); },
+        [&](std::vector<CoReq*>& batch, uint32_t, uint32_t kmax) { search_coalesced(h, batch, kmax); },
+        [](int code, const std::string& msg) { return fail(code, msg); });
+}
+
+int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batches_in_flight, uint32_t window_us) {
+    if (!h) return fail(CGV_ERR_INVALID_ARG, "handle is NULL");
+    if (max_batches_in_flight > (uint32_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "at most cgv_max_batches_in_flight() batches");
+    // (applies to calls that arrive from now on; requests already queued are served under whichever values their leader reads)
+    h->co.configure(max_batch_queries != 0 && max_batches_in_flight != 0, max_batch_queries, (int)max_batches_in_flight, window_us);
+    return CGV_OK;
+}
+
+int cgv_get_coalesce_stats(cgv_index* h, uint64_t* out8) {
+    if (!h || !out8) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    const CoStats st = h->co.stats();
+    out8[0] = st.batches;
+    out8[1] = st.batched_requests;
+    out8[2] = st.batched_queries;
+    out8[3] = st.lone_calls;
+    out8[4] = st.retried_alone;
+    out8[5] = st.max_batch_queries;
+    out8[6] = st.window_waits;
+    out8[7] = 0;
+    return CGV_OK;
 }
 
 int cgv_get_row_f32(cgv_index* h, uint64_t id, float* out_host) {

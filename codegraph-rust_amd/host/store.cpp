@@ -13,6 +13,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <set>
 #include <string>
@@ -403,7 +404,10 @@ class MockBackend : public SurrealVectorBackend {
     int upsert_nodes(const std::vector<Node>&) override { return CGV_OK; }
     int vector_knn(const std::string& column, const std::vector<float>&, size_t, size_t,
                    std::vector<std::pair<std::string, float>>& out) override {
-        columns.push_back(column);
+        {
+            std::lock_guard<std::mutex> lk(mu_);   // (read entries of the store run concurrently)
+            columns.push_back(column);
+        }
         out = results_;
         return CGV_OK;
     }
@@ -412,6 +416,7 @@ class MockBackend : public SurrealVectorBackend {
         return CGV_OK;
     }
     std::vector<std::string> columns;
+    std::mutex mu_;
 
    private:
     std::vector<std::pair<std::string, float>> results_;
@@ -450,13 +455,60 @@ bool starts_with(const std::string& s, const std::string& p) { return s.compare(
 
 }  // namespace
 
+// Readers-writer lock of a store, writers first. The reference serialises its storage behind a tokio::sync::Mutex
+// (surreal_store.rs:45-47) while the traits are Send + Sync and called from a multi-thread runtime: here the read entries
+// (search_similar, vector_knn, get_embedding, the SemanticSearch calls) hold the lock SHARED, so concurrent callers reach the
+// kNN layer together - where cgv_search_f32 merges them into one device batch (csrc/coalesce.h) - and upserts hold it
+// exclusively. A waiting writer stops new readers (pthread's default rwlock prefers readers: a steady stream of searches would
+// starve every upsert).
+class StoreLock {
+   public:
+    void lock_shared() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !writer_ && writers_waiting_ == 0; });
+        ++readers_;
+    }
+    void unlock_shared() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--readers_ == 0) cv_.notify_all();
+    }
+    void lock() {
+        std::unique_lock<std::mutex> lk(mu_);
+        ++writers_waiting_;
+        cv_.wait(lk, [&] { return !writer_ && readers_ == 0; });
+        --writers_waiting_;
+        writer_ = true;
+    }
+    void unlock() {
+        std::lock_guard<std::mutex> lk(mu_);
+        writer_ = false;
+        cv_.notify_all();
+    }
+
+   private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int readers_ = 0, writers_waiting_ = 0;
+    bool writer_ = false;
+};
+struct SharedGuard {
+    explicit SharedGuard(StoreLock& l) : l_(l) { l_.lock_shared(); }
+    ~SharedGuard() { l_.unlock_shared(); }
+    StoreLock& l_;
+};
+struct ExclusiveGuard {
+    explicit ExclusiveGuard(StoreLock& l) : l_(l) { l_.lock(); }
+    ~ExclusiveGuard() { l_.unlock(); }
+    StoreLock& l_;
+};
+
 // SurrealVectorStore (surreal_store.rs:25-86) + SemanticSearch (search.rs) over one backend.
 struct cgvs_store {
     std::unique_ptr<SurrealVectorBackend> backend;
     MockBackend* mock = nullptr;
     size_t ef_search = 100;
     std::unordered_map<NodeId, NodeMeta, NodeIdHash> node_metadata;
-    std::mutex mu;
+    StoreLock mu;   // shared: searches / reads; exclusive: upserts
 
     // VectorStore::search_similar, surreal_store.rs:61-85
     int search_similar(const float* q, size_t dim, size_t limit, std::vector<NodeId>& out) {
@@ -640,6 +692,7 @@ int cgvs_store_create_mock(const char* const* ids, const float* distances, uint3
 int cgvs_mock_recorded_columns(cgvs_store* s, char* buf, size_t buf_len) {
     if (!s || !s->mock || !buf || !buf_len) return fail(CGV_ERR_INVALID_ARG, "not a mock store");
     std::string j;
+    std::lock_guard<std::mutex> lk(s->mock->mu_);
     for (auto& c : s->mock->columns) j += (j.empty() ? "" : "\n") + c;
     snprintf(buf, buf_len, "%s", j.c_str());
     return CGV_OK;
@@ -654,7 +707,7 @@ int cgvs_upsert_nodes(cgvs_store* s, uint32_t n, const uint8_t* ids16, const flo
     if (!s) return fail(CGV_ERR_INVALID_ARG, "store is NULL");
     if (n == 0) return CGV_OK;  // surreal_store.rs:92-94
     if (!ids16) return fail(CGV_ERR_INVALID_ARG, "ids is NULL");
-    std::lock_guard<std::mutex> lk(s->mu);
+    ExclusiveGuard lk(s->mu);
     std::vector<Node> nodes(n);
     for (uint32_t i = 0; i < n; ++i) {
         memcpy(nodes[i].id.data(), ids16 + 16 * i, 16);
@@ -668,7 +721,7 @@ int cgvs_upsert_node_metadata(cgvs_store* s, const uint8_t* id16, const char* la
                               const char* file_path, const char* const* attr_keys, const char* const* attr_values,
                               uint32_t n_attrs) {
     if (!s || !id16) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    ExclusiveGuard lk(s->mu);
     NodeId id;
     memcpy(id.data(), id16, 16);
     NodeMeta m;
@@ -689,7 +742,7 @@ int cgvs_upsert_node_metadata(cgvs_store* s, const uint8_t* id16, const char* la
 int cgvs_vector_knn(cgvs_store* s, const char* column, const float* query, uint32_t dim, uint32_t limit,
                     uint32_t ef_search, char* out_ids, float* out_dist, uint32_t* out_n) {
     if (!s || !column || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     std::vector<std::pair<std::string, float>> nb;
     int rc = s->backend->vector_knn(column, std::vector<float>(query, query + dim), limit, ef_search, nb);
     if (rc) return rc;
@@ -704,7 +757,7 @@ int cgvs_vector_knn(cgvs_store* s, const char* column, const float* query, uint3
 int cgvs_search_similar(cgvs_store* s, const float* query, uint32_t dim, uint32_t limit, uint8_t* out_ids16,
                         uint32_t* out_n) {
     if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     std::vector<NodeId> ids;
     int rc = s->search_similar(query, dim, limit, ids);
     if (rc) return rc;
@@ -715,7 +768,7 @@ int cgvs_search_similar(cgvs_store* s, const float* query, uint32_t dim, uint32_
 
 int cgvs_get_embedding(cgvs_store* s, const uint8_t* id16, float* out, uint32_t cap, uint32_t* out_dim) {
     if (!s || !id16 || !out_dim) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     NodeId id;
     memcpy(id.data(), id16, 16);
     std::vector<float> e;
@@ -733,7 +786,7 @@ int cgvs_get_embedding(cgvs_store* s, const uint8_t* id16, float* out, uint32_t 
 int cgvs_search_by_embedding(cgvs_store* s, const float* query, uint32_t dim, uint32_t limit, uint8_t* out_ids16,
                              float* out_scores, uint32_t* out_n) {
     if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     std::vector<SearchResult> r;
     int rc = s->search_by_embedding(query, dim, limit, r);
     if (rc) return rc;
@@ -751,7 +804,7 @@ int cgvs_search_by_text(cgvs_store* s, const char* text, uint32_t limit, uint8_t
 int cgvs_semantic_search(cgvs_store* s, const float* query, uint32_t dim, const cgvs_filters* filters,
                          uint32_t limit, uint8_t* out_ids16, float* out_scores, uint32_t* out_n) {
     if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);  // search.rs:293
     std::vector<SearchResult> base;
     int rc = s->search_by_embedding(query, dim, pk, base);
@@ -763,7 +816,7 @@ int cgvs_semantic_search(cgvs_store* s, const float* query, uint32_t dim, const 
 int cgvs_hybrid_search(cgvs_store* s, const float* query, uint32_t dim, const cgvs_filters* filters,
                        float vector_weight, uint32_t limit, uint8_t* out_ids16, float* out_scores, uint32_t* out_n) {
     if (!s || !out_n || !filters) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     const float vw = vector_weight < 0.0f ? 0.0f : (vector_weight > 1.0f ? 1.0f : vector_weight);  // clamp(0,1)
     const float mw = 1.0f - vw;
     const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);
@@ -784,7 +837,7 @@ int cgvs_multi_vector_search(cgvs_store* s, const float* queries, uint32_t nq, u
     if (!s || !out_n) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
     *out_n = 0;
     if (nq == 0) return CGV_OK;  // search.rs:354-356
-    std::lock_guard<std::mutex> lk(s->mu);
+    SharedGuard lk(s->mu);
     const size_t pk = std::max<size_t>((size_t)limit * 4, (size_t)limit + 25);
     std::vector<std::vector<SearchResult>> lists;
     int rc = s->search_by_embedding_batch(queries, nq, dim, pk, lists);  // one GPU batch for all queries

@@ -89,7 +89,8 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_MAX_K 2048u
 #define CGV_FAST_MAX_K 228u
 
-/* Library/ABI version (major<<16 | minor). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
+/* Library/ABI version (major<<16 | minor). Minor 7 (round 6): cgv_set_coalesce / cgv_get_coalesce_stats (concurrent small
+ * cgv_search_f32 calls share one device batch). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
  * environment variable; cgv_alloc_pinned / cgv_free_pinned. Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
  * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. Minor 5 (round 4): cgv_search_packed_begin_f32_dev
  * / cgv_search_packed_end / cgv_merge_packed_flag_dev (the join-free exchange), cgv_host_device_alias, CGV_METRIC_COSINE_SCALAR /
@@ -157,6 +158,21 @@ int cgv_truncate(cgv_index* h, uint64_t n_rows);
  * library. On a non-zero status the out arrays are unspecified (they may already have been written). */
 int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_t k,
                    uint64_t* out_idx_host, float* out_score_host);
+
+/* Group commit of concurrent small calls. The trait-level call of the reference is ONE query
+ * (VectorStore::search_similar(&self, &[f32], limit), traits.rs:14; surreal_store.rs:61-85; caller search.rs:114-117) and its
+ * multi-query caller issues B concurrent single-query searches (search.rs:358-361, try_join_all): concurrent cgv_search_f32
+ * calls of <= 8 queries each on one handle are therefore merged into ONE device batch (<= max_batch_queries queries, default 64 =
+ * one launch that streams the corpus once for all of them) - every caller gets exactly the ids, scores, status and message
+ * of a lone call (a NaN / Inf query fails its own caller only). At most max_batches_in_flight (default 2, <=
+ * cgv_max_batches_in_flight()) such batches are on the device at once; calls that arrive meanwhile queue up and form the next batch
+ * - a lone caller never waits. window_us > 0 (default 0) lets the thread that starts a batch right behind a multi-caller batch
+ * linger up to that long for the callers that batch has just released. max_batch_queries == 0 or max_batches_in_flight == 0 switches
+ * the merging off (every call is its own batch, as before ABI minor 7).
+ * cgv_get_coalesce_stats: out8 = {batches that carried > 1 caller, callers served by them, their queries, eligible calls that ran
+ * alone, requests handed back to run alone, largest batch (queries), batches that lingered, 0}. */
+int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batches_in_flight, uint32_t window_us);
+int cgv_get_coalesce_stats(cgv_index* h, uint64_t* out8);
 
 /* Same with DEVICE pointers for queries and outputs (results stay in HBM; the call
  * returns after the work is enqueued and the exactness check has been read back). */

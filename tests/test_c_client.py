@@ -13,14 +13,17 @@ from _util import ROOT, pkg
 SRC = os.path.join(ROOT, "tests", "c_client", "abi_client.c")
 
 
-def _build(tmp_path, src=SRC, name="abi_client"):
+def _build(tmp_path, src=SRC, name="abi_client", extra=()):
     m = pkg()
     m.build_library()
     exe = str(tmp_path / name)
     libdir = os.path.dirname(m.cgvec.LIB_PATH)
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", *extra, "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                            "-L", libdir, "-lcgvec_hip", "-Wl,-rpath," + libdir])
     return exe
+
+
+CALLERS = os.path.join(ROOT, "tests", "c_client", "callers.c")
 
 
 SHIM = os.path.join(ROOT, "tests", "c_client", "shim_replay.c")
@@ -42,6 +45,17 @@ def test_c_client_compiles_and_fails_loudly_without_gpu(tmp_path):
     _write_input(tmp_path / "in.bin", rng.standard_normal((64, 16)).astype(np.float32),
                  rng.standard_normal((2, 16)).astype(np.float32), 5)
     p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert p.returncode == 3 and "no CPU fallback" in p.stderr
+
+
+def test_pthread_client_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build(tmp_path, CALLERS, "callers", extra=("-pthread", "-DCALLERS_MAIN"))
+    if pkg().device_count() > 0:
+        pytest.skip("GPU present")
+    rng = np.random.default_rng(0)
+    _write_input(tmp_path / "in.bin", rng.standard_normal((64, 16)).astype(np.float32),
+                 rng.standard_normal((4, 16)).astype(np.float32), 5)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "1", "4"], capture_output=True, text=True)
     assert p.returncode == 3 and "no CPU fallback" in p.stderr
 
 
@@ -132,3 +146,29 @@ def test_c_client_sharded_handle_equals_oracle(tmp_path, oracle, n_shards):
     ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
     assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
     assert np.array_equal(back, oracle.round_trip(rows[1], 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,odt,threads", [(1, 1, 64), (0, 0, 16)])
+def test_pthread_client_concurrent_single_query_callers(tmp_path, oracle, dtype, odt, threads):
+    """The pthread variant of the plain-C client (tests/c_client/callers.c): `threads` native threads, each in a serial loop of
+    SINGLE-query cgv_search_f32 calls on one index - the reference's call shape (traits.rs:14; search.rs:358-361 issues B of them
+    concurrently). The library merges concurrent callers into shared device batches (csrc/coalesce.h); every caller's ids and
+    scores must be the oracle's."""
+    exe = _build(tmp_path, CALLERS, "callers", extra=("-pthread", "-DCALLERS_MAIN"))
+    rng = np.random.default_rng(13)
+    n, d, k = 60_000, 256, 10
+    nq = threads * 8
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    _write_input(tmp_path / "in.bin", rows, q, k)
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(dtype), str(threads)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    idx = np.frombuffer(raw[: nq * k * 8], dtype=np.uint64).reshape(nq, k)
+    sc = np.frombuffer(raw[nq * k * 8: nq * k * 12], dtype=np.float32).reshape(nq, k)
+    ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+    assert np.array_equal(idx, ri) and np.array_equal(sc, rs)
+    # "coalesce: batches B requests R ..." on stderr: the callers really shared batches
+    words = p.stderr.split()
+    assert int(words[words.index("batches") + 1]) > 0, p.stderr
