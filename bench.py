@@ -762,7 +762,7 @@ def run(args, wd, world, rank, local_rank):
             for c_ in sample:
                 ix.search_host_ptr(qall[c_ % qall.shape[0]].ctypes.data, 1, k, li.ctypes.data, ls.ctypes.data)
                 same_cc = same_cc and bool(np.array_equal(li[0], ci[c_, 0]) and np.array_equal(ls[0], csc[c_, 0]))
-            ix.set_coalesce(64, 2, 0)
+            ix.set_coalesce()   # (back to the library's defaults)
             nb = max(1, cs1["batches"] - cs0["batches"])
             coalesced = {
                 "threads": T, "calls_per_thread": calls, "nq_per_call": 1,
@@ -780,8 +780,8 @@ def run(args, wd, world, rank, local_rank):
                 "same_results_as_lone_calls": same_cc, "checked_calls": len(sample),
                 "corpus_stream_gb_per_s": round(float(n_total) * dim * ESIZE[dtype] * nb / wallc / 1e9, 1),
                 "note": "native threads (tests/c_client/callers.c), each in a serial loop of single-query cgv_search_f32 calls with "
-                        "pageable buffers; concurrent callers share device batches (group commit, csrc/coalesce.h: <= 64 queries per "
-                        "batch, <= 2 batches on the device, no time window); `lone` = the same loop with one thread; checked calls are "
+                        "pageable buffers; concurrent callers share device batches (group commit, csrc/coalesce.h; the library's default "
+                        "policy: CGV_COALESCE_* in include/cgvec.h); `lone` = the same loop with one thread; checked calls are "
                         "compared bit for bit with lone calls of the same queries"}
         except Exception as e:   # noqa: BLE001 - a side measurement never takes the line down
             coalesced = {"error": f"{type(e).__name__}: {e}"}

@@ -265,8 +265,9 @@ class HipKnnIndex:
         """How long the end of a search polls its stream before it blocks (cgv_set_spin_us; default 3000, 0 = block at once)."""
         _check(lib().cgv_set_spin_us(self._h, int(us)))
 
-    def set_coalesce(self, max_batch_queries=64, max_batches_in_flight=2, window_us=0):
-        """Group commit of concurrent small search calls (cgv_set_coalesce); max_batch_queries = 0 switches it off."""
+    def set_coalesce(self, max_batch_queries=64, max_batches_in_flight=1, window_us=250):
+        """Group commit of concurrent small search calls (cgv_set_coalesce; the defaults are the library's:
+        CGV_COALESCE_* in include/cgvec.h); max_batch_queries = 0 switches it off."""
         _check(lib().cgv_set_coalesce(self._h, int(max_batch_queries), int(max_batches_in_flight), int(window_us)))
 
     def coalesce_stats(self):

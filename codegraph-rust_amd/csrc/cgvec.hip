@@ -184,7 +184,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone, qspread;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     hipEvent_t copied = nullptr;   // batches in flight: the copy engine has fetched this batch's host queries (fetch_host_queries)
@@ -206,7 +206,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -214,7 +214,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -1107,6 +1107,17 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             if (!c->floor_clean) HIPCHK(hipMemsetAsync(c->floor.p, 0, (size_t)TOP2_MAX_NQ * 4, s));
             c->floor_clean = false;   // (true again once this search's final kernel has run: search_finish)
             a.floor_ord = c->floor.as<uint32_t>();
+            if (nq > TOP2_QPW) {   // more than 16 queries: spread over the four wave columns (kernels_coarse.h: top2_col_of)
+                const size_t tile_bytes = (size_t)a.kc * BLOCK_BYTES;
+                if (c->qspread.bytes < tile_bytes) {
+                    if ((rc = c->qspread.ensure(tile_bytes))) return rc;
+                    HIPCHK(hipMemsetAsync(c->qspread.p, 0, c->qspread.bytes, s));   // (columns without a query: zeros, once)
+                }
+                hipLaunchKernelGGL(top2_spread_queries_kernel, dim3((nq * a.kc * 4u + 255u) / 256u), dim3(256), 0, s, a.qrows,
+                                   c->qspread.as<char>(), nq, a.kc);
+                HIPCHK(hipGetLastError());
+                a.qrows = c->qspread.as<char>();
+            }
             a.j0 = 0;
             a.cnt = p.ntiles;
             a.nsplit = std::min<uint32_t>(p.ntiles, nsplit_max);
@@ -2280,40 +2291,16 @@ static uint32_t coalesce_kclass(const cgv_index* h, uint32_t k) {
 // with k = kmax, every caller's first k results scattered to its own buffers. Sets DONE / ALONE on every request.
 static void search_coalesced(cgv_index* h, std::vector<CoReq*>& batch, uint32_t kmax) {
     const size_t row_bytes = (size_t)h->D * 4;
-    // (outcome, not state: the owner of a request reads `state` under the coalescer's mutex - coalesce.h)
-    for (CoReq* r : batch) r->outcome = CoReq::TAKEN;
+    for (CoReq* r : batch) r->outcome = CoReq::PENDING;
     auto all_alone = [&]() {
         for (CoReq* r : batch) r->outcome = CoReq::ALONE;
     };
-    // (1) isolation: a query the device would reject for the whole batch (NaN / Inf: the reference panics, simd_ops.rs:379;
-    // fp8: largest magnitude outside [2^-48, 2^48]) sends ITS caller to the plain path, which reports it exactly as a lone call
-    uint32_t nq_total = 0;
+    uint32_t nq_total = 0;   // (every caller has checked its own queries before it joined: cgv_search_f32)
     for (CoReq* r : batch) {
-        bool ok = true;
-        for (uint32_t j = 0; j < r->nq && ok; ++j) {
-            const float* v = r->q + (size_t)j * h->D;
-            float amax = 0.0f;
-            bool finite = true;
-            for (uint32_t i = 0; i < h->D; ++i) {
-                const float a = fabsf(v[i]);
-                finite = finite && (a <= 3.402823466e38f);
-                amax = a > amax ? a : amax;
-            }
-            ok = finite;
-            if (ok && h->dtype == CGV_DTYPE_FP8E4M3 && amax > 0.0f) {
-                const int e = fp8_row_exponent(amax);
-                ok = e >= FP8_EXP_MIN && e <= FP8_EXP_MAX;
-            }
-        }
-        if (!ok) {
-            r->outcome = CoReq::ALONE;
-            continue;
-        }
         r->off = nq_total;
         nq_total += r->nq;
     }
     if (nq_total == 0) return;
-    // (2) the batch
     std::unique_lock<std::mutex> lk(h->mu);
     if (hipSetDevice(h->device) != hipSuccess) {
         (void)hipGetLastError();
@@ -2324,7 +2311,7 @@ static void search_coalesced(cgv_index* h, std::vector<CoReq*>& batch, uint32_t 
     hipStream_t s = c->stream;
     const size_t ibytes = (size_t)nq_total * kmax * 8, sbytes = (size_t)nq_total * kmax * 4;
     for (CoReq* r : batch)
-        if (r->outcome == CoReq::TAKEN) memcpy(c->h_stage + (size_t)r->off * row_bytes, r->q, (size_t)r->nq * row_bytes);
+        if (r->outcome == CoReq::PENDING) memcpy(c->h_stage + (size_t)r->off * row_bytes, r->q, (size_t)r->nq * row_bytes);
     uint64_t* oi = (uint64_t*)(c->h_stage_dev + SMALL_Q_BYTES);
     float* os = (float*)(c->h_stage_dev + SMALL_Q_BYTES + ibytes);
     int rc = order_after_caller(h, c);
@@ -2340,7 +2327,7 @@ static void search_coalesced(cgv_index* h, std::vector<CoReq*>& batch, uint32_t 
     const float* rs = (const float*)(c->h_stage + SMALL_Q_BYTES + ibytes);
     (void)sbytes;
     for (CoReq* r : batch) {
-        if (r->outcome != CoReq::TAKEN) continue;
+        if (r->outcome != CoReq::PENDING) continue;
         for (uint32_t j = 0; j < r->nq; ++j) {
             memcpy(r->out_idx + (size_t)j * r->k, ri + (size_t)(r->off + j) * kmax, (size_t)r->k * 8);
             memcpy(r->out_score + (size_t)j * r->k, rs + (size_t)(r->off + j) * kmax, (size_t)r->k * 4);
@@ -2360,6 +2347,24 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
     // A few queries per call - the reference's trait-level call is ONE (traits.rs:14; surreal_store.rs:61-85), its multi-query
     // caller is B concurrent single-query searches (search.rs:358-361): concurrent callers share one device batch (coalesce.h).
     if (!h->co.eligible(nq, k, h->D)) return search_host_plain(h, queries_host, nq, k, out_idx_host, out_score_host);
+    // isolation: a query the device would reject for a whole batch (NaN / Inf: the reference panics, simd_ops.rs:379; fp8: largest
+    // magnitude outside [2^-48, 2^48]) never joins one - the plain path reports it to its own caller exactly as a lone call
+    for (uint32_t j = 0; j < nq; ++j) {
+        const float* v = queries_host + (size_t)j * h->D;
+        float amax = 0.0f;
+        bool finite = true;
+        for (uint32_t i = 0; i < h->D; ++i) {
+            const float a = fabsf(v[i]);
+            finite = finite && (a <= 3.402823466e38f);
+            amax = a > amax ? a : amax;
+        }
+        bool ok = finite;
+        if (ok && h->dtype == CGV_DTYPE_FP8E4M3 && amax > 0.0f) {
+            const int e = fp8_row_exponent(amax);
+            ok = e >= FP8_EXP_MIN && e <= FP8_EXP_MAX;
+        }
+        if (!ok) return search_host_plain(h, queries_host, nq, k, out_idx_host, out_score_host);
+    }
     CoReq r;
     r.q = queries_host;
     r.nq = nq;

@@ -157,6 +157,12 @@ __host__ __device__ inline uint64_t blocked_row_base(uint64_t R, uint32_t ld, ui
 }
 __host__ __device__ inline uint32_t blocked_row_key(uint64_t R) { return (uint32_t)((R & 255u) >> 2) & 3u; }
 
+// Query placement of a COARSE_TOP2 launch (kernels_coarse.h: Top2): query j of the one query tile sits in column
+// (j / 16) * 64 + j % 16 - 16 queries in the first N-block of each of the four wave columns. (row >> 2) & 3, the slot swizzle key
+// of the blocked layout, is the same for j and its column: a row's 64-byte chunks move verbatim.
+constexpr uint32_t TOP2_QPW = 16;
+__host__ __device__ inline uint32_t top2_col_of(uint32_t j) { return (j / TOP2_QPW) * 64u + (j % TOP2_QPW); }
+
 template <int DT>
 struct Elem;
 template <>

@@ -331,6 +331,26 @@ __device__ __forceinline__ float block_threshold(const CoarseArgs& a, float tq, 
 // k'-th. Three of a query's top-(k + few) rows in ONE of 1024 cells (probability ~C(11,3) / 1024^2 = 1.6e-4 for k = 10 on
 // data without structure; a run of near-duplicates does it on purpose) raise the floor above the k-th exact score: the check
 // fails and the query is answered by the exact scan, as always - never a wrong answer. ONE launch, no threshold, no sample.
+// Query placement of a COARSE_TOP2 launch (round 6). The MFMA C layout gives wave column wn the query columns wn * 64 .. + 63, and
+// the two waves of one wave column (wave = wm * 4 + wn) share a SIMD: with the queries in columns 0 .. 63 all the cell updates
+// (~10 VALU per score) ran on ONE of the CU's four SIMDs, beside that SIMD's share of the MFMAs - up to 32 queries the launch still
+// streamed the corpus at the HBM rate (418 us on C2's corpus), with 64 it took ~620 us (profiles/r06_coalesce_sweep.txt). So
+// query j sits in column (j / 16) * 64 + j % 16: 16 queries in the first N-block of every wave column, every SIMD does a quarter
+// of the updates, and a wave never has more than 4 blocks per tile to fold (what 32 queries cost before). The host builds the
+// spread copy of the query tile (top2_spread_queries_kernel, kernels_prep.h; batches of <= 16 queries are in place already);
+// every per-query array (inverse norms, exponents, candidate lists, floor words) stays indexed by the query.
+// (TOP2_QPW = 16 queries per wave column and top2_col_of: common.h)
+__device__ __forceinline__ uint32_t top2_query_of(int wn, int nb, int lane) {   // query in this lane's column of N-block nb, or none
+    const uint32_t l = (uint32_t)lane & 31u;
+    return (nb == 0 && l < TOP2_QPW) ? (uint32_t)wn * TOP2_QPW + l : 0xFFFFFFFFu;
+}
+// query index of the column a lane owns in N-block nb of wave column wn (one query tile in COARSE_TOP2: qt == 0)
+template <int MODE, int BN, int WTN>
+__device__ __forceinline__ uint32_t column_query(uint32_t qt, int wn, int nb, int lane) {
+    if (MODE == 4) return top2_query_of(wn, nb, lane);
+    return qt * (uint32_t)BN + (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
+}
+
 struct Top2 {
     float s1, s2, b;      // best, second best, best score left out (coarse / invn_q for cosine: the query's own positive factor
     uint32_t r1, r2;      // is applied when the cell is flushed); rows of s1, s2
@@ -347,27 +367,26 @@ __device__ __forceinline__ void top2_insert(Top2& t, float v, uint32_t row) {
 template <int BN, int NB>
 __device__ inline void top2_flush(const CoarseArgs& a, const Top2 (&t)[NB], const float (&invq)[NB], int wn, int lane, uint32_t g,
                                   uint32_t qt, uint32_t* cntq) {
-    if (wn != 0) return;   // (uniform: query columns 0..63 live in the waves with wn == 0)
+    if ((uint32_t)wn * TOP2_QPW >= a.nq) return;   // (uniform: this wave column holds no query)
+    constexpr int nb = 0;                          // (the queries sit in the first N-block of every wave column: top2_col_of)
+    const uint32_t q = top2_query_of(wn, nb, lane), ql = q;
+    if (q >= a.nq) return;
+    const float iq = (a.metric == METRIC_DOT) ? 1.0f : invq[nb];
+    const float sv[2] = {t[nb].s1, t[nb].s2};
+    const uint32_t rv[2] = {t[nb].r1, t[nb].r2};
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const uint32_t ql = (uint32_t)(nb * 32 + (lane & 31)), q = qt * (uint32_t)BN + ql;
-        if (q >= a.nq) continue;
-        const float iq = (a.metric == METRIC_DOT) ? 1.0f : invq[nb];
-        const float sv[2] = {t[nb].s1, t[nb].s2};
-        const uint32_t rv[2] = {t[nb].r1, t[nb].r2};
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if (sv[e] > -INFINITY) {
-                const float sc = (a.metric == METRIC_DOT) ? sv[e] : sv[e] * iq;   // = (acc * invn_c) * invn_q, block_hits' order
-                const uint32_t p = lds_inc_rtn(&cntq[ql]);
-                if (p < CAND_CAPS) a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(sc), rv[e]);
-                else a.overflow[q] = 1u;
-            }
-        if (t[nb].b > -INFINITY) {
-            const float fb = (a.metric == METRIC_DOT) ? t[nb].b : t[nb].b * iq;   // monotone in b: bounds every left-out row
-            atomicMax(a.floor_ord + q, f2ord(fb + 0.0f));
+    for (int e = 0; e < 2; ++e)
+        if (sv[e] > -INFINITY) {
+            const float sc = (a.metric == METRIC_DOT) ? sv[e] : sv[e] * iq;   // = (acc * invn_c) * invn_q, block_hits' order
+            const uint32_t p = lds_inc_rtn(&cntq[ql]);
+            if (p < CAND_CAPS) a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(sc), rv[e]);
+            else a.overflow[q] = 1u;
         }
+    if (t[nb].b > -INFINITY) {
+        const float fb = (a.metric == METRIC_DOT) ? t[nb].b : t[nb].b * iq;   // monotone in b: bounds every left-out row
+        atomicMax(a.floor_ord + q, f2ord(fb + 0.0f));
     }
+    (void)qt;
 }
 
 // Fused top-k' epilogue of one corpus tile (shared by the coarse kernel variants).
@@ -392,10 +411,10 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
     asm volatile("" : "+v"(lane_o));
     lane = lane_o;
     if (MODE == 4) {
-        // TOP2 (small batches): the waves that hold query columns 0..63 fold the tile into their cells. Fast skip per 32 x 32
-        // block: no lane's raw maximum reaches its cell's b (conservative raw-accumulator form of b, block_threshold) - after
-        // a few tiles that is almost every block of a batch of few queries (unused columns carry b = +inf).
-        if (wn != 0) return;   // uniform per wave
+        // TOP2 (small batches): the waves whose columns hold queries (16 per wave column, top2_col_of) fold the tile into their
+        // cells. Fast skip per 32 x 32 block: no lane's raw maximum reaches its cell's b (conservative raw-accumulator form of b,
+        // block_threshold) - after a few tiles that is almost every block of a batch of few queries (unused columns carry b = +inf).
+        if ((uint32_t)wn * TOP2_QPW >= a.nq) return;   // uniform per wave: this wave column holds no query (top2_col_of)
         float mn[MB], mx[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -403,8 +422,8 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
             mx[mb] = stat_s[8 + (wm * WTM) / 32 + mb];
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // vmax3 (asm) reads MFMA results: hipcc pads nothing for asm
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        {
+            constexpr int nb = 0;   // (the queries sit in the first N-block of every wave column)
             Top2 st = t2[nb];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -682,7 +701,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const uint32_t q = column_query<MODE, BN, WTN>(qt, wn, nb, lane);
         const bool valid = q < a.nq;
         const float tau = (MODE == 3 || MODE == 4) ? INFINITY : (valid ? a.tau[q] : INFINITY);  // MODE 3: no threshold yet (boot_block); 4: none at all
         const float iq = (a.metric == METRIC_DOT) ? 1.0f : (valid ? a.invn_q[q] : 0.0f);
@@ -708,7 +727,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     Top2 t2[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const bool active = MODE == 4 && wn == 0 && qt * (uint32_t)BN + (uint32_t)(nb * 32 + (lane & 31)) < a.nq;
+        const bool active = MODE == 4 && top2_query_of(wn, nb, lane) < a.nq;
         t2[nb].s1 = t2[nb].s2 = -INFINITY;
         t2[nb].b = active ? -INFINITY : INFINITY;
         t2[nb].r1 = t2[nb].r2 = 0xFFFFFFFFu;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const uint32_t q = column_query<MODE, BN, WTN>(qt, wn, nb, lane);   // (COARSE_TOP2: the spread placement, top2_col_of)
         const bool valid = q < a.nq;
         const float tau = MODE == 4 ? INFINITY : (valid ? a.tau[q] : INFINITY);   // COARSE_TOP2: no threshold at all
         const float iq = valid ? a.invn_q[q] : 0.0f;  // fp8 is cosine-only
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     Top2 t2[NB];   // COARSE_TOP2: the lane's cells (kernels_coarse.h)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const bool active = MODE == 4 && wn == 0 && qt * (uint32_t)BN + (uint32_t)(nb * 32 + (lane & 31)) < a.nq;
+        const bool active = MODE == 4 && top2_query_of(wn, nb, lane) < a.nq;
         t2[nb].s1 = t2[nb].s2 = -INFINITY;
         t2[nb].b = active ? -INFINITY : INFINITY;
         t2[nb].r1 = t2[nb].r2 = 0xFFFFFFFFu;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     int sb = 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
+        const uint32_t q = column_query<MODE, BN, WTN>(qt, wn, nb, lane);
         const int e = q < a.nq ? (int)a.rexp_q[q] : 0;
         sb |= ((127 - e) & 0xff) << (8 * nb);
     }

@@ -253,6 +253,16 @@ __global__ __launch_bounds__(1024) void max_norm_kernel(const float* __restrict_
     }
 }
 
+// COARSE_TOP2 with more than 16 queries: the spread copy of the (single) query tile - query j's 64-byte row chunks go to row
+// top2_col_of(j) of `dst` (same blocked layout, kc_count blocks of 16 KiB). One thread per 16-byte piece.
+__global__ void top2_spread_queries_kernel(const char* __restrict__ src, char* __restrict__ dst, uint32_t nq, uint32_t kc_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * kc_count * 4u) return;
+    const uint32_t j = i / (kc_count * 4u), rem = i % (kc_count * 4u), kc = rem >> 2, pc = rem & 3u;
+    const uint4 v = *(const uint4*)(src + (uint64_t)kc * BLOCK_BYTES + (uint64_t)j * CHUNK_BYTES + pc * 16u);
+    *(uint4*)(dst + (uint64_t)kc * BLOCK_BYTES + (uint64_t)top2_col_of(j) * CHUNK_BYTES + pc * 16u) = v;
+}
+
 __global__ void fill_f32_kernel(float* p, float v, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -164,13 +164,17 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
  * multi-query caller issues B concurrent single-query searches (search.rs:358-361, try_join_all): concurrent cgv_search_f32
  * calls of <= 8 queries each on one handle are therefore merged into ONE device batch (<= max_batch_queries queries, default 64 =
  * one launch that streams the corpus once for all of them) - every caller gets exactly the ids, scores, status and message
- * of a lone call (a NaN / Inf query fails its own caller only). At most max_batches_in_flight (default 2, <=
- * cgv_max_batches_in_flight()) such batches are on the device at once; calls that arrive meanwhile queue up and form the next batch
- * - a lone caller never waits. window_us > 0 (default 0) lets the thread that starts a batch right behind a multi-caller batch
- * linger up to that long for the callers that batch has just released. max_batch_queries == 0 or max_batches_in_flight == 0 switches
- * the merging off (every call is its own batch, as before ABI minor 7).
+ * of a lone call (a NaN / Inf query fails its own caller only). At most max_batches_in_flight (default 1, <=
+ * cgv_max_batches_in_flight()) such batches are on the device at once; calls that arrive meanwhile collect in the next batch -
+ * a lone caller never waits. window_us (default 250): the thread that starts a batch right behind a MULTI-caller batch lingers
+ * at most that long for the callers that batch has just released - until as many have joined as it had, the batch is full, or
+ * arrivals stop (for a third of the window, less when few callers are expected back); 0 = never. max_batch_queries == 0 or max_batches_in_flight == 0 switches the merging off (every call is its own batch, as
+ * before ABI minor 7).
  * cgv_get_coalesce_stats: out8 = {batches that carried > 1 caller, callers served by them, their queries, eligible calls that ran
- * alone, requests handed back to run alone, largest batch (queries), batches that lingered, 0}. */
+ * alone, requests handed back to run alone, largest batch (queries), batches whose leader lingered, 0}. */
+#define CGV_COALESCE_MAX_BATCH_QUERIES 64u
+#define CGV_COALESCE_BATCHES_IN_FLIGHT 1u
+#define CGV_COALESCE_WINDOW_US 250u
 int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batches_in_flight, uint32_t window_us);
 int cgv_get_coalesce_stats(cgv_index* h, uint64_t* out8);
 

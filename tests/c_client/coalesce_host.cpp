@@ -2,7 +2,9 @@
 // in a serial loop of single-request calls, a batch runner that sleeps like a device batch and answers from the query values,
 // a poisoned request every now and then (handed back to run alone, must fail its own caller only). Built with g++ (and once more
 // under -fsanitize=thread) by tests/test_coalesce_host.py. Prints one JSON line; exit code 0 = every caller got its own answers.
-//   usage: coalesce_host <threads> <calls per thread> <max_leaders> <window_us> <batch_sleep_us>
+//   usage: coalesce_host <threads> <calls per thread> <max_leaders> <window_us> <batch_sleep_us> [k classes]
+//   k classes > 1: the callers fall into that many classes that never share a batch - single-member batches of a rare class get led
+//   by threads of another one (the case that once slept forever: its one member was never woken)
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -28,6 +30,7 @@ int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 16, N = argc > 2 ? atoi(argv[2]) : 200, leaders = argc > 3 ? atoi(argv[3]) : 2;
     const uint32_t window = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
     const int sleep_us = argc > 5 ? atoi(argv[5]) : 200;
+    const int kclasses = argc > 6 ? atoi(argv[6]) : 1;
     Coalescer co;
     co.max_q_bytes = 64 * D * 4;
     co.max_out_bytes = 64 * 16 * 12;
@@ -59,7 +62,7 @@ int main(int argc, char** argv) {
                 r.q = q.data();
                 r.nq = nq;
                 r.k = k;
-                r.kclass = 0;
+                r.kclass = (kclasses > 1 && t % 7 == 0) ? (uint32_t)(1 + (t / 7) % (kclasses - 1)) : 0u;   // rare classes
                 r.out_idx = oi.data();
                 r.out_score = os.data();
                 if (!co.eligible(nq, k, D)) {
@@ -82,7 +85,7 @@ int main(int argc, char** argv) {
                         ++batch_runs;
                         uint32_t seen = 0;
                         for (CoReq* b : batch) {
-                            b->outcome = CoReq::TAKEN;
+                            b->outcome = CoReq::PENDING;
                             if (b->q[2] < 0.0f) {
                                 b->outcome = CoReq::ALONE;
                                 continue;
@@ -92,7 +95,7 @@ int main(int argc, char** argv) {
                         if (seen > nq_total || nq_total > 64) ++bad;
                         device(sleep_us + (int)nq_total);
                         for (CoReq* b : batch) {
-                            if (b->outcome != CoReq::TAKEN) continue;
+                            if (b->outcome != CoReq::PENDING) continue;
                             if (b->k > kmax) ++bad;
                             for (uint32_t j = 0; j < b->nq; ++j) answer(b->q + j * D, b->k, b->out_idx + j * b->k, b->out_score + j * b->k);
                             b->rc = 0;

@@ -121,7 +121,7 @@ def test_mixed_k_and_nq_and_a_nan_caller(oracle):
             ri, rs = oracle.batch_top_k(qs[(t, r)], rows, k, dtype=1)
             assert np.array_equal(gi, ri) and np.array_equal(gs, rs), (t, r, k)
         st = ix.coalesce_stats()
-        assert st["batches"] > 0 and st["retried_alone"] >= len(bad), st
+        assert st["batches"] > 0, st
         # the handle is fine afterwards
         gi, gs = ix.search(qs[(0, 0)], 10)
         ri, rs = oracle.batch_top_k(qs[(0, 0)], rows, 10, dtype=1)
