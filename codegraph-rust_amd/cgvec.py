@@ -153,6 +153,8 @@ def lib():
     L.cgv_set_coalesce.restype = i32
     L.cgv_get_coalesce_stats.argtypes = [vp, C.POINTER(u64)]
     L.cgv_get_coalesce_stats.restype = i32
+    L.cgv_get_small_batch_stats.argtypes = [vp, C.POINTER(u64)]
+    L.cgv_get_small_batch_stats.restype = i32
     L.cgv_alloc_pinned.argtypes = [C.c_size_t]
     L.cgv_alloc_pinned.restype = vp
     L.cgv_free_pinned.argtypes = [vp]
@@ -275,6 +277,11 @@ class HipKnnIndex:
         _check(lib().cgv_get_coalesce_stats(self._h, out))
         names = ("batches", "batched_requests", "batched_queries", "lone_calls", "retried_alone", "max_batch_queries", "window_waits")
         return {n: int(out[i]) for i, n in enumerate(names)}
+
+    def small_batch_stats(self):
+        out = (C.c_uint64 * 4)()
+        _check(lib().cgv_get_small_batch_stats(self._h, out))
+        return {"searches": int(out[0]), "failed_queries": int(out[1]), "repaired_by_cell_rescan": int(out[2]), "exact_scans": int(out[3])}
 
     def synchronize(self):
         _check(lib().cgv_synchronize(self._h))

@@ -42,6 +42,7 @@
 #include "kernels_exact.h"
 #include "kernels_exact_small.h"
 #include "kernels_prep.h"
+#include "kernels_repair.h"
 #include "kernels_select.h"
 
 using namespace cgv;
@@ -122,10 +123,23 @@ uint32_t esize_of(int dtype) { return dtype == CGV_DTYPE_F32 ? 4u : (dtype == CG
 // The model (1) is an assumption about undocumented hardware; tests/test_gpu_guarantee.py measures it
 // with adversarial same-sign / alternating-sign / one-huge-many-tiny inputs, and rescore_body's
 // trip-wire sends any query with an observed candidate error above eps/2 to the exact scan.
-float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, int metric) {
+//  (1') fp8 (round 6): the block-scaled K = 64 instruction does NOT follow (1), and rounds 2-5 priced it as if it did. Measured
+//      (scripts/fp8_mfma_align_probe.py, scripts/fp8_mfma_error_probe.py -> profiles/r06_fp8_mfma_error.txt): one product of
+//      448 * 448 and 63 equal small ones in one K = 64 block - down to 2^-13.6 of the large product all 63 arrive; from 2^-15.6 on
+//      exactly 56 of 63 arrive, whatever their sign, down to 2^-23.6: the SEVEN products that share a group of 8 with the large one
+//      are dropped, the other 56 are added exactly. So the instruction sums its products in groups of 8, each group aligned to its
+//      largest product and cut 13-14 bits below that product's exponent, and adds the group sums at full f32 precision. A group
+//      loses < 7 * 2^-13 * max|product of the group|; the groups' largest products sum to at most |q||c| (Cauchy-Schwarz over the
+//      groups): 7 * 2^-13 = 14336 u of |q||c| in all, WHATEVER D (measured worst on random data: 420 u; heavy-tailed magnitudes:
+//      4650 u at D = 64, 1530 u at D = 768). The old price, (ld/16) * 34 u, was 136 u at D = 64: an fp8 index of D <= 256 could
+//      see coarse errors above its eps (random data, D = 64: 2.4 x). The trip-wire caught that on candidates - those queries took
+//      the exact scan - but rows OUTSIDE the candidate set were covered by the model alone. tests/test_gpu_guarantee.py now
+//      measures D = 64 .. 256 and heavy-tailed / near-duplicate data too. (The non-scaled K = 16 fp8 instruction of the boot
+//      kernel is priced the same way.)
+float coarse_eps_scale(uint32_t ld_coarse, uint32_t ld_exact, uint32_t k_inst, int metric, bool fp8 = false) {
     const double u = 5.9604644775390625e-8;
     const double n_inst = (double)((ld_coarse + k_inst - 1) / k_inst);
-    const double mfma = n_inst * (double)(k_inst + 1) * 2.0;
+    const double mfma = n_inst * (double)(k_inst + 1) * 2.0 + (fp8 ? 14336.0 : 0.0);
     const double scale = (double)ld_coarse / 64.0 + 12.0;
     const bool sequential = metric == CGV_METRIC_COSINE_SEQ || metric == CGV_METRIC_COSINE_SCALAR;  // one accumulator per sum
     const double ref = sequential ? 2.0 * ld_exact + 4.0 : (double)ld_exact / 4.0 + 10.0;
@@ -145,7 +159,12 @@ uint32_t query_group(uint32_t nqt, uint32_t ld, int dtype) {
     return g;
 }
 
-uint32_t kprime_of(uint32_t k) {
+// Candidates kept per query. The check is e_k > (k'-th best coarse score) + eps: k' - k is what separates them on ordinary data.
+// fp8: eps is ~8.6e-4 whatever D (coarse_eps_scale (1')) - at C5's 62.5M rows per shard the 10th and the 16th best scores of a
+// query are closer than that for ~0.7 % of the queries, and every one of those costs an exact scan of 48 GB; k' = 2k + 12 (32 for
+// k = 10: 22 order-statistic spacings instead of 6) puts the k'-th score ~7e-3 below the k-th there.
+uint32_t kprime_of(uint32_t k, bool fp8 = false) {
+    if (fp8) return ((2u * k + 12u + 7u) / 8u) * 8u;
     uint32_t m = std::max<uint32_t>(6u, k / 8u);
     return ((k + m + 7u) / 8u) * 8u;
 }
@@ -184,7 +203,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone, qspread;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone, qspread, cellb, reptheta, repkeys, repn;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     hipEvent_t copied = nullptr;   // batches in flight: the copy engine has fetched this batch's host queries (fetch_host_queries)
@@ -196,6 +215,8 @@ struct SearchCtx {
     bool mfma = false, timed_coarse = false;
     bool boot_used = false;  // the search in flight used the fused sample + emit launch (its rendezvous words need clearing)
     bool top2 = false;       // the search in flight took the small-batch form (COARSE_TOP2: one launch, no thresholds)
+    bool repair = false;     // ... and can repair a floor violation by re-scanning the offending cells (kernels_repair.h)
+    uint32_t t2_nsplit = 0, t2_cnt = 0, t2_R = 0, t2_P = 0;   // its walk (what top2_repair_kernel maps a cell to rows with)
     bool floor_clean = false;  // the TOP2 floor words are known to be zero (final_kernel clears the ones it read)
     bool rewrote = false;  // search_finish ran the exact scan and rewrote (some of) the outputs after its first sync
     bool exact_enqueued = false;  // exact-scan-only batch (f32 index, forced exact, large k): the scan was enqueued by
@@ -206,7 +227,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -214,7 +235,7 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn};
         for (DevBuf* d : bufs) d->release();
     }
 };
@@ -257,6 +278,7 @@ struct cgv_index {
     bool force_exact = false;
     bool wide_range = false;  // a stored row's magnitude is outside [2^-40, 2^40]: searches take the exact scan (kernels_prep.h)
     bool last_top2 = false;   // the last finished search took the small-batch form (cgv_debug_last_top2_)
+    uint64_t top2_stats[3] = {0, 0, 0};   // COARSE_TOP2 searches, their queries that failed the check, of those repaired by a cell re-scan
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
     Coalescer co;   // group commit of concurrent small cgv_search_f32 calls (coalesce.h)
@@ -804,6 +826,7 @@ struct Tunables {
     int epi = CGV_ENV_INT("CGV_EPI", 1);                      // emitting epilogue variant of the bf16 coarse kernel (A/B)
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
+    int top2_repair = CGV_ENV_INT("CGV_TOP2_REPAIR", 1);      // COARSE_TOP2 floor violations: re-scan the offending cells only (A/B: 0 = exact scan)
     int exact_small = CGV_ENV_INT("CGV_EXACT_SMALL", 1);      // exact scan of <= 8 queries as ONE kernel (kernels_exact_small.h; A/B: 0)
     int fetch_queries = CGV_ENV_INT("CGV_FETCH_QUERIES", 1);  // batches in flight: host queries fetched by the copy engine (A/B: 0 = converted in place)
     int self_publish = CGV_ENV_INT("CGV_SELF_PUBLISH", 1);    // <= 64 queries: the final kernel's last workgroup publishes the flags (A/B: 0)
@@ -1008,7 +1031,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
     }
 
     // f32 + shadow: the coarse scores carry bf16 rounding error (~2e-3), so more candidates are re-scored
-    const uint32_t kprime = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
+    const uint32_t kprime = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k, h->dtype == CGV_DTYPE_FP8E4M3);
     const bool mfma = !h->force_exact && !h->wide_range && (h->dtype != CGV_DTYPE_F32 || h->shadow) && kprime <= CAND_CAPS &&
                       (!h->shadow || k <= 60);
     c->mfma = mfma;
@@ -1092,6 +1115,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         a.boot_sync = c->flags + F_COUNT + PACE_WORDS;
         a.kprime = kprime;
         a.floor_ord = nullptr;
+        a.cellb = nullptr;
+        c->repair = false;
         a.lad = nullptr;
         a.ladc = nullptr;
         // Small batches (one query tile of <= 64 queries - the trait-level call is ONE query, traits.rs:14): the corpus streams at the
@@ -1123,6 +1148,19 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             a.nsplit = std::min<uint32_t>(p.ntiles, nsplit_max);
             a.pace = nullptr;
             top2_nsplit = a.nsplit;
+            // every cell's left-out score, for the cheap way out of a floor violation (kernels_repair.h)
+            c->repair = tun().top2_repair != 0;
+            if (c->repair) {
+                if ((rc = c->cellb.ensure((size_t)4 * a.nsplit * 64 * 4))) return rc;
+                if ((rc = c->reptheta.ensure((size_t)TOP2_MAX_NQ * 4))) return rc;
+                if ((rc = c->repkeys.ensure((size_t)TOP2_MAX_NQ * REPAIR_KEYS * 8))) return rc;
+                if ((rc = c->repn.ensure((size_t)TOP2_MAX_NQ * 4 + 16))) return rc;
+                a.cellb = c->cellb.as<float>();
+                c->t2_nsplit = a.nsplit;
+                c->t2_cnt = a.cnt;
+                c->t2_R = a.R;
+                c->t2_P = a.P;
+            }
             if (h->profiling) HIPCHK(hipEventRecord(c->ev[1], s));
             if ((rc = launch_coarse(cdt, COARSE_TOP2, a, a.nsplit, s))) return rc;
             if (h->profiling) {
@@ -1246,12 +1284,15 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.metric = h->metric;
         // K = 16 for every dtype: the boot stage scores its rows with v_mfma_f32_32x32x16_* (fp8 included),
         // and (ld/16)*17 >= (ld/64)*65 covers the K = 64 block-scaled instruction of the fp8 main kernel
-        r.eps_scale = coarse_eps_scale(h->shadow ? h->lds : h->ld, h->ld, 16u, h->metric);
+        r.eps_scale = coarse_eps_scale(h->shadow ? h->lds : h->ld, h->ld, 16u, h->metric, h->dtype == CGV_DTYPE_FP8E4M3);
         r.max_norm_c = h->max_norm_c;
         r.qres = h->shadow ? c->qres.as<float>() : nullptr;
         r.res_rel_c = h->res_rel_c;
         r.res_abs_c = h->res_abs_c;
         r.stat_maxeps = c->flags + F_MAXEPS;
+        r.rep_theta = (top2 && c->repair) ? c->reptheta.as<float>() : nullptr;
+        r.rep_keys = c->repkeys.as<uint64_t>();
+        r.rep_n = c->repn.as<uint32_t>();
         if ((rc = c->qstat.ensure((size_t)nq * 8))) return rc;
         r.qstat = c->qstat.as<uint2>();   // per-query statistics, folded into the flag words by publish_flags_kernel
         // ... or, for a small batch, by the last workgroup of the final kernel itself (RescoreArgs::pub_*)
@@ -1416,7 +1457,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
     if (c->h_flags[F_NONFINITE_Q] & 2u)
         return fail(CGV_ERR_INVALID_ARG, "fp8 index: a query's largest magnitude is outside [2^-48, 2^48]");
-    uint32_t nfb = 0;
+    uint32_t nfb = 0, nrepaired = 0;
     float me = 0.0f;
     if (!c->mfma && c->exact_enqueued) {
         // the scan ran behind the query conversion on the same stream: nothing left to do
@@ -1429,7 +1470,54 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         memcpy(&me, &c->h_flags[F_MAXERR], 4);
         if (h->shadow) memcpy(&c->eps, &c->h_flags[F_MAXEPS], 4);  // largest per-query bound of this batch
         nfb = c->h_flags[F_FB_COUNT];
-        if (nfb > 0) {
+        uint32_t nscan = nfb;   // queries left for the exact scan
+        if (nfb > 0 && c->top2 && c->repair) {
+            // COARSE_TOP2: a query that failed on its floor alone (flag 2) gets the offending cells re-scanned (kernels_repair.h);
+            // what is still flagged afterwards is compacted for the exact scan
+            c->rewrote = true;
+            Top2RepairArgs ra;
+            ra.rows = h->rows;
+            ra.qrows = c->qrows.as<char>();
+            ra.nq = nq;
+            ra.n = (uint32_t)h->n;
+            ra.D = h->D;
+            ra.ld = h->ld;
+            ra.k = k;
+            ra.metric = (uint32_t)h->metric;
+            ra.cellb = c->cellb.as<float>();
+            ra.nsplit = c->t2_nsplit;
+            ra.cnt = c->t2_cnt;
+            ra.R = c->t2_R;
+            ra.P = c->t2_P;
+            ra.theta = c->reptheta.as<float>();
+            ra.keys = c->repkeys.as<uint64_t>();
+            ra.nkeys = c->repn.as<uint32_t>();
+            ra.idmap = h->idmap;
+            ra.out_idx = c->out_idx;
+            ra.out_score = c->out_score;
+            ra.fb_flag = c->fbflag.as<uint32_t>();
+            ra.repaired = c->flags + F_MAXEPS;   // (a free word here: the flag words were published and cleared; read back below)
+            HIPCHK(hipMemsetAsync(c->flags + F_MAXEPS, 0, 4, s));
+            switch (h->dtype) {
+                case CGV_DTYPE_F32: hipLaunchKernelGGL(top2_repair_kernel<DT_F32>, dim3(nq), dim3(256), 0, s, ra); break;
+                case CGV_DTYPE_BF16: hipLaunchKernelGGL(top2_repair_kernel<DT_BF16>, dim3(nq), dim3(256), 0, s, ra); break;
+                case CGV_DTYPE_FP16: hipLaunchKernelGGL(top2_repair_kernel<DT_FP16>, dim3(nq), dim3(256), 0, s, ra); break;
+                default: hipLaunchKernelGGL(top2_repair_kernel<DT_FP8>, dim3(nq), dim3(256), 0, s, ra); break;
+            }
+            hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
+                               c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(c->h_flags + F_COMPACT, c->flags + F_COMPACT, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(c->h_flags + F_MAXEPS, c->flags + F_MAXEPS, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            nscan = c->h_flags[F_COMPACT];
+            nrepaired = c->h_flags[F_MAXEPS];
+            if (nscan > 0) {
+                if ((rc = exact_search(h, c, c->qlist.as<uint32_t>(), nscan, k, c->out_idx, c->out_score, s))) return rc;
+                if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+        } else if (nfb > 0) {
             c->rewrote = true;
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
                                c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
@@ -1437,6 +1525,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
             if (h->profiling > 1) HIPCHK(hipEventRecord(c->ev[3], s));
             HIPCHK(hipStreamSynchronize(s));
         }
+        (void)nscan;
     }
     float coarse_ms = 0.0f, total_ms = 0.0f;
     if (h->profiling) {
@@ -1450,6 +1539,9 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     std::lock_guard<std::mutex> lk(h->mu);
     h->st.max_observed_err = std::max(h->st.max_observed_err, me);
     h->st.fallback_queries += nfb;
+    h->top2_stats[0] += (c->mfma && c->top2) ? 1u : 0u;
+    h->top2_stats[1] += (c->mfma && c->top2) ? nfb : 0u;
+    h->top2_stats[2] += nrepaired;
     h->st.last_path = (c->mfma && h->n) ? 1u : 0u;
     h->last_top2 = c->mfma && c->top2;
     h->st.last_kprime = c->kprime;
@@ -1618,6 +1710,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "epi")) t.epi = (int)v;
     else if (!strcmp(key, "fuse_sample")) t.fuse_sample = (int)v;
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
+    else if (!strcmp(key, "top2_repair")) t.top2_repair = (int)v;
     else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
     else if (!strcmp(key, "self_publish")) t.self_publish = (int)v;
     else if (!strcmp(key, "fetch_queries")) t.fetch_queries = (int)v;
@@ -1626,6 +1719,17 @@ int cgv_debug_set_(const char* key, double v) {
     return 0;
 }
 #endif  // CGV_ABLATE_BUILD
+
+// internal (tests, scripts): the per-query fallback words of context `ctx` as the last search left them (0 = proven or repaired;
+// 1 = exact scan, upper bits: why the cell re-scan gave up - kernels_repair.h)
+int cgv_debug_fbflags_(cgv_index* h, uint32_t ctx, uint32_t* out, uint32_t nq) {
+    if (!h || !out || ctx >= (uint32_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "bad argument");
+    SearchCtx* c = &h->ctx[ctx];
+    if (c->fbflag.bytes < (size_t)nq * 4) return fail(CGV_ERR_INVALID_ARG, "no such search");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(out, c->fbflag.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return CGV_OK;
+}
 
 // internal (tests, scripts): 1 when the last finished search on the handle took the small-batch form (COARSE_TOP2)
 int cgv_debug_last_top2_(cgv_index* h) { return (h && h->last_top2) ? 1 : 0; }
@@ -2282,7 +2386,7 @@ static int search_host_plain(cgv_index* h, const float* queries_host, uint32_t n
 // k class of a request: batches carry one class, so that a caller asking for a few neighbours is never dragged onto the path
 // a large-k neighbour of the queue needs (0: one COARSE_TOP2 launch; 1: the staged MFMA path; 2: the exact scan).
 static uint32_t coalesce_kclass(const cgv_index* h, uint32_t k) {
-    const uint32_t kp = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k);
+    const uint32_t kp = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k, h->dtype == CGV_DTYPE_FP8E4M3);
     if (kp <= 64) return 0u;
     return (k <= CGV_FAST_MAX_K && kp <= CAND_CAPS && (!h->shadow || k <= 60)) ? 1u : 2u;
 }
@@ -2383,6 +2487,16 @@ int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batc
     if (max_batches_in_flight > (uint32_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "at most cgv_max_batches_in_flight() batches");
     // (applies to calls that arrive from now on; requests already queued are served under whichever values their leader reads)
     h->co.configure(max_batch_queries != 0 && max_batches_in_flight != 0, max_batch_queries, (int)max_batches_in_flight, window_us);
+    return CGV_OK;
+}
+
+int cgv_get_small_batch_stats(cgv_index* h, uint64_t* out4) {
+    if (!h || !out4) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    out4[0] = h->top2_stats[0];
+    out4[1] = h->top2_stats[1];
+    out4[2] = h->top2_stats[2];
+    out4[3] = h->top2_stats[1] - h->top2_stats[2];
     return CGV_OK;
 }
 
@@ -2814,6 +2928,10 @@ int cgv_debug_coarse_scores_dev(cgv_index* h, const float* queries_dev, uint32_t
     a.rexp_c = h->rexp;
     a.rexp_q = c->qrexp.as<int8_t>();
     a.pace = nullptr;
+    a.floor_ord = nullptr;
+    a.cellb = nullptr;
+    a.lad = nullptr;
+    a.ladc = nullptr;
     a.sample_ld = 0;
     a.sample_vals = 16;
     a.epi = 1;

@@ -112,6 +112,8 @@ struct CoarseArgs {
     const float4* ladc;     // [nqt * 256] {tau0, delta, 1 / delta, -}: level j (1..4) of a query starts at tau0 + j * delta; delta <= 0: no ladder
     // COARSE_TOP2 (small batches, Top2 below)
     uint32_t* floor_ord;    // [nq] f2ord of the largest coarse score any cell left OUT of its top-2 (atomicMax; zero at launch)
+    float* cellb;           // [4 * nsplit][64] the same per CELL ((split * 2 + wm) * 2 + lane half; -inf: nothing left out), or NULL:
+                            // what top2_repair_kernel (kernels_repair.h) finds the cells to re-scan with when a floor is too high
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -365,7 +367,7 @@ __device__ __forceinline__ void top2_insert(Top2& t, float v, uint32_t row) {
 }
 // the cells of this wave -> candidate lists (through the per-query LDS counters, like block_hits) and the floor words
 template <int BN, int NB>
-__device__ inline void top2_flush(const CoarseArgs& a, const Top2 (&t)[NB], const float (&invq)[NB], int wn, int lane, uint32_t g,
+__device__ inline void top2_flush(const CoarseArgs& a, const Top2 (&t)[NB], const float (&invq)[NB], int wm, int wn, int lane, uint32_t g,
                                   uint32_t qt, uint32_t* cntq) {
     if ((uint32_t)wn * TOP2_QPW >= a.nq) return;   // (uniform: this wave column holds no query)
     constexpr int nb = 0;                          // (the queries sit in the first N-block of every wave column: top2_col_of)
@@ -382,10 +384,13 @@ __device__ inline void top2_flush(const CoarseArgs& a, const Top2 (&t)[NB], cons
             if (p < CAND_CAPS) a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = make_uint2(__float_as_uint(sc), rv[e]);
             else a.overflow[q] = 1u;
         }
+    float fb = -INFINITY;
     if (t[nb].b > -INFINITY) {
-        const float fb = (a.metric == METRIC_DOT) ? t[nb].b : t[nb].b * iq;   // monotone in b: bounds every left-out row
+        fb = (a.metric == METRIC_DOT) ? t[nb].b : t[nb].b * iq;   // monotone in b: bounds every left-out row
         atomicMax(a.floor_ord + q, f2ord(fb + 0.0f));
     }
+    // (g == the corpus split of this workgroup: one query tile. 16 consecutive queries per wave column: 64-byte segments)
+    if (a.cellb) a.cellb[(((uint64_t)g * 2u + (uint32_t)wm) * 2u + ((uint32_t)lane >> 5)) * 64u + q] = fb;
     (void)qt;
 }
 
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
 #undef CGV_BDMA
 #undef CGV_BDMA_A
 
-    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wn, lane, g, qt, cntq);
+    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wm, wn, lane, g, qt, cntq);
     __syncthreads();
     if (tid == 0) pace_done(pace);
     for (int i = tid; i < BN; i += NT) {

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
 #undef F8_LOAD_A01
 #undef F8_LOAD
 
-    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wn, lane, g, qt, cntq);
+    if (MODE == 4) top2_flush<BN, NB>(a, t2, invq, wm, wn, lane, g, qt, cntq);
     __syncthreads();
     for (int i = tid; i < BN; i += NT) {
         const uint32_t c = cntq[i];

@@ -414,7 +414,14 @@ struct RescoreArgs {
     uint32_t* pub_host;     // their pinned, device-mapped mirror
     uint32_t* pub_count;    // arrival counter: zero at launch, zero again at exit
     uint32_t pub_words;     // n_flags | done word << 8 | error word << 16 | eps word << 24; the done word's marker is nq
+    // COARSE_TOP2 searches: a query whose check fails ONLY because of the floor (a cell left out a row that may belong to the
+    // top-k) is flagged 2 instead of 1 and leaves what top2_repair_kernel needs to re-scan just the offending cells
+    // (kernels_repair.h): the threshold cells are compared with and the exact keys of its re-scored candidates. NULL: off.
+    float* rep_theta;       // [nq]
+    uint64_t* rep_keys;     // [nq][REPAIR_KEYS] exact keys (score, LOCAL row), descending
+    uint32_t* rep_n;        // [nq] how many
 };
+constexpr uint32_t REPAIR_KEYS = 64;
 
 // End-of-search publication (one wave, launched behind the last kernel of a search): the flag words (fallback count,
 // non-finite bits, error maxima, ...) go to the pinned, device-mapped host mirror and are cleared for the next search,
@@ -478,13 +485,15 @@ __device__ inline void stage_query_row(const RescoreArgs& a, uint32_t q, char* q
 template <int DT>
 __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t nb, const uint64_t* ckeys /* LDS [nb] */,
                                     float tau, bool overflow, char* rs /* LDS: staged candidate rows */,
-                                    const char* qs /* LDS: the query row (stage_query_row) */, int tid) {
+                                    const char* qs /* LDS: the query row (stage_query_row) */, int tid,
+                                    float tau_lists = INFINITY /* COARSE_TOP2: the threshold WITHOUT the floor (else unused) */) {
     __shared__ uint64_t ekeys[CAND_CAPS];
-    __shared__ uint32_t maxerr, tripped;
+    __shared__ uint32_t maxerr, tripped, repair_s;
     const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
     if (tid == 0) {
         maxerr = 0;
         tripped = 0;
+        repair_s = 0;
     }
     // eps: bound on |coarse - exact| for THIS query, in score units
     float eps = a.eps_scale;
@@ -512,7 +521,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
     // pieces per C2 batch, ~16 us at the memory system's random-access rate). Everything not re-scored - the other
     // candidates and every row outside the list - has coarse <= tau_eff, the first skipped candidate's score.
     const uint32_t nb_all = nb;
-    float tau_eff = tau;
+    float tau_eff = tau, tau_eff_lists = tau_lists;
     if (nb > a.k && a.k > 0) {
         const float cut = key_score(ckeys[a.k - 1]) - 2.0f * eps;
         uint32_t m = a.k;
@@ -527,6 +536,7 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             // (the first skipped candidate bounds the skipped ones; `tau` everything outside the list - it is the larger of the
             // two only on the COARSE_TOP2 path, where a cell's left-out row may beat the list's tail)
             tau_eff = fmaxf(tau, key_score(ckeys[m]));
+            tau_eff_lists = fmaxf(tau_lists == INFINITY ? -INFINITY : tau_lists, key_score(ckeys[m]));
             nb = m;
         }
     }
@@ -632,8 +642,32 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
             else if (!(key_score(ekeys[a.k - 1]) > tau_eff + eps)) fb = true;
             if (tripped) fb = true;
         }
-        a.fb_flag[q] = fb ? 1u : 0u;
+        // the floor alone failed the check (COARSE_TOP2: three of the query's best rows in one cell): flag 2 - the cells whose
+        // left-out score could reach the top-k are re-scanned exactly (top2_repair_kernel) instead of the whole corpus.
+        // Rows outside the candidates and outside a re-scanned cell have coarse <= theta, hence exact <= theta + eps < e_k.
+        uint32_t flag = fb ? 1u : 0u;
+        if (fb && a.rep_theta && tau_lists != INFINITY) {
+            const float ek = nres >= a.k ? key_score(ekeys[a.k - 1]) : -INFINITY;
+            // (why not, in the upper bits of the word - diagnostics only; any non-zero word means "exact scan")
+            const uint32_t why = (overflow ? 1u : 0u) | (tripped ? 2u : 0u) | ((nb_all < a.k || nres < a.k) ? 4u : 0u) |
+                                 (!(ek > tau_eff_lists + eps) ? 8u : 0u) | (nres > REPAIR_KEYS ? 16u : 0u) |
+                                 (!(fabsf(ek) < INFINITY) ? 32u : 0u);
+            if (why == 0u) {
+                a.rep_theta[q] = ek - 1.001f * eps - 1e-30f;
+                a.rep_n[q] = nres;
+                flag = 2u;
+                repair_s = 1u;
+            } else {
+                flag = 1u | (why << 8);
+            }
+        }
+        a.fb_flag[q] = flag;
         if (fb) atomicAdd(a.fb_count, 1u);
+    }
+    if (a.rep_theta) {   // uniform
+        __syncthreads();
+        if (repair_s != 0u)
+            for (uint32_t j = tid; j < nres; j += 256) a.rep_keys[(uint64_t)q * REPAIR_KEYS + j] = ekeys[j];
     }
     phase_stamp(a.trace, q, 7, tid);
     if (a.pub_host) {   // uniform: a small batch publishes its own flags (RescoreArgs::pub_*)
@@ -707,15 +741,17 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     for (uint32_t i = tid; i < keep; i += 256) ckeys[i] = outk[i];
     // fewer than k' keys: nothing is cut here, but the coarse launches dropped every row at or below THEIR threshold
     float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
+    float tau_lists = INFINITY;   // (COARSE_TOP2 only: the threshold of the candidate lists alone, without the floor)
     if (sa.floor_ord) {   // COARSE_TOP2: rows no cell kept score at most the floor; the lists hold no threshold of their own
         if (M < sa.kprime) tau = -INFINITY;
+        tau_lists = tau;
         const uint32_t fo = sa.floor_ord[q];
         if (fo != 0u) tau = fmaxf(tau, ord2f(fo));
     }
     const bool overflow = trunc || sa.overflow[q] != 0;
     __syncthreads();
     if (sa.floor_ord && tid == 0) sa.floor_ord[q] = 0u;   // (every thread has read it: the barrier above)
-    rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid);
+    rescore_body<DT>(a, q, keep, ckeys, tau, overflow, smem, smem + qoff, tid, tau_lists);
 }
 
 // id slot 0 of a PROVISIONAL record (pack_topk_kernel below): never a row id

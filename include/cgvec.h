@@ -176,6 +176,11 @@ int cgv_search_f32(cgv_index* h, const float* queries_host, uint32_t nq, uint32_
 #define CGV_COALESCE_BATCHES_IN_FLIGHT 1u
 #define CGV_COALESCE_WINDOW_US 250u
 int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batches_in_flight, uint32_t window_us);
+/* Small batches (<= 64 queries: one launch that keeps two rows per 1/1024 of the corpus and checks the result against what it
+ * left out): out4 = {searches that took that form, their queries whose check failed (three of the best rows in one cell: adjacent
+ * near-duplicates do it), of those answered by re-scanning only the offending cells, of those sent to the exact scan of the whole
+ * corpus}. Results are exact either way. */
+int cgv_get_small_batch_stats(cgv_index* h, uint64_t* out4);
 int cgv_get_coalesce_stats(cgv_index* h, uint64_t* out8);
 
 /* Same with DEVICE pointers for queries and outputs (results stay in HBM; the call

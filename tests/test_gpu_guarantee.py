@@ -26,25 +26,32 @@ def _pattern(rng, n, d, kind):
     elif kind == "huge_tiny":        # one dominant coordinate + many tiny ones (alignment / absorption)
         x = 1e-3 * rng.standard_normal((n, d))
         x[np.arange(n), rng.integers(0, d, n)] = 1.0
+    elif kind == "heavy_tail":       # products spread over many binades (what an aligned, truncating adder tree likes least)
+        x = rng.standard_normal((n, d)) * np.exp(1.5 * rng.standard_normal((n, d)))
     else:
         x = rng.standard_normal((n, d))
     return x.astype(np.float32)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp8", "f32s"])
-@pytest.mark.parametrize("d", [768, 4096, 8192])
+@pytest.mark.parametrize("d", [64, 128, 256, 768, 4096, 8192])
 def test_measured_coarse_error_stays_inside_the_model_bound(oracle, dtype, d):
+    """(Round 6: D = 64 .. 256 and the near-duplicate / heavy-tail patterns. The eps of rounds 2-5 shrank with D while the error
+    of the fp8 block-scaled MFMA does not: an fp8 index of D = 64 measured 2.4 x its eps on plain random data - cgvec.hip
+    coarse_eps_scale (1').)"""
     import torch
     m = pkg()
     rng = np.random.default_rng(d)
-    n, nq = 320, 40
+    n, nq = (1280, 64) if d <= 256 else (320, 40)
     worst = {}
-    for kind in ("same_sign", "alternating", "huge_tiny", "gauss"):
+    for kind in ("same_sign", "alternating", "huge_tiny", "gauss", "near_dup", "heavy_tail"):
         rows = _pattern(rng, n, d, kind)
         q = _pattern(rng, nq, d, "same_sign" if kind in ("same_sign", "alternating") else kind)
         if kind == "huge_tiny":
             q[:, :] = 1e-3 * rng.standard_normal((nq, d)).astype(np.float32)
             q[np.arange(nq), np.arange(nq) % d] = 1.0
+        if kind == "near_dup":       # cosine ~ 1: every product positive AND of the data's own spread of magnitudes
+            rows[:nq] = q + 0.01 * rng.standard_normal((nq, d)).astype(np.float32)
         ix = m.HipKnnIndex(d, dtype=dtype)
         try:
             ix.add(rows)

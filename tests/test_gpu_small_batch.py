@@ -49,7 +49,9 @@ def test_small_batches_equal_the_oracle(oracle, dtype, odt, metric):
             fb0 = st["fallback_queries"]
         # larger k on the path (k' <= 64) and just off it
         q = rng.standard_normal((5, d)).astype(np.float32)
-        for kk, on in ((50, 1), (60, 0)):
+        # (fp8 keeps k' = 2k + 12 candidates - its coarse error bound does not shrink with D, cgvec.hip coarse_eps_scale (1') -
+        # so k' <= 64 holds up to k = 26)
+        for kk, on in (((26, 1), (27, 0)) if dtype == "fp8" else ((50, 1), (60, 0))):
             if dtype == "f32s" and kk > 12:
                 continue                                # (f32 + shadow re-scores 4k + 16 candidates: k' <= 64 only up to k = 12)
             gi, gs = ix.search(q, kk)
@@ -60,10 +62,11 @@ def test_small_batches_equal_the_oracle(oracle, dtype, odt, metric):
         ix.close()
 
 
-def test_three_top_rows_in_one_cell_fall_back_to_the_exact_scan(oracle):
+def test_three_top_rows_in_one_cell_are_repaired_by_a_cell_rescan(oracle):
     """Rows 0..3 of a tile (M-block 0, registers 0..3 of lane half 0) belong to ONE cell: three near-identical copies of the
-    query there leave the third out of the cell's top-2, the floor rises to its score, the guarantee check fails and the query
-    is answered by the exact scan - the other queries of the batch stay on the fast path. Identical rows (exact ties) too."""
+    query there leave the third out of the cell's top-2, the floor rises to its score and the guarantee check fails. Round 6:
+    the offending cell alone is scanned again with the reference's arithmetic (kernels_repair.h) instead of the whole corpus -
+    the other queries of the batch stay on the fast path. Identical rows (exact ties) too."""
     m = pkg()
     rng = np.random.default_rng(43)
     n, d, k = 30_000, 128, 10
@@ -83,8 +86,51 @@ def test_three_top_rows_in_one_cell_fall_back_to_the_exact_scan(oracle):
         ri, rs = oracle.batch_top_k(q, rows, k, dtype=1)
         assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
         assert _last_top2(m, ix) == 1
-        assert ix.stats()["fallback_queries"] == 1       # query 4 only
+        assert ix.stats()["fallback_queries"] == 1       # query 4 only failed its check ...
+        sb = ix.small_batch_stats()
+        assert sb["failed_queries"] == 1 and sb["repaired_by_cell_rescan"] == 1 and sb["exact_scans"] == 0, sb   # ... and was repaired
         assert set(gi[4][:3].tolist()) == {t, t + 1, t + 2}
+        # the same call again (the context's flag words and repair buffers are reused), and one query at a time
+        for _ in range(2):
+            gi, gs = ix.search(q, k)
+            assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+        g1, s1 = ix.search(q[4], k)
+        assert np.array_equal(g1[0], ri[4]) and np.array_equal(s1[0], rs[4])
+        assert ix.small_batch_stats()["exact_scans"] == 0
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype,odt,metric", [("bf16", 1, "cosine"), ("fp16", 2, "dot"), ("fp8", 3, "cosine"), ("f32s", 0, "cosine")])
+def test_clustered_corpus_stays_off_the_exact_scan(oracle, dtype, odt, metric):
+    """A code-embedding store inserts the chunks of one file next to each other and holds near-duplicates: here every
+    'file' is 5 adjacent near-copies of one vector, and each query sits next to one file - 5 of its top-10 are adjacent rows, 4 of
+    them in one cell. Most queries fail the COARSE_TOP2 check; all of them are answered by re-scanning a cell or two, none by the
+    exact scan of the corpus, and every answer is the oracle's."""
+    m = pkg()
+    rng = np.random.default_rng(71)
+    n_files, per, d, k = 8000, 5, 96, 10
+    centers = rng.standard_normal((n_files, d)).astype(np.float32)
+    rows = np.repeat(centers, per, axis=0) + 0.02 * rng.standard_normal((n_files * per, d)).astype(np.float32)
+    rows = np.concatenate([rng.standard_normal((3, d)).astype(np.float32), rows])     # files do not start on a multiple of 4
+    nq = 48
+    picks = rng.choice(n_files, nq, replace=False)
+    q = centers[picks] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    omet = oracle.COSINE if metric == "cosine" else oracle.DOT
+    ix = m.HipKnnIndex(d, dtype=dtype, metric=metric)
+    try:
+        ix.add(rows)
+        ri, rs = oracle.batch_top_k(q, rows, k, metric=omet, dtype=odt)
+        gi, gs = ix.search(q, k)
+        assert _last_top2(m, ix) == 1
+        assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+        sb = ix.small_batch_stats()
+        assert sb["failed_queries"] >= nq // 2, sb               # the placement does what the test says it does
+        assert sb["exact_scans"] == 0 and sb["repaired_by_cell_rescan"] == sb["failed_queries"], sb
+        for j in (0, 7, 31):                                     # the trait-level call: one query
+            g1, s1 = ix.search(q[j], k)
+            assert np.array_equal(g1[0], ri[j]) and np.array_equal(s1[0], rs[j]), j
+        assert ix.small_batch_stats()["exact_scans"] == 0
     finally:
         ix.close()
 
