@@ -41,6 +41,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 # Hardware queues of the HIP runtime (read when the runtime starts: before torch is imported). Its default of 4 is shared by every
@@ -171,10 +172,30 @@ def run_native_callers(CL, ix, q, k, threads, calls, warm=3, nq_per_call=1):
     return oi, os_, lat, wall.value
 
 
+RNG = "counter"   # --rng: "counter" = SURVEY.md section 8(d)'s generator; "torch" = rounds 1-5's torch.randn chunks
+
+
 def gen_chunk(c, rows, dim, device):
+    """Rows [c * CHUNK, c * CHUNK + rows) of the corpus, unit-norm f32 on the device. `counter`: the counter-based stream
+    keyed (seed, row, col) of SURVEY.md section 8(d) (cgv_synth_rows_f32_dev; the CPU oracle's cgo_synth_rows produces the same
+    bits, tests/test_synth.py) - the same corpus whatever the chunking, the rank count or the torch / rocRAND build."""
+    if RNG == "counter":
+        from importlib import import_module
+        return import_module("codegraph-rust_amd").cgvec.synth_rows_dev(SEED_CORPUS, c * CHUNK, rows, dim,
+                                                                         device=torch.device(device).index or 0)
     g = torch.Generator(device=device).manual_seed(SEED_CORPUS + c)
     x = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
     return torch.nn.functional.normalize(x, dim=1)
+
+
+def gen_query_pool(npool, batch, dim, device):
+    """npool query batches of `batch` unit-norm f32 rows on the device (stream SEED_QUERY; batch p = rows [p * batch, ...))."""
+    if RNG == "counter":
+        from importlib import import_module
+        cg = import_module("codegraph-rust_amd").cgvec
+        return [cg.synth_rows_dev(SEED_QUERY, p * batch, batch, dim, device=torch.device(device).index or 0) for p in range(npool)]
+    gq = torch.Generator(device=device).manual_seed(SEED_QUERY)
+    return [torch.nn.functional.normalize(torch.randn((batch, dim), generator=gq, device=device), dim=1) for _ in range(npool)]
 
 
 def respawn_under_launcher(n):
@@ -199,11 +220,37 @@ class Watchdog:
         import threading
         self.limit, self.rank, self.world = float(limit_s), rank, world
         self.stage, self.last, self.on = "start", time.monotonic(), limit_s > 0
+        # every rank leaves its last completed stage in a file of its own (one node: a shared /tmp), so that the error line of a
+        # hung run names the stage EVERY rank reached - the ranks that hang in a collective cannot be asked through one
+        self.dir = os.path.join(tempfile.gettempdir(), f"cgv_bench_{os.environ.get('MASTER_PORT', 'solo')}_{os.getuid()}")
         if self.on:
+            os.makedirs(self.dir, exist_ok=True)
+            self._write()
             threading.Thread(target=self._run, daemon=True).start()
 
+    def _write(self):
+        try:
+            with open(os.path.join(self.dir, f"rank{self.rank}.stage"), "w") as f:
+                f.write(f"{self.stage}\t{time.time():.3f}")
+        except OSError:
+            pass
+
     def kick(self, stage):
+        changed = stage != self.stage
         self.stage, self.last = stage, time.monotonic()
+        if self.on and changed:
+            self._write()
+
+    def stages_of_all_ranks(self):
+        out = []
+        for r in range(self.world):
+            try:
+                with open(os.path.join(self.dir, f"rank{r}.stage")) as f:
+                    st, ts = f.read().split("\t")
+                out.append({"rank": r, "last_stage": st, "seconds_ago": round(time.time() - float(ts), 1)})
+            except (OSError, ValueError):
+                out.append({"rank": r, "last_stage": None, "seconds_ago": None})
+        return out
 
     def stop(self):
         self.on = False
@@ -215,15 +262,79 @@ class Watchdog:
             if self.on and time.monotonic() - self.last > limit:
                 msg = f"no progress for {limit:.0f} s in stage '{self.stage}' (rank {self.rank} of {self.world})"
                 if self.rank == 0:
-                    print(json.dumps(error_line(self.world, msg, self.stage)), flush=True)
+                    print(json.dumps(error_line(self.world, msg, self.stage, self.stages_of_all_ranks())), flush=True)
                 else:
                     print(f"bench.py: {msg}", file=sys.stderr, flush=True)
                 os._exit(3)
 
 
-def error_line(world, msg, stage=None):
+def error_line(world, msg, stage=None, per_rank=None):
     return {"metric": "queries_per_sec", "value": None, "unit": "queries/s", "n_gpus": world, "higher_is_better": True,
-            "error": msg, "stage": stage}
+            "error": msg, "stage": stage, "per_rank_last_stage": per_rank}
+
+
+def rank_diagnostics(dist, searcher, phases, st, dev, dev_index, ctl, world, gloo, batch, dim, k, wd):
+    """What makes a first run on N GPUs readable in one shot (nobody has seen this path with more than one RCCL rank): where one
+    batch of EVERY rank goes (HIP events at the phase boundaries: the library's profiling level 3 + ShardedKnn's events, on the
+    stream the batch runs on), what an all-gather of the record size and of the query-batch size costs in this process group,
+    which physical device every rank sits on (two ranks on one GPU would show up here) and whether peers are reachable."""
+    ph = searcher.last_phase_ms or {"queries": 0.0, "search_pack": 0.0, "all_gather": 0.0, "merge": 0.0}
+    lib_us = [phases["prep"], phases["first_threshold"], phases["emitting"], phases["final_publish"]]
+    mine = [*lib_us, max(0.0, 1e3 * ph["search_pack"] - sum(lib_us)), 1e3 * ph["queries"], 1e3 * ph["all_gather"], 1e3 * ph["merge"],
+            1e3 * st["last_total_ms"]]
+    names = ["prep", "sample_tau", "emitting", "final_publish", "pack_and_gaps", "query_exchange", "all_gather", "merge",
+             "search_device_total"]
+    t = torch.tensor(mine, dtype=torch.float64, device=ctl)
+    allr = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allr, t)
+    allr = [x.cpu().tolist() for x in allr]
+    per_phase = {n: {"max": round(max(r[i] for r in allr), 1), "min": round(min(r[i] for r in allr), 1),
+                     "per_rank": [round(r[i], 1) for r in allr]} for i, n in enumerate(names)}
+    wd.kick("phase breakdown gathered")
+
+    def gather_us(words, iters=50):   # all_gather_into_tensor of `words` int32 per rank, HIP events on the current stream
+        if gloo:
+            src = torch.zeros(words, dtype=torch.int32)
+            dst = [torch.empty_like(src) for _ in range(world)]
+            for _ in range(3):
+                dist.all_gather(dst, src)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                dist.all_gather(dst, src)
+            return 1e6 * (time.perf_counter() - t0) / iters
+        src = torch.zeros(words, dtype=torch.int32, device=dev)
+        dst = torch.empty(world * words, dtype=torch.int32, device=dev)
+        for _ in range(5):
+            dist.all_gather_into_tensor(dst, src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            dist.all_gather_into_tensor(dst, src)
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / iters
+    from importlib import import_module
+    rec_words = batch * import_module("codegraph-rust_amd").sharded.packed_width(k)
+    ag_rec = gather_us(rec_words)
+    ag_q = gather_us((batch + world - 1) // world * dim)
+    wd.kick("all-gather micro-latency measured")
+    props = torch.cuda.get_device_properties(dev)
+    ident = {"rank": dist.get_rank(), "device_index": dev_index, "uuid": str(getattr(props, "uuid", "")),
+             "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "pci_device_id": int(getattr(props, "pci_device_id", -1)),
+             "name": props.name, "visible_devices": torch.cuda.device_count(),
+             "can_access_peer": [bool(torch.cuda.can_device_access_peer(dev_index, j)) for j in range(torch.cuda.device_count())
+                                 if j != dev_index]}
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    keys = [(i["uuid"], i["pci_bus_id"], i["pci_device_id"]) for i in idents]
+    return {"per_rank_phases_us": per_phase,
+            "all_gather_latency_us": {"packed_records": round(ag_rec, 1), "packed_records_bytes_per_rank": rec_words * 4,
+                                      "query_slices": round(ag_q, 1), "query_slice_bytes_per_rank": (batch + world - 1) // world * dim * 4,
+                                      "note": "all_gather_into_tensor in this process group, 50 back to back on one stream, HIP events "
+                                              "(gloo dry run: host wall time)"},
+            "per_rank_device_identity": idents,
+            "ranks_on_distinct_devices": len(set(keys)) == world}
 
 
 def bench_sharded_handle(args, m, dev):
@@ -238,9 +349,7 @@ def bench_sharded_handle(args, m, dev):
     for c in range((n_total + CHUNK - 1) // CHUNK):
         c_lo, c_hi = c * CHUNK, min(n_total, (c + 1) * CHUNK)
         sx.add(gen_chunk(c, c_hi - c_lo, dim, dev).cpu().numpy())
-    gq = torch.Generator(device=dev).manual_seed(SEED_QUERY)
-    qhost = [torch.nn.functional.normalize(torch.randn((batch, dim), generator=gq, device=dev), dim=1).cpu().numpy()
-             for _ in range(4)]
+    qhost = [q.cpu().numpy() for q in gen_query_pool(4, batch, dim, dev)]
     for i in range(args.warmup):
         sx.search(qhost[i % 4], k)
     t0 = time.perf_counter()
@@ -280,7 +389,7 @@ def bench_sharded_handle(args, m, dev):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload.upper()} through ONE cgv_sharded handle: {n_total} x {dim} {dtype} {metric}, "
                                f"batch={batch}, k={k}, {G} shards on {min(G, nd)} device(s)",
-                   "rows": n_total, "dim": dim, "batch": batch, "k": k, "metric": metric, "sharding": f"block-cyclic rows/{G}",
+                   "rows": n_total, "dim": dim, "batch": batch, "k": k, "metric": metric, "sharding": f"block-cyclic rows/{G}", "rng": RNG,
                    "step": "cgv_sharded_search_f32: host queries -> every shard -> pack -> exchange -> merge -> host results",
                    "exchange": st["exchange"]},
         "two_in_flight": {"queries_per_sec": round(batch * args.steps / piped, 1), "ms_per_batch": round(1e3 * piped / args.steps, 4),
@@ -300,6 +409,9 @@ def main():
                          "timed region was 28 ms of a 20 s run)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; 3 for the big workloads)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--rng", default="counter", choices=("counter", "torch"),
+                    help="synthetic inputs: `counter` = SURVEY.md 8(d)'s counter-based generator keyed (seed, row, col), identical "
+                         "on the device and in the CPU oracle; `torch` = torch.randn per 125 k-row chunk (rounds 1-5)")
     ap.add_argument("--pipelined-steps", type=int, default=None,
                     help="batches of each pipelined side measurement (default: --steps; 0 = skip): `pipelined_host` = the SAME "
                          "work as a step (pinned host batch in, host results out, exchange + merge included when N > 1) with "
@@ -332,6 +444,11 @@ def main():
                          "RCCL refuses two ranks on one device): every rank owns a real device shard, packs and merges on the "
                          "device, the packed records and the control collectives travel over gloo through the host - the whole "
                          "world > 1 control flow of this file on a 1-GPU box; its numbers are not a scaling measurement")
+    ap.add_argument("--query-exchange", default="auto", choices=("auto", "replicated", "sharded"),
+                    help="N > 1: how the host query batch reaches the ranks - every rank reads all of it over its own PCIe link "
+                         "(replicated), or each rank moves 1/N of it and one all-gather of the f32 slices over xGMI completes it "
+                         "(sharded; ShardedKnn.query_exchange). auto = both forms are timed in a short trial before the warm-up "
+                         "(multi_gpu.query_exchange) and the faster one runs the timed steps")
     ap.add_argument("--dist-timeout", type=float, default=180.0,
                     help="seconds: process-group timeout AND the no-progress limit of the watchdog - a hung collective ends the "
                          "run with a JSON line carrying an `error` field instead of hanging the launcher")
@@ -347,6 +464,8 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="print this rank's RANK/WORLD_SIZE and exit before touching a GPU (CPU test of the self-spawn)")
     args = ap.parse_args()
+    global RNG
+    RNG = args.rng
     big = args.workload in ("c5shard", "c5mini", "c3", "c3shard")       # steps of 6 - 300 ms
     if args.steps is None:
         args.steps = {"c5shard": 5, "c3": 20}.get(args.workload, 50 if big else 200)
@@ -379,7 +498,8 @@ def main():
         import traceback
         traceback.print_exc()
         if rank == 0:
-            print(json.dumps(error_line(world, f"{type(e).__name__}: {e}", wd.stage)), flush=True)
+            print(json.dumps(error_line(world, f"{type(e).__name__}: {e}", wd.stage, wd.stages_of_all_ranks() if wd.on else None)),
+                  flush=True)
         wd.stop()
         os._exit(1)   # (not sys.exit: a broken process group may block interpreter shutdown in its destructors)
 
@@ -461,10 +581,8 @@ def run(args, wd, world, rank, local_rank):
             host_chunks.append(storage_values(x, dtype).cpu().numpy())   # rounded-then-upcast values
         del x
     wd.kick("corpus loaded")
-    gq = torch.Generator(device=dev).manual_seed(SEED_QUERY)
     npool = 4 if batch >= 64 else 128      # (single-query workloads: enough distinct queries for the CPU leg and the medians)
-    qpool = [torch.nn.functional.normalize(torch.randn((batch, dim), generator=gq, device=dev), dim=1)
-             for _ in range(npool)]
+    qpool = gen_query_pool(npool, batch, dim, dev)
     qhost = [q.cpu().pin_memory() for q in qpool]           # the caller's query batches: pinned host memory
     out_i = torch.empty((batch, k), dtype=torch.int64).pin_memory()
     out_s = torch.empty((batch, k), dtype=torch.float32).pin_memory()
@@ -526,6 +644,30 @@ def run(args, wd, world, rank, local_rank):
             wd.kick("settle")
             if not go:
                 break
+    query_exchange = None
+    if dist is not None:
+        # How the host batch reaches the ranks: both forms timed in the same process group, same clocks (setup, like the settle
+        # loop); max_over_ranks gives every rank the same two numbers, so every rank picks the same form
+        def trial(mode, nsteps=30):
+            searcher.query_exchange = mode
+            for i in range(3):
+                step(i)
+            sync_all()
+            tq = time.perf_counter()
+            for i in range(nsteps):
+                step(i)
+            sync_all()
+            wd.kick(f"query-exchange trial: {mode}")
+            return 1e3 * max_over_ranks(time.perf_counter() - tq) / nsteps
+        rep_ms = trial("replicated")
+        sha_ms = trial("sharded")
+        chosen = args.query_exchange if args.query_exchange != "auto" else ("sharded" if sha_ms < rep_ms else "replicated")
+        searcher.query_exchange = chosen
+        query_exchange = {"replicated_ms": round(rep_ms, 4), "sharded_ms": round(sha_ms, 4), "timed_steps_use": chosen,
+                          "selection": args.query_exchange,
+                          "note": "ms per serial step, 30 steps each, max over ranks; replicated = every rank reads the whole pinned "
+                                  "batch over its own PCIe link; sharded = each rank copies batch/N rows to its device and ONE "
+                                  "all-gather of the f32 slices over xGMI completes the batch in HBM (identical results)"}
     for i in range(args.warmup):
         step(i)
     wd.kick("warm-up done")
@@ -545,13 +687,15 @@ def run(args, wd, world, rank, local_rank):
     if os.environ.get("BENCH_DEBUG_STEPS"):   # (diagnostics: where in the timed region the slow steps sit)
         print("step_ms:", " ".join(f"{x:.3f}" for x in step_ms), file=sys.stderr, flush=True)
     wd.kick("timed steps done")
-    ix.set_profiling(2)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step)
+    ix.set_profiling(3)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step) and the phase events
     step(0)
     step(1)
     st = ix.stats()
+    phases = ix.phase_times_us()
     ix.set_profiling(1)
     multi = None
     if dist is not None:
+        diag = rank_diagnostics(dist, searcher, phases, st, dev, dev_index, ctl, world, gloo, batch, dim, k, wd)
         # self-proof of the N-rank run: a collective-derived rank count, every rank's dominant-launch
         # time and shard size, and the exchange time - gathered with RCCL itself, not built from WORLD_SIZE
         ones = torch.ones(1, device=ctl)
@@ -572,6 +716,8 @@ def run(args, wd, world, rank, local_rank):
                  "per_rank_device": [int(r[4]) for r in allr],
                  "exchange_ms": round(max(r[2] for r in allr), 4),
                  "redo_batches": searcher.redo_batches,
+                 "query_exchange": query_exchange,
+                 **diag,
                  "exchange": ("records packed behind the search's last kernel; DRY RUN: D2H, gloo all_gather, H2D, merge kernel "
                               "(host join in the middle - not timed)") if gloo else
                              ("records packed behind the search's last kernel, torch.distributed all_gather_into_tensor (backend "
@@ -912,6 +1058,8 @@ def run(args, wd, world, rank, local_rank):
             "config": {"workload": f"{args.workload.upper()}: {n_total} x {dim} {dtype} {metric} brute-force kNN, "
                                    f"batch={batch}, k={k}", "rows": n_total, "dim": dim, "batch": batch, "k": k,
                        "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
+                       "rng": ("counter-based (Philox4x32-10 keyed seed,row,col -> N(0,1) f32 -> unit norm; corpus seed 0xC0DE6001, "
+                               "queries 0xC0DE6002: SURVEY.md 8(d))") if RNG == "counter" else "torch.randn per 125 k-row chunk",
                        "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
                        "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none",
                        "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}},
@@ -995,6 +1143,12 @@ def run(args, wd, world, rank, local_rank):
         from oracle import oracle as o   # CPU baseline + recall checker only
         rows_host = np.concatenate(host_chunks)
         del host_chunks
+        rng_same = None
+        if RNG == "counter" and lo == 0:   # the device's corpus and queries are what the CPU generator produces (sampled here; -m gpu: tests/test_synth.py)
+            ocode = {"f32": o.F32, "f32s": o.F32, "bf16": o.BF16, "fp16": o.FP16, "fp8": o.FP8}[dtype]
+            ns = min(4096, len(rows_host))
+            rng_same = bool(np.array_equal(rows_host[:ns], o.round_trip(o.synth_rows(SEED_CORPUS, 0, ns, dim), ocode, fp8_codes=True))
+                            and np.array_equal(qpool[0].cpu().numpy(), o.synth_rows(SEED_QUERY, 0, batch, dim)))
         rs = o.RowSet(rows_host)
         del rows_host
         qcat = qpool[0] if batch >= args.cpu_max_queries else torch.cat(qpool)    # (single-query workloads: one query per batch)
@@ -1015,6 +1169,7 @@ def run(args, wd, world, rank, local_rank):
         scan_gbs = n_total * dim * 4 / max(leg["score_ms"], 1e-9) / 1e6
         result["cpu_baseline"] = {"value": round(nqc / cpu_t, 3), "unit": "queries/s", "cores": leg["cores"],
                                   "kind": "port", "numa_nodes": o.numa_nodes(), "host": host_cpus(),
+                                  "inputs_same_as_cpu_generator": rng_same,
                                   "thread_sweep_ms_per_query": leg["thread_sweep_ms"],
                                   "score_ms": round(leg["score_ms"], 2), "sort_ms": round(leg["sort_ms"], 2),
                                   "scan_gb_per_s": round(scan_gbs, 1), "scan_gb_per_s_per_thread": round(scan_gbs / leg["cores"], 2),

@@ -103,6 +103,8 @@ def lib():
     L.cgv_batch_similarity_f32.argtypes = [vp, vp, i32, u64, vp]
     L.cgv_search_baseline_f32.argtypes = [vp, vp, u32, vp, vp, C.POINTER(u32)]
     L.cgv_normalize_rows_f32.argtypes = [i32, vp, u64, u32]
+    L.cgv_normalize_rows_scalar_f32.argtypes = [i32, vp, u64, u32]
+    L.cgv_synth_rows_f32_dev.argtypes = [i32, u64, u64, u64, u32, i32, vp, vp]
     L.cgv_merge_topk_dev.argtypes = [i32, vp, vp, u32, u32, u32, vp, vp, vp]
     L.cgv_host_device_alias.argtypes = [i32, vp, C.c_size_t]
     L.cgv_host_device_alias.restype = vp
@@ -154,6 +156,8 @@ def lib():
     L.cgv_get_coalesce_stats.argtypes = [vp, C.POINTER(u64)]
     L.cgv_get_coalesce_stats.restype = i32
     L.cgv_get_small_batch_stats.argtypes = [vp, C.POINTER(u64)]
+    L.cgv_get_phase_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cgv_get_phase_times.restype = i32
     L.cgv_get_small_batch_stats.restype = i32
     L.cgv_alloc_pinned.argtypes = [C.c_size_t]
     L.cgv_alloc_pinned.restype = vp
@@ -169,7 +173,7 @@ def lib():
         getattr(L, name).restype = i32
     for name in ("cgv_pack_topk_dev", "cgv_merge_packed_dev", "cgv_add_f64", "cgv_load_mmap", "cgv_write_mmap_f32", "cgv_save_mmap", "cgv_create", "cgv_destroy", "cgv_reserve", "cgv_add_f32", "cgv_add_f32_dev",
                  "cgv_set_index_base", "cgv_update_row_f32", "cgv_search_f32", "cgv_search_f32_dev", "cgv_search_begin_f32_dev", "cgv_search_end", "cgv_get_row_f32",
-                 "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
+                 "cgv_merge_topk_dev", "cgv_batch_similarity_f32", "cgv_search_baseline_f32", "cgv_normalize_rows_f32", "cgv_normalize_rows_scalar_f32", "cgv_synth_rows_f32_dev", "cgv_set_stream", "cgv_use_own_stream", "cgv_synchronize", "cgv_get_stats",
                  "cgv_set_profiling", "cgv_set_force_exact", "cgv_debug_coarse_scores_dev"):
         getattr(L, name).restype = i32
     _lib = L
@@ -277,6 +281,12 @@ class HipKnnIndex:
         _check(lib().cgv_get_coalesce_stats(self._h, out))
         names = ("batches", "batched_requests", "batched_queries", "lone_calls", "retried_alone", "max_batch_queries", "window_waits")
         return {n: int(out[i]) for i, n in enumerate(names)}
+
+    def phase_times_us(self):
+        """Profiling level 3: device microseconds of the last finished search's phases (cgv_get_phase_times)."""
+        out = (C.c_float * 4)()
+        _check(lib().cgv_get_phase_times(self._h, out))
+        return dict(zip(("prep", "first_threshold", "emitting", "final_publish"), (round(float(x), 2) for x in out)))
 
     def small_batch_stats(self):
         out = (C.c_uint64 * 4)()
@@ -661,13 +671,27 @@ class ShardedIndex:
         return _Pending()
 
 
-def normalize_rows(rows, device=0):
-    """parallel_normalize_vectors on device; returns a normalised copy."""
+def normalize_rows(rows, device=0, arm="avx2"):
+    """parallel_normalize_vectors on device; returns a normalised copy. arm = "avx2" (simd_ops.rs:189-222, what an
+    AVX2 + FMA host runs) or "scalar" (simd_ops.rs:394-415, every other host)."""
     r = np.array(rows, dtype=np.float32, copy=True, order="C")
     if r.ndim == 1:
         r = r[None, :]
-    _check(lib().cgv_normalize_rows_f32(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1]))
+    fn = lib().cgv_normalize_rows_f32 if arm == "avx2" else lib().cgv_normalize_rows_scalar_f32
+    _check(fn(device, r.ctypes.data_as(C.c_void_p), r.shape[0], r.shape[1]))
     return r
+
+
+def synth_rows_dev(seed, row0, nrows, dim, normalise=True, device=0, out=None):
+    """rows [row0, row0 + nrows) of the counter-based stream `seed` as a float32 DEVICE tensor
+    (cgv_synth_rows_f32_dev on torch's current stream); `out` = an existing [nrows, dim] float32 cuda tensor to fill."""
+    import torch
+    if out is None:
+        out = torch.empty((nrows, dim), dtype=torch.float32, device=f"cuda:{device}")
+    assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (nrows, dim)
+    _check(lib().cgv_synth_rows_f32_dev(device, seed, row0, nrows, dim, 1 if normalise else 0, out.data_ptr(),
+                                        torch.cuda.current_stream(out.device).cuda_stream))
+    return out
 
 
 def write_mmap(path, rows):

@@ -186,6 +186,7 @@ struct SearchCtx {
     hipStream_t run = nullptr;
     hipStream_t cur() const { return on_caller ? run : stream; }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pev[3] = {nullptr, nullptr, nullptr};   // profiling level 3: behind the query conversion, the first threshold, the last emitting launch
     // cgv_search_packed_begin_f32_dev: recorded on the consumer's stream right behind the pack kernel. The consumer's stream is
     // SHARED with whatever the caller enqueues next (the collective, the merge, the next batch of the same stream), so the
     // search's end waits for THIS, not for the stream (end(A) used to be serialised behind batch B's device work)
@@ -281,6 +282,7 @@ struct cgv_index {
     uint64_t top2_stats[3] = {0, 0, 0};   // COARSE_TOP2 searches, their queries that failed the check, of those repaired by a cell re-scan
     cgv_stats st;
     uint64_t last_coarse_rows = 0;
+    float last_phase_us[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // cgv_get_phase_times
     Coalescer co;   // group commit of concurrent small cgv_search_f32 calls (coalesce.h)
     cgv_index() {
         memset(&st, 0, sizeof(st));
@@ -1030,6 +1032,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         HIPCHK(hipGetLastError());
     }
 
+    if (h->profiling > 2) HIPCHK(hipEventRecord(c->pev[0], s));
     // f32 + shadow: the coarse scores carry bf16 rounding error (~2e-3), so more candidates are re-scored
     const uint32_t kprime = h->shadow ? std::min<uint32_t>(((4 * k + 16 + 7) / 8) * 8, 256u) : kprime_of(k, h->dtype == CGV_DTYPE_FP8E4M3);
     const bool mfma = !h->force_exact && !h->wide_range && (h->dtype != CGV_DTYPE_F32 || h->shadow) && kprime <= CAND_CAPS &&
@@ -1161,6 +1164,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                 c->t2_R = a.R;
                 c->t2_P = a.P;
             }
+            if (h->profiling > 2) HIPCHK(hipEventRecord(c->pev[1], s));   // (no threshold phase: the one launch counts as emitting)
             if (h->profiling) HIPCHK(hipEventRecord(c->ev[1], s));
             if ((rc = launch_coarse(cdt, COARSE_TOP2, a, a.nsplit, s))) return rc;
             if (h->profiling) {
@@ -1217,6 +1221,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             HIPCHK(hipGetLastError());
             if ((rc = launch_select(c, nq, nqt, 0, kprime, c->dump.as<float>(), n_boot, s, 0, sampled))) return rc;
         }
+        if (h->profiling > 2 && !top2) HIPCHK(hipEventRecord(c->pev[1], s));
         uint32_t j0 = 0;
         const bool fused_final = kprime <= 64 && !p.counts.empty();  // extraction path of select (k' <= 64)
         uint32_t last_nsplit = top2_nsplit;
@@ -1261,6 +1266,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             }
             j0 += cnt;
         }
+        if (h->profiling > 2) HIPCHK(hipEventRecord(c->pev[2], s));
         RescoreArgs r;
         r.best = c->best.as<uint64_t>();
         r.nbest = c->nbest.as<uint32_t>();
@@ -1533,6 +1539,15 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         if (c->timed_coarse && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) coarse_ms = ms;
         if (h->profiling > 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) total_ms = ms;
     }
+    float phase_us[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // level 3, MFMA path: conversion | first threshold | emitting launches | final + publish
+    if (h->profiling > 2 && c->mfma && h->n && !c->rewrote) {
+        hipEvent_t seq[5] = {c->ev[0], c->pev[0], c->pev[1], c->pev[2], c->ev[3]};
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, seq[i], seq[i + 1]) == hipSuccess) phase_us[i] = 1e3f * ms;
+            else (void)hipGetLastError();
+        }
+    }
     // the last kernel reset the flag words - unless the exact scan ran afterwards (its kernels use them too)
     c->flags_clean = c->published && !c->rewrote;
     if (c->mfma && c->top2) c->floor_clean = true;   // final_kernel ran for every query and cleared the floor words it read
@@ -1548,6 +1563,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     h->st.last_eps = c->eps;
     h->st.last_coarse_ms = coarse_ms;
     h->st.last_total_ms = total_ms;
+    for (int i = 0; i < 4; ++i) h->last_phase_us[i] = phase_us[i];
     h->last_coarse_rows = c->coarse_rows;
     return CGV_OK;
 }
@@ -1803,6 +1819,7 @@ int cgv_create(uint32_t dim, int metric, int dtype, int device_id, cgv_index** o
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.packed_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.copied, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c.ev[i]);
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&c.pev[i]);
         if (e == hipSuccess) e = hipMalloc((void**)&c.flags, CTX_FLAG_WORDS * 4);
         if (e == hipSuccess) e = hipHostMalloc((void**)&c.h_flags, F_COUNT * 4, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_flags_dev, c.h_flags, 0);
@@ -1850,6 +1867,8 @@ int cgv_destroy(cgv_index* h) {
         if (c.copied) (void)hipEventDestroy(c.copied);
         for (int i = 0; i < 4; ++i)
             if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
+        for (int i = 0; i < 3; ++i)
+            if (c.pev[i]) (void)hipEventDestroy(c.pev[i]);
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->flags) (void)hipFree(h->flags);
@@ -2696,7 +2715,7 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
     return CGV_OK;
 }
 
-int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim) {
+static int normalize_rows_host(int device_id, float* rows_host, uint64_t n, uint32_t dim, bool scalar_arm) {
     if (n == 0 || dim == 0) return CGV_OK;  // simd_ops.rs:190-192
     if (!rows_host) return fail(CGV_ERR_INVALID_ARG, "rows is NULL");
     if (cgv_device_count() == 0) return fail(CGV_ERR_HIP, "no HIP device visible: libcgvec_hip has no CPU fallback");
@@ -2706,13 +2725,22 @@ int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t
     HIPCHK(hipMalloc((void**)&d, bytes));
     hipError_t e = hipMemcpy(d, rows_host, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, 0, d, n, dim);
+        if (scalar_arm) hipLaunchKernelGGL(normalize_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, n, dim);
+        else hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, 0, d, n, dim);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(rows_host, d, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(CGV_ERR_HIP, std::string("cgv_normalize_rows_f32: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(CGV_ERR_HIP, std::string("cgv_normalize_rows: ") + hipGetErrorString(e));
     return CGV_OK;
+}
+
+int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim) {
+    return normalize_rows_host(device_id, rows_host, n, dim, false);
+}
+
+int cgv_normalize_rows_scalar_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim) {
+    return normalize_rows_host(device_id, rows_host, n, dim, true);
 }
 
 int cgv_merge_topk_dev(int device_id, const uint64_t* idx_dev, const float* score_dev, uint32_t g, uint32_t nq,
@@ -2841,6 +2869,13 @@ int cgv_get_stats(cgv_index* h, cgv_stats* out) {
     h->st.device_bytes = device_bytes(h);
     *out = h->st;
     out->coarse_rows = h->last_coarse_rows;
+    return CGV_OK;
+}
+
+int cgv_get_phase_times(cgv_index* h, float* out_us4) {
+    if (!h || !out_us4) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < 4; ++i) out_us4[i] = h->last_phase_us[i];
     return CGV_OK;
 }
 

@@ -129,6 +129,43 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__
     for (uint32_t i = l; i < dim; i += 8) v[i] = v[i] * inv;
 }
 
+// The SCALAR arm of parallel_normalize_vectors (simd_ops.rs:394-403 on an x86_64 host without AVX2, :406-415 on every other
+// host): norm_squared = the elements' squares summed IN ORDER by one accumulator (`iter().map(|&x| x * x).sum()`), nothing
+// happens unless norm_squared > 0.0 (a NaN sum leaves the row alone), then every element is DIVIDED by sqrt(norm_squared) - the
+// AVX2 arm multiplies by the reciprocal, which rounds differently. One lane owns a row's sum (the order is the contract); a
+// wave stages 64 rows x 64 columns through LDS so that global reads stay coalesced (row pitch 65 words: conflict-free walks).
+__global__ __launch_bounds__(256) void normalize_rows_scalar_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
+    __shared__ float tile[4][64][65];
+    __shared__ float nrm[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t row0 = ((uint64_t)blockIdx.x * 4 + w) * 64;
+    if (row0 >= n) return;
+    const uint32_t nr = (uint32_t)((n - row0 < 64) ? (n - row0) : 64);
+    float acc = 0.0f;
+    for (uint32_t c0 = 0; c0 < dim; c0 += 64) {
+        const uint32_t nc = (dim - c0 < 64) ? (dim - c0) : 64;
+        for (uint32_t r = 0; r < nr; ++r)
+            if ((uint32_t)lane < nc) tile[w][r][lane] = rows[(row0 + r) * dim + c0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);
+        if ((uint32_t)lane < nr)
+            for (uint32_t c = 0; c < nc; ++c) {
+                const float x = tile[w][lane][c];
+                acc = acc + x * x;   // (the library is built -ffp-contract=off: a multiply and an add, as in the reference)
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+    nrm[w][lane] = (acc > 0.0f) ? sqrtf(acc) : 0.0f;   // 0: leave the row alone
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t r = 0; r < nr; ++r) {
+        const float d = nrm[w][r];
+        if (d == 0.0f) continue;
+        float* v = rows + (row0 + r) * dim;
+        for (uint32_t i = lane; i < dim; i += 64) v[i] = v[i] / d;
+    }
+}
+
 // Compact the flagged query ids: qlist[0..count) (order irrelevant).
 __global__ void compact_flags_kernel(const uint32_t* __restrict__ flag, uint32_t nq,
                                      uint32_t* __restrict__ qlist, uint32_t* __restrict__ count) {

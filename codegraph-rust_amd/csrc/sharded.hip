@@ -67,6 +67,8 @@ struct Rccl {
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*CommAbort)(ncclComm_t) = nullptr;  // optional: unblocks the other ranks when one fails to post
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;  // optional pair: the warm-up collective of a new communicator set (warm_up_comms)
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GetErrorString; }
 };
@@ -96,6 +98,8 @@ const Rccl* load_rccl(std::string* why = nullptr) {
             g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
             g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(g_rccl.lib, "ncclCommAbort");
             g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+            g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+            g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
             g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
             if (!g_rccl.ok()) g_rccl_err = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
         }
@@ -215,9 +219,11 @@ struct cgv_sharded {
     bool rccl_broken = false;  // a rank failed to post a collective: communicators aborted, copy exchange from now on
     // abort_comms_now(): the failing rank's worker aborts every communicator, once - EXCLUSIVE; every ncclAllGather call is
     // made under a SHARED hold after checking comms_aborted, so no worker can enter a collective on a freed communicator
-    // (ADVICE r4). ncclAllGather only enqueues (blocking communicators return once the kernel is on the stream), so a shared
-    // hold never waits for a peer.
-    std::shared_mutex abort_mu;
+    // (ADVICE r4). A communicator's FIRST collective may block inside the call on lazy connection setup until every rank has
+    // entered; that one is made by warm_up_comms() at creation, from one thread inside a group, so the per-batch calls only
+    // enqueue and a shared hold does not wait for a peer. Should one block all the same, abort_comms_now() stops waiting for the
+    // exclusive hold after ABORT_LOCK_MS and aborts anyway: the abort is what unblocks that call.
+    std::shared_timed_mutex abort_mu;
     std::atomic<bool> comms_aborted{false};
     // a handle over ONE shard normally skips pack / exchange / merge; cgv_sharded_force_exchange() runs them anyway - a
     // one-rank ncclAllGather: the only way to execute the RCCL branch on a single-GPU box (tests)
@@ -231,6 +237,7 @@ namespace {
 constexpr uint64_t C = CGV_SHARD_CHUNK_ROWS;
 
 constexpr int N_SLOTS = 3;
+constexpr int ABORT_LOCK_MS = 500;
 
 void worker_main(Shard* s) {
     (void)hipSetDevice(s->device);
@@ -312,6 +319,33 @@ int busy_if_in_flight(const cgv_sharded* s, const char* what) {
     return CGV_OK;
 }
 
+// The first collective of a communicator set, made here by ONE thread inside a group: lazy connection setup (which can block
+// inside the call until every rank has entered) happens now, not under a worker's hold of abort_mu.
+int warm_up_comms(cgv_sharded* s, const Rccl* r) {
+    if (!r->GroupStart || !r->GroupEnd) return CGV_OK;
+    std::vector<void*> src(s->G, nullptr), dst(s->G, nullptr);
+    int rc = CGV_OK, e = 0;
+    for (uint32_t g = 0; g < s->G && rc == CGV_OK; ++g) {
+        if (hipSetDevice(s->sh[g]->device) != hipSuccess || hipMalloc(&src[g], 64) != hipSuccess ||
+            hipMalloc(&dst[g], (size_t)64 * s->G) != hipSuccess)
+            rc = fail(CGV_ERR_HIP, "warm-up buffers of the RCCL exchange");
+    }
+    if (rc == CGV_OK) {
+        (void)r->GroupStart();
+        for (uint32_t g = 0; g < s->G && e == 0; ++g) e = r->AllGather(src[g], dst[g], 16, NCCL_INT32, s->sh[g]->comm, s->sh[g]->xs);
+        const int ge = r->GroupEnd();
+        if (e == 0) e = ge;
+        if (e != 0) rc = fail(CGV_ERR_HIP, std::string("ncclAllGather (warm-up): ") + r->GetErrorString(e));
+    }
+    for (uint32_t g = 0; g < s->G; ++g) {
+        if (hipSetDevice(s->sh[g]->device) != hipSuccess) continue;
+        if (rc == CGV_OK && hipStreamSynchronize(s->sh[g]->xs) != hipSuccess) rc = fail(CGV_ERR_HIP, "warm-up collective did not complete");
+        if (src[g]) (void)hipFree(src[g]);
+        if (dst[g]) (void)hipFree(dst[g]);
+    }
+    return rc;
+}
+
 int set_exchange_locked(cgv_sharded* s, int kind) {
     if (s->G <= 1 && !s->force_xch) {
         s->exchange = CGV_EXCHANGE_NONE;
@@ -333,6 +367,13 @@ int set_exchange_locked(cgv_sharded* s, int kind) {
         const int e = r->CommInitAll(comms.data(), (int)s->G, devs.data());
         if (e != 0) return fail(CGV_ERR_HIP, std::string("ncclCommInitAll: ") + r->GetErrorString(e));
         for (uint32_t g = 0; g < s->G; ++g) s->sh[g]->comm = comms[g];
+        if (int rc = warm_up_comms(s, r)) {
+            for (uint32_t g = 0; g < s->G; ++g) {
+                (void)r->CommDestroy(s->sh[g]->comm);
+                s->sh[g]->comm = nullptr;
+            }
+            return rc;
+        }
     }
     s->exchange = CGV_EXCHANGE_RCCL;
     return CGV_OK;
@@ -677,9 +718,10 @@ void drain_streams(cgv_sharded* s) {
 // thread after the join: the communicators are gone and the handle continues with the copy exchange. Without
 // ncclCommAbort in the library the communicators are destroyed instead.
 void abort_comms_now(cgv_sharded* s, const Rccl* r) {
-    std::unique_lock<std::shared_mutex> lk(s->abort_mu);  // no ncclAllGather call is in progress while the communicators go
-    if (s->comms_aborted.load()) return;
-    s->comms_aborted.store(true);
+    // no ncclAllGather call should be in progress while the communicators go - but never wait for one forever: a rank stuck INSIDE
+    // the call (holding abort_mu shared) can only be released by the abort itself
+    std::unique_lock<std::shared_timed_mutex> lk(s->abort_mu, std::chrono::milliseconds(ABORT_LOCK_MS));
+    if (s->comms_aborted.exchange(true)) return;
     for (Shard* sh : s->sh) {
         if (!sh->comm || !r) continue;
         if (r->CommAbort) (void)r->CommAbort(sh->comm);
@@ -690,7 +732,7 @@ void abort_comms_now(cgv_sharded* s, const Rccl* r) {
 // ncclAllGather of one shard's records, entered only while the communicators are alive. Returns 0, an RCCL error code, or -1
 // when the communicators were aborted (by a failing rank of this or an earlier batch): the call is skipped.
 int guarded_all_gather(cgv_sharded* s, const Rccl* r, Shard* sh, const void* src, void* dst, size_t count) {
-    std::shared_lock<std::shared_mutex> lk(s->abort_mu);
+    std::shared_lock<std::shared_timed_mutex> lk(s->abort_mu);
     if (s->comms_aborted.load() || !sh->comm) return -1;
     return r->AllGather(src, dst, count, NCCL_INT32, sh->comm, sh->xs);
 }

@@ -75,11 +75,12 @@ class _Batch:
     kernel raises, the stream the whole batch is enqueued on (shard search, packing, all-gather, merge - in line, no hop) and
     the event behind its last kernel. Reused round-robin; `busy` between begin and end."""
     __slots__ = ("key", "rec", "gathered", "redo", "stream", "done", "ev", "ticket", "k", "nq", "out", "res", "busy",
-                 "mode", "timed", "queries")
+                 "mode", "timed", "queries", "qkey", "qslice", "qfull")
 
     def __init__(self):
-        self.key = None
+        self.key = self.qkey = None
         self.stream = self.done = self.ev = None
+        self.qslice = self.qfull = None
         self.busy = False
 
 
@@ -114,8 +115,19 @@ class ShardedKnn:
     # i + 1 runs - the fixed per-batch cost that does not shrink with the shard (PCIe read of the replicated batch, sample, final,
     # exchange, host) hides behind the neighbours' coarse kernels ("unless batches are pipelined") ----
     redo_batches = 0
-    time_exchange = False      # HIP-event pair around all-gather + merge on the stream they run on
-    last_exchange_ms = 0.0
+    time_exchange = False      # HIP events at the phase boundaries of a batch, on the stream it runs on (last_phase_ms)
+    last_exchange_ms = 0.0     # all-gather + merge of the last ended batch
+    last_phase_ms = None       # {"queries", "search_pack", "all_gather", "merge"} of the last ended batch (time_exchange)
+    # How a HOST query batch reaches the ranks ("queries replicated ... broadcast or loaded by every rank"):
+    #   "replicated"  every rank reads the whole batch over its own PCIe link (in place, by the shard search's conversion kernel,
+    #                 or by the copy engine while another batch is in flight): 3 MB per rank at C2 whatever the rank count - the
+    #                 largest per-batch cost that does not shrink with the shard;
+    #   "sharded"     rank r copies only rows [r * ceil(nq / G), ...) to its device (nq * D * 4 / G bytes over PCIe) and ONE
+    #                 all-gather of the f32 slices over xGMI gives every rank the whole batch in HBM; the shard search then
+    #                 converts from device memory. The f32 values every rank converts are the same as in the replicated form,
+    #                 so the results are identical bit for bit. (The slices travel as f32, not as converted rows: 3 MB instead
+    #                 of 1.5 MB is latency-bound either way at these sizes, and the conversion stays one code path.)
+    query_exchange = "replicated"
 
     def _collective(self):
         """None: no collective (one rank, not forced); else the backend of the group ("nccl" = RCCL, "gloo")."""
@@ -146,9 +158,50 @@ class ShardedKnn:
                 b.redo = b.redo.pin_memory()   # written in place by the merge kernel, read by the host after the batch's event
                 b.stream = torch.cuda.Stream(device=dev)
                 b.done = torch.cuda.Event()
-                b.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                b.ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(5))   # start | queries | search + pack | all-gather | merge
             b.key = key
         return b
+
+    def _shard_bounds(self, nq):
+        per = (nq + self.world - 1) // self.world
+        lo = min(nq, self.rank * per)
+        return per, lo, min(nq, lo + per)
+
+    def _gather_queries(self, b, queries, device):
+        """query_exchange == "sharded": this rank's slice of the host batch -> device, all-gather of the slices -> the whole
+        batch in device memory (CUDA ranks), or through gloo (CPU stand-ins; device shards of several ranks on one GPU)."""
+        nq, d = queries.shape
+        per, lo, hi = self._shard_bounds(nq)
+        coll = self._collective()
+        if b.rec.is_cuda:
+            key = (per, d, self.world)
+            if b.qkey != key:
+                b.qslice = torch.zeros((per, d), dtype=torch.float32, device=b.rec.device)   # (a short last slice: zero tail, never read)
+                b.qfull = torch.empty((self.world * per, d), dtype=torch.float32, device=b.rec.device)
+                b.qkey = key
+            if coll == "gloo" or coll is None:
+                torch.cuda.current_stream(b.rec.device).synchronize()
+                mine = torch.zeros((per, d), dtype=torch.float32)
+                mine[: hi - lo] = queries[lo:hi]
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                if self.world > 1 and coll is not None:
+                    dist.all_gather(parts, mine, group=self.group)
+                else:
+                    parts[0].copy_(mine)
+                b.qfull.copy_(torch.cat(parts))
+            else:
+                if hi > lo:
+                    b.qslice[: hi - lo].copy_(queries[lo:hi], non_blocking=True)    # pinned host -> HBM on the batch's stream
+                dist.all_gather_into_tensor(b.qfull, b.qslice, group=self.group)
+            return b.qfull[:nq]
+        mine = torch.zeros((per, d), dtype=torch.float32)
+        mine[: hi - lo] = queries[lo:hi]
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(parts, mine, group=self.group)
+        else:
+            parts[0].copy_(mine)
+        return torch.cat(parts)[:nq].contiguous()
 
     def _gather_merge(self, b):
         """all-gather of the batch's records + merge (redo word) - enqueued on the current stream (RCCL), or, when the records
@@ -173,6 +226,8 @@ class ShardedKnn:
             else:
                 dist.all_gather_into_tensor(gathered, rec, group=self.group)
                 g = gathered
+            if b.timed and b.mode == "stream":
+                b.ev[3].record()
             return merge_packed(g, k, out=out, redo=redo)
         parts = [gathered[r] for r in range(self.world)]
         if self.world > 1:
@@ -219,18 +274,25 @@ class ShardedKnn:
             b.mode = "host" if coll == "gloo" else "stream"
             if queries.is_cuda:              # the producer of a CUDA batch comes first
                 b.stream.wait_stream(torch.cuda.current_stream(b.rec.device))
+            sharded_q = self.query_exchange == "sharded" and not queries.is_cuda and coll is not None
             with torch.cuda.stream(b.stream):
-                b.ticket = self.local.search_packed_begin(queries, k, b.rec)
+                if b.timed:
+                    b.ev[0].record()
+                q_in = self._gather_queries(b, queries, device) if sharded_q else queries
+                if b.timed:
+                    b.ev[1].record()
+                b.ticket = self.local.search_packed_begin(q_in, k, b.rec)
                 if b.mode == "stream":
                     if b.timed:
-                        b.ev[0].record()
+                        b.ev[2].record()
                     b.res = self._gather_merge(b)
                     if b.timed:
-                        b.ev[1].record()
+                        b.ev[4].record()
                 b.done.record()
         else:
             b.mode = "cpu"
-            b.ticket = self.local.search_packed_begin(queries, k, b.rec)
+            q_in = self._gather_queries(b, queries, device) if (self.query_exchange == "sharded" and self.world > 1) else queries
+            b.ticket = self.local.search_packed_begin(q_in, k, b.rec)
         b.busy = True
         return b
 
@@ -249,7 +311,9 @@ class ShardedKnn:
                         b.done.record()
                     self._wait(b.done)
                 elif b.timed:
-                    self.last_exchange_ms = b.ev[0].elapsed_time(b.ev[1])
+                    t = [b.ev[i].elapsed_time(b.ev[i + 1]) for i in range(4)]
+                    self.last_phase_ms = {"queries": t[0], "search_pack": t[1], "all_gather": t[2], "merge": t[3]}
+                    self.last_exchange_ms = t[2] + t[3]
             else:
                 b.res = self._gather_merge(b)
             # A search that fails on ONE rank only (an OOM in its exact rescan ...) must not take that rank out of the collective

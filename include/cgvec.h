@@ -261,6 +261,17 @@ int cgv_search_baseline_f32(cgv_index* h, const float* query_host, uint32_t limi
 /* ParallelVectorOps::parallel_normalize_vectors / SIMDVectorOps::normalize_avx2
  * (simd_ops.rs:386-419, 189-222), in place on a flat HOST matrix [n][dim], computed on device. */
 int cgv_normalize_rows_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim);
+/* The same entry on a host that never takes the AVX2 kernel - the scalar arm of parallel_normalize_vectors
+ * (simd_ops.rs:394-403 without AVX2 + FMA, :406-415 on every non-x86_64 host; the counterpart of CGV_METRIC_COSINE_SCALAR):
+ * the squares summed in order by one accumulator, rows whose sum is not > 0 left alone, every element DIVIDED by the norm. */
+int cgv_normalize_rows_scalar_f32(int device_id, float* rows_host, uint64_t n, uint32_t dim);
+
+/* SURVEY.md section 8(d) synthetic inputs (measurement plumbing, no reference counterpart): rows [row0, row0 + nrows) of the
+ * counter-based stream `seed` - Philox4x32-10 keyed (seed, row, col / 4) -> Box-Muller N(0, 1) f32 -> (normalise != 0)
+ * L2-normalised in f32 - written row-major [nrows][dim] to DEVICE memory on `stream`. Any chunking and any rank produce the
+ * same values, and the CPU checker's cgo_synth_rows restates the contract bit for bit (csrc/synth.hip states it). */
+int cgv_synth_rows_f32_dev(int device_id, uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, int normalise,
+                           float* out_dev, void* stream);
 
 /* Merge G partial top-k lists per query on device `device_id` (the step after the
  * all-gather of per-shard partial results): inputs are
@@ -356,6 +367,11 @@ int cgv_get_stats(cgv_index* h, cgv_stats* out);
  * the dominant coarse launch (cgv_stats.last_coarse_ms); 2 = also around the whole pipeline (last_total_ms). Each
  * record is a packet on the stream: level 2 measured ~10 us per batch on short searches. */
 int cgv_set_profiling(cgv_index* h, int enabled);
+/* Level 3 adds three more records per search, at the phase boundaries of the MFMA pipeline; out_us4 = device microseconds of
+ * the last finished search's {query conversion, first threshold (sample launch + tau, or boot + select), emitting coarse
+ * launches + selections, final kernel + publish} - zeros for an exact-scan search, a search that fell back, or level < 3.
+ * What the multi-GPU bench line prints per rank, so that a first run on N GPUs shows where a rank's batch goes. */
+int cgv_get_phase_times(cgv_index* h, float* out_us4);
 
 /* How a search's end waits for the device: it polls the batch's stream / event for up to spin_us microseconds (default 3000,
  * capped at 1 s) and then blocks in the driver. A batch takes 0.3-1.5 ms and the wake-up of a blocked wait costs tens of

@@ -174,6 +174,17 @@ void cgo_normalize_avx2(float* v, size_t len) {
     for (size_t i = chunks * 8; i < len; ++i) v[i] *= inv;
 }
 
+// simd_ops.rs:394-403 / 406-415: the scalar arm of parallel_normalize_vectors (no AVX2 + FMA, or not x86_64):
+// `iter().map(|&x| x * x).sum()` = one accumulator in element order, `if norm_squared > 0.0`, `*x /= norm`.
+void cgo_normalize_scalar(float* v, size_t len) {
+    float nsq = 0.0f;
+    for (size_t i = 0; i < len; ++i) nsq = nsq + v[i] * v[i];
+    if (nsq > 0.0f) {
+        const float norm = sqrtf(nsq);
+        for (size_t i = 0; i < len; ++i) v[i] = v[i] / norm;
+    }
+}
+
 // simd_ops.rs:85-99 batch_cosine_similarity_avx2: one query vs many rows, serial.
 void cgo_batch_cosine_avx2(const float* q, const float* const* rows, size_t n, size_t len,
                            float* out) {
@@ -875,6 +886,115 @@ void cgo_pq_encode(const float* v, uint64_t n, uint64_t dim, uint64_t m, uint32_
             }
             codes[r * m + sub] = (uint8_t)best;
         }
+}
+
+
+// ---------------------------------------------------------------------------
+// SURVEY.md section 8(d) synthetic inputs: counter-based generator keyed (seed, row, col) -> N(0, 1) f32 -> L2-normalised in
+// f32. Not reference code (the reference has no generator): the CPU side of the bench's data contract, restated here
+// independently of codegraph-rust_amd/csrc/synth.hip from the contract in that file's header, so that the CPU baseline and
+// the parity checks can produce any row of any corpus without copying it from the device. Philox4x32-10 (Salmon et al.,
+// SC'11; pinned by the Random123 known-answer vectors in tests/test_synth.py), Box-Muller with polynomial ln / sin / cos
+// (libm's differ between hosts and devices in the last bit), 64 strided partial sums of squares met by a xor butterfly.
+static void cgo_philox4x32_10_impl(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void cgo_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4) { cgo_philox4x32_10_impl(ctr4, key2, out4); }
+
+static float cgo_synth_ln(float u) {
+    uint32_t b;
+    memcpy(&b, &u, 4);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007FFFFFu) | 0x3F800000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float t2 = t * t;
+    float p = 0.0909090936f;
+    p = p * t2 + 0.111111112f;
+    p = p * t2 + 0.142857149f;
+    p = p * t2 + 0.2f;
+    p = p * t2 + 0.333333343f;
+    p = p * t2 + 1.0f;
+    return (float)e * 0.693147182f + (2.0f * t) * p;
+}
+static void cgo_synth_pair(uint32_t xa, uint32_t xb, float* z0, float* z1) {
+    const float u = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float v = (float)(xb >> 8) * 5.9604644775390625e-08f;
+    const float rad = sqrtf(-2.0f * cgo_synth_ln(u));
+    const float a4 = v * 4.0f;
+    const int q = (int)a4;
+    const float a = (a4 - (float)q) * 1.57079637f;
+    const float a2 = a * a;
+    float ps = -2.50521084e-08f;
+    ps = ps * a2 + 2.75573188e-06f;
+    ps = ps * a2 - 1.98412701e-04f;
+    ps = ps * a2 + 8.33333377e-03f;
+    ps = ps * a2 - 0.166666672f;
+    ps = ps * a2 + 1.0f;
+    const float sn = a * ps;
+    float pc = 2.08767570e-09f;
+    pc = pc * a2 - 2.75573188e-07f;
+    pc = pc * a2 + 2.48015876e-05f;
+    pc = pc * a2 - 1.38888892e-03f;
+    pc = pc * a2 + 4.16666679e-02f;
+    pc = pc * a2 - 0.5f;
+    pc = pc * a2 + 1.0f;
+    float c, s;
+    switch (q & 3) {
+        case 0: c = pc; s = sn; break;
+        case 1: c = -sn; s = pc; break;
+        case 2: c = -pc; s = -sn; break;
+        default: c = sn; s = -pc; break;
+    }
+    *z0 = rad * c;
+    *z1 = rad * s;
+}
+// rows [row0, row0 + nrows) of the stream `seed`, dim columns, into out[nrows][dim]; normalise = 0: the N(0, 1) values
+void cgo_synth_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, int normalise, float* out) {
+    const uint32_t nblk = (dim + 3) / 4;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nrows; ++i) {
+        const uint64_t r = row0 + (uint64_t)i;
+        float* o = out + (size_t)i * dim;
+        float part[64];
+        for (int l = 0; l < 64; ++l) part[l] = 0.0f;
+        for (uint32_t b = 0; b < nblk; ++b) {
+            const uint32_t ctr[4] = {b, (uint32_t)r, (uint32_t)(r >> 32), 0u};
+            const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+            uint32_t x[4];
+            cgo_philox4x32_10_impl(ctr, key, x);
+            float z[4];
+            cgo_synth_pair(x[0], x[1], &z[0], &z[1]);
+            cgo_synth_pair(x[2], x[3], &z[2], &z[3]);
+            for (int j = 0; j < 4; ++j)
+                if (4 * b + j < dim) {
+                    o[4 * b + j] = z[j];
+                    part[b & 63] = part[b & 63] + z[j] * z[j];   // lane b % 64 visits its blocks in ascending order
+                }
+        }
+        if (!normalise) continue;
+        for (int off = 32; off >= 1; off >>= 1) {
+            float nxt[64];
+            for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
+            for (int l = 0; l < 64; ++l) part[l] = nxt[l];
+        }
+        const float nrm = sqrtf(part[0]);
+        for (uint32_t c = 0; c < dim; ++c) o[c] = o[c] / nrm;
+    }
 }
 
 }  // extern "C"

@@ -43,6 +43,12 @@ def lib():
             f.argtypes = [fp, fp, C.c_size_t]
         L.cgo_normalize_avx2.restype = None
         L.cgo_normalize_avx2.argtypes = [fp, C.c_size_t]
+        L.cgo_synth_rows.restype = None
+        L.cgo_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, fp]
+        L.cgo_philox4x32_10.restype = None
+        L.cgo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.cgo_normalize_scalar.restype = None
+        L.cgo_normalize_scalar.argtypes = [fp, C.c_size_t]
         L.cgo_parallel_top_k_flat.restype = C.c_int
         L.cgo_parallel_top_k_flat.argtypes = [fp, fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                               C.c_int, u64p, fp]
@@ -119,11 +125,13 @@ def normalize_avx2(v):
     return v
 
 
-def normalize_rows(m):
-    """simd_ops.rs:386-419 parallel_normalize_vectors (AVX2 branch), row by row."""
+def normalize_rows(m, arm="avx2"):
+    """simd_ops.rs:386-419 parallel_normalize_vectors, row by row: the AVX2 branch (:393, normalize_avx2) or the
+    scalar branch a host without AVX2 + FMA / a non-x86_64 host takes (:394-403, :406-415)."""
     m = np.array(m, dtype=np.float32, copy=True)
+    fn = lib().cgo_normalize_avx2 if arm == "avx2" else lib().cgo_normalize_scalar
     for r in m:
-        lib().cgo_normalize_avx2(r.ctypes.data_as(C.POINTER(C.c_float)), r.size)
+        fn(r.ctypes.data_as(C.POINTER(C.c_float)), r.size)
     return m
 
 
@@ -201,6 +209,23 @@ def numa_nodes():
 
 def prefetch_k(limit):
     return int(lib().cgo_prefetch_k(limit))  # search.rs:113
+
+
+def synth_rows(seed, row0, nrows, dim, normalise=True):
+    """rows [row0, row0 + nrows) of the counter-based stream `seed` (Philox4x32-10 keyed
+    (seed, row, col) -> N(0, 1) f32 -> L2-normalised in f32); the CPU side of the contract in csrc/synth.hip."""
+    out = np.empty((nrows, dim), dtype=np.float32)
+    if nrows and dim:
+        lib().cgo_synth_rows(seed, row0, nrows, dim, 1 if normalise else 0, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(x) for x in ctr])
+    k = (C.c_uint32 * 2)(*[int(x) for x in key])
+    o = (C.c_uint32 * 4)()
+    lib().cgo_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
 
 
 def normalize_scores(s):

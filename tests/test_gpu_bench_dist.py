@@ -53,6 +53,28 @@ def test_bench_rank_program_runs_with_several_ranks_on_one_gpu(world):
     ph = d["pipelined_host"]
     assert ph["same_results_as_serial_step"] is True and ph["batches"] == 9 and ph["batches_in_flight"] == 3
     assert d["pipeline"]["fallback_queries"] == 0
+    _check_diagnostics(mg, world, dry_run=True)
+
+
+def _check_diagnostics(mg, world, dry_run):
+    """Round 6: what makes the first real multi-GPU run readable in one shot - both query-exchange forms timed in the line, the
+    per-rank phase breakdown from HIP events, the all-gather micro-latency, the ranks' device identities."""
+    qx = mg["query_exchange"]
+    assert qx["replicated_ms"] > 0 and qx["sharded_ms"] > 0 and qx["timed_steps_use"] in ("replicated", "sharded")
+    assert qx["timed_steps_use"] == ("sharded" if qx["sharded_ms"] < qx["replicated_ms"] else "replicated")
+    ph = mg["per_rank_phases_us"]
+    for name in ("prep", "sample_tau", "emitting", "final_publish", "pack_and_gaps", "query_exchange", "all_gather", "merge",
+                 "search_device_total"):
+        assert len(ph[name]["per_rank"]) == world and ph[name]["max"] >= ph[name]["min"] >= 0.0, name
+    for name in ("prep", "emitting", "final_publish", "search_device_total"):
+        assert ph[name]["min"] > 0.0, name                      # every rank ran the MFMA pipeline with the phase events on
+    if not dry_run:                                             # (the dry run's exchange goes through the host: no stream events)
+        assert ph["all_gather"]["min"] > 0.0 and ph["merge"]["min"] > 0.0
+    ag = mg["all_gather_latency_us"]
+    assert ag["packed_records"] > 0 and ag["query_slices"] > 0 and ag["packed_records_bytes_per_rank"] > 0
+    ids = mg["per_rank_device_identity"]
+    assert [i["rank"] for i in ids] == list(range(world)) and all(i["visible_devices"] >= 1 for i in ids)
+    assert mg["ranks_on_distinct_devices"] is (world == 1 or not dry_run)     # the dry run shares one GPU - and the line says so
 
 
 def test_bench_one_rank_nccl_pipelined_host_step():
@@ -63,6 +85,22 @@ def test_bench_one_rank_nccl_pipelined_host_step():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = lines[-1]
     assert "error" not in d and d["multi_gpu"]["rccl_ranks_seen"] == 1 and d["multi_gpu"]["backend"].startswith("nccl")
+    assert d["recall_at_10"] == d["ordered_match_rate"] == d["score_bit_exact_rate"] == 1.0
+    assert d["pipelined_host"]["same_results_as_serial_step"] is True
+    ex = d["exact_check"]
+    assert ex["recall_at_10"] == ex["ordered_match_rate"] == ex["score_bit_exact_rate"] == 1.0
+    _check_diagnostics(d["multi_gpu"], 1, dry_run=False)
+
+
+def test_bench_one_rank_nccl_sharded_query_exchange():
+    """--query-exchange sharded over RCCL with one rank: the slice copy, the all-gather of the f32 slices and the shard search
+    reading the gathered batch from HBM are what the timed steps run; parity fields as in the replicated form."""
+    p, lines = _run(1, ["--force-dist", "--workload", "c2shard8", "--steps", "20", "--warmup", "3", "--settle-ms", "50",
+                        "--pipelined-steps", "30", "--check-queries", "16", "--query-exchange", "sharded"])
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = lines[-1]
+    assert "error" not in d and d["multi_gpu"]["query_exchange"]["timed_steps_use"] == "sharded"
+    assert d["multi_gpu"]["per_rank_phases_us"]["query_exchange"]["min"] > 0.0
     assert d["recall_at_10"] == d["ordered_match_rate"] == d["score_bit_exact_rate"] == 1.0
     assert d["pipelined_host"]["same_results_as_serial_step"] is True
     ex = d["exact_check"]
@@ -83,3 +121,6 @@ def test_bench_hung_rank_ends_with_an_error_line():
     assert p.returncode != 0
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert all("error" in l for l in lines)
+    for l in lines:          # the line of a hung run names the stage every rank reached (files: a hung rank cannot be asked)
+        if l.get("per_rank_last_stage"):
+            assert [r["rank"] for r in l["per_rank_last_stage"]] == [0, 1]

@@ -523,6 +523,29 @@ def test_normalize_rows_on_device(oracle):
         assert np.array_equal(m.cgvec.normalize_rows(rows), oracle.normalize_rows(rows)), d
 
 
+def test_normalize_rows_scalar_arm_on_device(oracle):
+    """simd_ops.rs:394-403 / 406-415: the arm of parallel_normalize_vectors a host without AVX2 + FMA takes - squares
+    summed in order by one accumulator, `> 0.0` (a NaN sum leaves the row alone), a DIVIDE per element. Bit-exact against
+    the oracle for D = 8 .. 768, ragged row counts (the kernel stages 64 x 64 tiles), zero rows and a NaN row; the two arms
+    differ on ordinary data (reciprocal-multiply vs divide), so the test would notice one standing in for the other."""
+    m = pkg()
+    rng = np.random.default_rng(5)
+    differ = 0
+    for d in (1, 7, 8, 63, 64, 65, 100, 384, 768):
+        for n in (1, 50, 64, 257):
+            rows = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+            if n > 4:
+                rows[4] = 0.0
+                rows[2, d // 2] = np.nan
+            got = m.cgvec.normalize_rows(rows, arm="scalar")
+            want = oracle.normalize_rows(rows, arm="scalar")
+            assert np.array_equal(got, want, equal_nan=True), (d, n)
+            if n > 4:
+                assert np.array_equal(got[2], rows[2], equal_nan=True)   # NaN sum: `nsq > 0.0` is false, row untouched
+            differ += int(not np.array_equal(got, oracle.normalize_rows(rows, arm="avx2"), equal_nan=True))
+    assert differ > 0
+
+
 def test_batches_in_flight_and_concurrent_callers(oracle):
     """cgv_search_begin/_end: more batches begun than the pool holds contexts (begin blocks until a
     context frees up from another thread's end), different nq / k per batch, results equal to the

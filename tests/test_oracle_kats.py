@@ -353,3 +353,36 @@ def test_cpu_baseline_leg_reports_its_split(oracle):
         assert oracle.numa_nodes() >= 1 and oracle.max_threads() >= 1
     finally:
         rs.close()
+
+
+def test_scalar_arm_of_parallel_normalize_vectors(oracle):
+    """simd_ops.rs:394-403 / 406-415 (the branch of parallel_normalize_vectors taken without AVX2 + FMA and on every
+    non-x86_64 host): the reference holds no test for it, so the oracle's cgo_normalize_scalar is pinned by a pure-Python
+    restatement with one f32 rounding per operation (sequential sum of squares, `> 0.0`, sqrt, a divide per element) and by
+    the properties the source states: zero rows and rows whose sum is NaN stay as they are; unit length within a few ulps."""
+    f32 = np.float32
+
+    def scalar_normalize(v):
+        nsq = f32(0.0)
+        for x in v:
+            nsq = f32(nsq + f32(x * x))
+        if not nsq > 0.0:
+            return v.copy()
+        norm = f32(np.sqrt(nsq))
+        return np.array([f32(x / norm) for x in v], dtype=f32)
+
+    rng = np.random.default_rng(17)
+    for d in (1, 3, 8, 9, 31, 64, 100):
+        rows = (rng.standard_normal((6, d)) * 5).astype(f32)
+        rows[1] = 0.0
+        got = oracle.normalize_rows(rows, arm="scalar")
+        want = np.stack([scalar_normalize(r) for r in rows])
+        assert np.array_equal(got, want), d
+        assert np.array_equal(got[1], rows[1])
+        assert abs(float(np.linalg.norm(got[0].astype(np.float64))) - 1.0) < 1e-6
+    v = np.array([3.0, 4.0], f32)
+    assert np.array_equal(oracle.normalize_rows(v[None, :], arm="scalar")[0], np.array([0.6, 0.8], f32))   # 3/5, 4/5 rounded once
+    nan_row = np.array([[1.0, np.nan, 2.0]], f32)
+    assert np.array_equal(oracle.normalize_rows(nan_row, arm="scalar"), nan_row, equal_nan=True)
+    big = np.array([[1e30, 1e30]], f32)   # the sum overflows to +inf: inf > 0.0, every element / inf = 0 (as the reference would)
+    assert np.array_equal(oracle.normalize_rows(big, arm="scalar"), np.zeros((1, 2), f32))

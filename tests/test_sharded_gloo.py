@@ -192,6 +192,24 @@ def _packed_worker(rank, world, port, n, d, nq, k, out):
         assert ("exact rescan failed" in str(e)) if rank == 1 else ("still provisional" in str(e)), (rank, str(e))
     i9, s9 = clean.step_packed(queries, k)
     assert torch.equal(i9, i1) and torch.equal(s9, s1)
+    # ---- query_exchange = "sharded" (round 6): a rank moves only ITS slice of the host batch; one all-gather of the f32 slices
+    # gives every rank the whole batch. Each rank's copy of the batch is POISONED outside its own slice, so the answers can
+    # only be right if they were computed from the gathered rows; a batch whose size does not divide by the world (short last
+    # slice) and batches in flight go the same way. Results = the replicated form's, bit for bit.
+    sq = m.ShardedKnn(_PackedOracleShard(rows[lo:hi], lo))
+    sq.query_exchange = "sharded"
+    for nq_s in (nq, nq - 1):
+        per = (nq_s + world - 1) // world
+        mine = queries[:nq_s].clone()
+        poison = torch.ones(nq_s, dtype=torch.bool)
+        poison[rank * per: (rank + 1) * per] = False
+        mine[poison] = float("nan")
+        i_s, s_s = sq.step_packed(mine, k)
+        assert torch.equal(i_s, i1[:nq_s]) and torch.equal(s_s, s1[:nq_s]), (rank, nq_s)
+    h1 = sq.step_packed_begin(queries, k)
+    h2 = sq.step_packed_begin(q_rev, k)
+    g1, g2 = sq.step_packed_end(h1), sq.step_packed_end(h2)
+    assert torch.equal(g1[0], i1) and torch.equal(g2[0], torch.flip(i1, dims=[0])) and torch.equal(g2[1], torch.flip(s1, dims=[0]))
     # and the packed step agrees with the unpacked exchange of the same shards
     i0, s0 = m.ShardedKnn(_OracleShard(rows[lo:hi], lo), merge=_oracle_merge).search(queries, k)
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
