@@ -210,6 +210,26 @@ def respawn_under_launcher(n):
     return subprocess.call(cmd, env=env)
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """Multi-rank runs: RCCL prints a version banner on the process's stdout (file descriptor 1) when the first communicator
+    forms - in front of the ONE JSON line the caller parses. Everything written to descriptor 1 from here on goes to stderr; the
+    line itself is written to a saved duplicate of the original stdout (emit)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 class Watchdog:
     """No-progress limit for a multi-rank run: every phase of the rank program calls kick(stage); when nothing has been kicked
     for `limit` seconds (a collective that never completes: a rank died, a communicator never formed) the process prints ONE
@@ -262,7 +282,7 @@ class Watchdog:
             if self.on and time.monotonic() - self.last > limit:
                 msg = f"no progress for {limit:.0f} s in stage '{self.stage}' (rank {self.rank} of {self.world})"
                 if self.rank == 0:
-                    print(json.dumps(error_line(self.world, msg, self.stage, self.stages_of_all_ranks())), flush=True)
+                    emit(error_line(self.world, msg, self.stage, self.stages_of_all_ranks()))
                 else:
                     print(f"bench.py: {msg}", file=sys.stderr, flush=True)
                 os._exit(3)
@@ -498,8 +518,7 @@ def main():
         import traceback
         traceback.print_exc()
         if rank == 0:
-            print(json.dumps(error_line(world, f"{type(e).__name__}: {e}", wd.stage, wd.stages_of_all_ranks() if wd.on else None)),
-                  flush=True)
+            emit(error_line(world, f"{type(e).__name__}: {e}", wd.stage, wd.stages_of_all_ranks() if wd.on else None))
         wd.stop()
         os._exit(1)   # (not sys.exit: a broken process group may block interpreter shutdown in its destructors)
 
@@ -512,6 +531,7 @@ def run(args, wd, world, rank, local_rank):
     if world > 1 or args.force_dist:
         import datetime
         import torch.distributed as dist
+        protect_stdout()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         gloo = args.dist_backend == "gloo"
         if gloo:   # dry run: more ranks than GPUs - rank r on device r % device_count, records + control over gloo
@@ -688,11 +708,15 @@ def run(args, wd, world, rank, local_rank):
         print("step_ms:", " ".join(f"{x:.3f}" for x in step_ms), file=sys.stderr, flush=True)
     wd.kick("timed steps done")
     ix.set_profiling(3)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step) and the phase events
+    if dist is not None:
+        searcher.time_phases = True
     step(0)
     step(1)
     st = ix.stats()
     phases = ix.phase_times_us()
     ix.set_profiling(1)
+    if dist is not None:
+        searcher.time_phases = False
     multi = None
     if dist is not None:
         diag = rank_diagnostics(dist, searcher, phases, st, dev, dev_index, ctl, world, gloo, batch, dim, k, wd)
@@ -1257,7 +1281,7 @@ def run(args, wd, world, rank, local_rank):
     wd.stop()
     gc.enable()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     ix.close()
     if dist is not None:
         dist.barrier()

@@ -115,7 +115,9 @@ class ShardedKnn:
     # i + 1 runs - the fixed per-batch cost that does not shrink with the shard (PCIe read of the replicated batch, sample, final,
     # exchange, host) hides behind the neighbours' coarse kernels ("unless batches are pipelined") ----
     redo_batches = 0
-    time_exchange = False      # HIP events at the phase boundaries of a batch, on the stream it runs on (last_phase_ms)
+    time_exchange = False      # HIP-event pair around all-gather + merge on the stream they run on (last_exchange_ms)
+    time_phases = False        # ... and at every phase boundary of the batch (last_phase_ms): three more records per batch,
+                               # a few microseconds each - for diagnostic steps, not for timed ones
     last_exchange_ms = 0.0     # all-gather + merge of the last ended batch
     last_phase_ms = None       # {"queries", "search_pack", "all_gather", "merge"} of the last ended batch (time_exchange)
     # How a HOST query batch reaches the ranks ("queries replicated ... broadcast or loaded by every rank"):
@@ -226,7 +228,7 @@ class ShardedKnn:
             else:
                 dist.all_gather_into_tensor(gathered, rec, group=self.group)
                 g = gathered
-            if b.timed and b.mode == "stream":
+            if b.timed == 2 and b.mode == "stream":
                 b.ev[3].record()
             return merge_packed(g, k, out=out, redo=redo)
         parts = [gathered[r] for r in range(self.world)]
@@ -268,7 +270,7 @@ class ShardedKnn:
         b = self._take_slot(nq, int(k), like)
         b.k, b.nq, b.out, b.res, b.queries = int(k), nq, out, None, queries
         b.redo.zero_()                       # (the slot is idle: no kernel writes it)
-        b.timed = b.rec.is_cuda and self.time_exchange
+        b.timed = 2 if (b.rec.is_cuda and self.time_phases) else (1 if (b.rec.is_cuda and self.time_exchange) else 0)
         if b.rec.is_cuda:
             coll = self._collective()
             b.mode = "host" if coll == "gloo" else "stream"
@@ -276,10 +278,10 @@ class ShardedKnn:
                 b.stream.wait_stream(torch.cuda.current_stream(b.rec.device))
             sharded_q = self.query_exchange == "sharded" and not queries.is_cuda and coll is not None
             with torch.cuda.stream(b.stream):
-                if b.timed:
+                if b.timed == 2:
                     b.ev[0].record()
                 q_in = self._gather_queries(b, queries, device) if sharded_q else queries
-                if b.timed:
+                if b.timed == 2:
                     b.ev[1].record()
                 b.ticket = self.local.search_packed_begin(q_in, k, b.rec)
                 if b.mode == "stream":
@@ -310,10 +312,12 @@ class ShardedKnn:
                         b.res = self._gather_merge(b)
                         b.done.record()
                     self._wait(b.done)
-                elif b.timed:
+                elif b.timed == 2:
                     t = [b.ev[i].elapsed_time(b.ev[i + 1]) for i in range(4)]
                     self.last_phase_ms = {"queries": t[0], "search_pack": t[1], "all_gather": t[2], "merge": t[3]}
                     self.last_exchange_ms = t[2] + t[3]
+                elif b.timed:
+                    self.last_exchange_ms = b.ev[2].elapsed_time(b.ev[4])
             else:
                 b.res = self._gather_merge(b)
             # A search that fails on ONE rank only (an OOM in its exact rescan ...) must not take that rank out of the collective
