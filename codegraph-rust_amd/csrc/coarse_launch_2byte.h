@@ -10,8 +10,8 @@
 #include "../../include/cgvec.h"
 #include "coarse_launch.h"
 #ifdef CGV_ABLATE_BUILD
-#include "kernels_coarse_w4.h"   // one wave per SIMD, 128 x 128 per wave (A/B against the 8-wave kernel; epi bit 7)
-#include "kernels_coarse_wg2.h"  // two workgroups of 4 waves per CU, 128 x 256 tiles (A/B; epi bit 10)
+#include "experiments/kernels_coarse_w4.h"   // one wave per SIMD, 128 x 128 per wave (A/B against the 8-wave kernel; epi bit 7)
+#include "experiments/kernels_coarse_wg2.h"  // two workgroups of 4 waves per CU, 128 x 256 tiles (A/B; epi bit 10)
 #endif
 
 extern "C" int cgv_set_error_(int code, const char* msg);
@@ -95,7 +95,8 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     }
             switch (abl) {
                 CGV_ABLK2(1) CGV_ABLK2(4) CGV_ABLK2(5) CGV_ABLK2(65) CGV_ABLK2(197) CGV_ABLK2(256) CGV_ABLK2(512) CGV_ABLK2(768)
-                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: no such mask for the ring-unrolled kernel (1, 4, 5, 65, 197, 256, 512, 768)");
+                CGV_ABLK2(1024) CGV_ABLK2(1025) CGV_ABLK2(2048) CGV_ABLK2(4096)
+                default: return cgv_set_error_(CGV_ERR_INVALID_ARG, "CGV_ABLATE: no such mask for the ring-unrolled kernel (1, 4, 5, 65, 197, 256, 512, 768, 1024, 1025, 2048, 4096)");
             }
 #undef CGV_ABLK2
             return coarse_hip_status("coarse_kernel (ablation, ring-unrolled)");

@@ -20,7 +20,7 @@
 //     for the tile that STARTS there, so the stage loop has no branch besides its back edge.
 // A 64-byte stage is two K=16 k-steps (A phase, B phase); needs kc >= 4.
 #pragma once
-#include "kernels_coarse.h"
+#include "../kernels_coarse.h"
 
 namespace cgv {
 
@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+    if ((true) && a.append_splits != 0u) {   // uniform: the first launch behind an emitting sample (kernels_coarse.h)
+        __syncthreads();
+        append_sample_candidates<BN, NT>(a, g, qt, split, cntq, tid);
+    }
 
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll

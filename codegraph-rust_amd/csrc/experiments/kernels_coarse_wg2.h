@@ -17,7 +17,7 @@
 // chunks (every half-tile then starts in ring slot 0 and the stage loop, unrolled by the ring size, has constant LDS addresses):
 // D = 384, 768, 1536 for the 2-byte types.
 #pragma once
-#include "kernels_coarse.h"
+#include "../kernels_coarse.h"
 
 namespace cgv {
 
@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+    if ((true) && a.append_splits != 0u) {   // uniform: the first launch behind an emitting sample (kernels_coarse.h)
+        __syncthreads();
+        append_sample_candidates<BN, NT>(a, g, qt, split, cntq, tid);
+    }
 
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll

@@ -114,6 +114,14 @@ struct CoarseArgs {
     uint32_t* floor_ord;    // [nq] f2ord of the largest coarse score any cell left OUT of its top-2 (atomicMax; zero at launch)
     float* cellb;           // [4 * nsplit][64] the same per CELL ((split * 2 + wm) * 2 + lane half; -inf: nothing left out), or NULL:
                             // what top2_repair_kernel (kernels_repair.h) finds the cells to re-scan with when a floor is too high
+    // The sample launch as an EMITTING launch (round 6; SAMPLE mode of tile_epilogue): its tiles are not scored again
+    uint32_t sample_emit;   // SAMPLE mode: != 0 = every lane also keeps the two best rows of its 64 rows per query column (one cell =
+                            // (tile, M-half of the wave grid, lane half)) -> scand[workgroup][query][cell][2], and the best
+                            // score it left out -> dump[q][sample_floor + seq * 4 + cell] (tau_kernel folds them into floor_ord[q])
+    uint32_t sample_floor;  // SAMPLE mode: offset (floats) of the floor values in a query's row of `dump`
+    uint2* scand;           // [W of the sample][256][8] (score bits, row): the cells' two best rows (-inf: none)
+    uint32_t append_splits; // EMIT: the workgroups of corpus splits [0, append_splits) first move the sample's candidates of their
+                            // list index (same g) that score above the query's threshold - known by now - into their lists
 };
 
 // Physical workgroup -> (query tile, corpus split), XCD-aware. Block b runs on XCD b % 8 (observed placement,
@@ -206,6 +214,25 @@ __device__ inline uint32_t lds_inc_rtn(uint32_t* p) {
     return old;
 }
 
+// Start of an emitting launch that follows an emitting sample (CoarseArgs::append_splits): the sample kept two rows per cell and
+// query without knowing any threshold; the threshold exists now, so only the few that pass it (about k' of the 8 x S per query)
+// enter the candidate lists - select / final see ~k' more keys, not 512. cntq must be zero and visible (barrier) before the call.
+template <int BN, int NT>
+__device__ __forceinline__ void append_sample_candidates(const CoarseArgs& a, uint32_t g, uint32_t qt, uint32_t split, uint32_t* cntq,
+                                                         int tid) {
+    if (split >= a.append_splits) return;   // uniform
+    const uint2* src = a.scand + (uint64_t)g * BN * 8u;
+    for (int i = tid; i < BN * 8; i += NT) {
+        const uint2 e = src[i];
+        const uint32_t ql = (uint32_t)i >> 3, q = qt * (uint32_t)BN + ql;
+        if (q < a.nq && __uint_as_float(e.x) > a.tau[q]) {   // block_hits' condition; absent entries carry -inf
+            const uint32_t p = lds_inc_rtn(&cntq[ql]);
+            if (p < CAND_CAPS) a.cand[((uint64_t)g * BN + ql) * CAND_CAPS + p] = e;
+            else a.overflow[q] = 1u;
+        }
+    }
+}
+
 __device__ inline void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -224,6 +251,17 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 __device__ __forceinline__ float vmax2(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float vmin2(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmed3(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -462,11 +500,29 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
         // seq * 16 + wm * 8 + (lane >> 5) * 4 + mb: one 16-byte store per lane and N-block); 8 / 4 = the maxima of
         // block pairs / of all four blocks of the lane (groups of 32 / 64 rows), for samples of up to 128 / 256 tiles
         // within tau_kernel's 1024 values per query (one query tile: C4 samples with ALL CUs, 256 tiles).
+        // Round 6, a.sample_emit: the sample EMITS. Until then its tiles were scored again by the emitting launches (1.6 % of C2's
+        // GEMM, 13 % of a 125 k-row shard's). No threshold exists here, so the lane keeps - per query column - the two best of the
+        // 64 rows it holds (its cell: 4 blocks x 16 rows) and the best score it left out, like a COARSE_TOP2 cell: the two go to
+        // scand (the first emitting launch moves those above the threshold - which exists by then - into its candidate lists:
+        // append_sample_candidates), the left-out score to the floor area of the query's dump row; tau_kernel folds the 4 x S floor values of a query into
+        // floor_ord[q] and the final kernel checks its guarantee against max(tau, floor), as it does for COARSE_TOP2: a sampled row
+        // that is in no list scores at most its cell's left-out score. (Three of a query's final top-k' rows in one 64-row cell of
+        // the sample raise the floor above e_k: the query takes the exact scan - C(16, 3) x (S / R)^3 / 256^2 per query.)
         static_assert(MODE != 2 || MB == 4, "sample layout assumes 4 M-blocks per wave");
+        const bool emit = a.sample_emit != 0u;   // uniform
+        // The cell's three best values by a max / med3 / min network on floats whose 6 low mantissa bits carry the value's
+        // position in the lane's sequence (mb * 16 + r): 6 VALU per score (scale, tag, 4 for the network) instead of the 13 of a
+        // compare-and-select insertion with row bookkeeping (the epilogue of a one-tile launch runs with the matrix pipe idle in
+        // all 8 waves: 128 scores per lane at 13 VALU cost the sample launch 8.6 us, profiles/r06_sample_emit_first_form.txt).
+        // The tag perturbs a score by < 64 ulp = 2^-17 relative: the candidates' coarse scores are off by that much more
+        // (coarse_eps_scale prices it), and the floor is raised by it. Rows beyond the corpus (its last tile) are NONE.
+        constexpr float NONE = -3.0e38f;
+        const bool full = (uint64_t)tile * BM + BM <= (uint64_t)a.n;   // uniform: every row of the tile exists
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const uint32_t q = qt * BN + wn * WTN + nb * 32 + (lane & 31);
             float m[MB];
+            float s1 = NONE, s2 = NONE, b3 = NONE;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 float mm = -INFINITY;
@@ -474,7 +530,15 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t rl = (uint32_t)(wm * WTM + mb * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (uint32_t)(lane >> 5);
                     const float sc = (a.metric == METRIC_DOT) ? acc[mb][nb][r] : acc[mb][nb][r] * invn_s[rl];
-                    if (tile * (uint32_t)BM + rl < a.n) mm = fmaxf(mm, sc);
+                    const bool valid = full || tile * (uint32_t)BM + rl < a.n;
+                    if (valid) mm = fmaxf(mm, sc);
+                    if (emit) {
+                        float v = __uint_as_float((__float_as_uint(sc) & ~63u) | (uint32_t)(mb * 16 + r));
+                        if (!full) v = valid ? v : NONE;
+                        b3 = vmax2(b3, vmin2(s2, v));   // (one instruction each: fmaxf would canonicalise its inputs first)
+                        s2 = vmed3(s1, s2, v);
+                        s1 = vmax2(s1, v);
+                    }
                 }
                 m[mb] = (mm == -INFINITY) ? -INFINITY : mm * invq[nb];
             }
@@ -487,6 +551,23 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
                     *(float2*)(dst + lg * 2u) = make_float2(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
                 } else {
                     dst[lg] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+                }
+                if (emit) {
+                    const uint32_t ql = (uint32_t)(wn * WTN + nb * 32 + (lane & 31));
+                    const float iq = (a.metric == METRIC_DOT) ? 1.0f : invq[nb];
+                    auto row_of = [&](float sv) {   // position tag -> corpus row
+                        const uint32_t p = __float_as_uint(sv) & 63u;
+                        return tile * (uint32_t)BM + (uint32_t)(wm * WTM) + (p >> 4) * 32u + (p & 3u) + 8u * ((p >> 2) & 3u) + 4u * (uint32_t)(lane >> 5);
+                    };
+                    // = (acc * invn_c) * invn_q, block_hits' order; one 16-byte store: the cell's two entries are adjacent
+                    const float c1 = (s1 > -1.0e38f) ? ((a.metric == METRIC_DOT) ? s1 : s1 * iq) : -INFINITY;
+                    const float c2 = (s2 > -1.0e38f) ? ((a.metric == METRIC_DOT) ? s2 : s2 * iq) : -INFINITY;
+                    *(uint4*)(a.scand + ((uint64_t)g * BN + ql) * 8u + lg * 2u) =
+                        make_uint4(__float_as_uint(c1), row_of(s1), __float_as_uint(c2), row_of(s2));
+                    // every score the cell left out is below b3 + 64 ulp (the tags): raise the floor by 2^-17 of its magnitude
+                    const float fb = b3 + fabsf(b3) * 7.6294e-6f;
+                    a.dump[(uint64_t)q * a.sample_ld + a.sample_floor + seq * 4u + lg] =
+                        (b3 > -1.0e38f) ? ((a.metric == METRIC_DOT) ? fb : fb * iq) : -INFINITY;
                 }
             }
         }
@@ -652,6 +733,8 @@ __device__ inline bool boot_wait(uint32_t* counter, uint32_t* degraded, uint32_t
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
 // 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §10.2 quotes the numbers.
+// 1024 = the query (B) operand for free: no B DMA, no B fragment reads (an upper bound of what feeding B through registers could buy);
+// 2048 = only the B DMA goes (the B fragment reads stay, on stale LDS); 4096 = only the B fragment reads go (the DMA stays).
 // 256 / 512 / 768 = the stage's counted wait is vmcnt(4) / (6) / (2) instead of (8): results stay correct, the DMA lead shrinks
 // by 1 / 0.5 / 1.5 stages (how much of the 3-stage lead does the kernel need? r03i: two stages are enough).
 // EPI, the emitting epilogue: 1 (default) = the conservative thresholds are formed in the MFMA gaps of a tile's last
@@ -702,6 +785,10 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     if ((a.epi & 64u) != 0u && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+    if (EMIT && a.append_splits != 0u) {   // uniform: the first launch behind an emitting sample
+        __syncthreads();
+        append_sample_candidates<BN, NT>(a, g, qt, split, cntq, tid);
+    }
 
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll
@@ -805,9 +892,9 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
             } else if (q == 1) {
                 CGV_BDMA_A(rsA, d_dst, 1024);
             } else if (q == 2) {
-                CGV_BDMA(rsB, d_dst + A_BYTES, 0);
+                if (!(ABL & (1024 | 2048))) CGV_BDMA(rsB, d_dst + A_BYTES, 0);
             } else {
-                CGV_BDMA(rsB, d_dst + A_BYTES, 1024);
+                if (!(ABL & (1024 | 2048))) CGV_BDMA(rsB, d_dst + A_BYTES, 1024);
                 if (SI == 1) si_slot += (uint32_t)STAGE;   // SI >= 2: set by the (unrolled) caller, a constant per iteration
                 si_so += BLOCK_BYTES;
             }
@@ -911,7 +998,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         for (int i = 0; i < NB; ++i) fb0[i] = fb1[i] = (frag)0;
     }
 #define CGV_LDA(FA, I, BASE, KK) if (!(ABL & (8 | 128))) FA[I] = *(const frag*)((BASE) + aoff + (I) * 2048 + xo[KK]);
-#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & (8 | 128))) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
+#define CGV_LDB(FB, I, BASE, KK) if (!(ABL & (8 | 128 | 1024 | 4096))) FB[I] = *(const frag*)((BASE) + boff + (I) * 2048 + xo[KK]);
 #define CGV_LOAD_FRAGS(FA, FB, BASE, KK)                                                         \
     {                                                                                            \
         CGV_LDA(FA, 0, BASE, KK) CGV_LDA(FA, 1, BASE, KK) CGV_LDA(FA, 2, BASE, KK) CGV_LDA(FA, 3, BASE, KK) \
@@ -999,6 +1086,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         if ((ABL & 768) == 256) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  /* lead - 1 stage (timing probe) */ \
         else if ((ABL & 768) == 512) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           \
         else if ((ABL & 768) == 768) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           \
+        else if (ABL & (1024 | 2048)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  /* 2 DMA per stage: the same 2-stage lead */ \
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                   \
     }                                                                                           \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier()
@@ -1160,10 +1248,19 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
         issue_q(2);
         issue_q(3);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // stage 0 (and the side data before it) landed; stages 1, 2 may be in flight
+    if (ABL & (1024 | 2048)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // stage 0 (and the side data before it) landed; stages 1, 2 may be in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my cntq zero-stores done
     __builtin_amdgcn_s_barrier();
     CGV_LOAD_FRAGS(fa0, fb0, smem, 0);
+    if (ABL & (1024 | 4096)) {  // timing probe "the query operand for free" (2048: only its DMA goes, 4096: only its fragment reads): B fragments once, straight from the query tile's first chunk
+                       // in global memory (real data); no B DMA, no B fragment reads in the loop (results are wrong)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            fb0[i] = *(const frag*)(bbase + (boff - (uint32_t)A_BYTES) + i * 2048 + xo[0]);
+            fb1[i] = *(const frag*)(bbase + (boff - (uint32_t)A_BYTES) + i * 2048 + xo[1]);
+        }
+    }
     if (ABL & 128) {  // both fragment sets once, from the first stage (real data), never again
 #pragma unroll
         for (int i = 0; i < MB; ++i) {

@@ -62,6 +62,10 @@ __global__ __launch_bounds__(512) void coarse_fp8s_kernel(const CoarseArgs a) {
     const uint32_t g = block_to_work(a, qt, split);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+    if ((MODE == 0) && a.append_splits != 0u) {   // uniform: the first launch behind an emitting sample (kernels_coarse.h)
+        __syncthreads();
+        append_sample_candidates<BN, NT>(a, g, qt, split, cntq, tid);
+    }
 
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll

@@ -7,7 +7,7 @@
 // and its accumulators are cleared per tile. One wave per SIMD has 256 + 256: fragments fully double-buffered
 // (2 x 8 blocks x 8 VGPRs), zero-C MFMAs at the tile start, 16 reads per 16 MFMAs (64 cycles each), and every
 // gap between two MFMAs carries either two fragment reads or one DMA piece.
-// Everything else follows kernels_coarse_w4.h / kernels_coarse.h: B32 blocked operands, 4-slot LDS ring filled
+// Everything else follows experiments/kernels_coarse_w4.h / kernels_coarse.h: B32 blocked operands, 4-slot LDS ring filled
 // by buffer_load ... lds three stages ahead and retired by a counted vmcnt, the fused threshold top-k' epilogue
 // (tile_epilogue), XCD-aware workgroup mapping (block_to_work). A stage is ONE K=64 k-step, so both phases of a
 // loop body are whole stages with their own counted wait + barrier (needs an even kc >= 4; the host falls back
@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const Pace pace = pace_init(a, g, qt);
 
     for (int i = tid; i < BN; i += NT) cntq[i] = 0;
+    if ((!DUMP) && a.append_splits != 0u) {   // uniform: the first launch behind an emitting sample (kernels_coarse.h)
+        __syncthreads();
+        append_sample_candidates<BN, NT>(a, g, qt, split, cntq, tid);
+    }
 
     float tauv[NB], tq[NB], invq[NB];
 #pragma unroll

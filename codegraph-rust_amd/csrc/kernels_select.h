@@ -22,6 +22,8 @@ struct SelectArgs {
     uint32_t tau_only;         // dense scores of a SAMPLE of the corpus: publish tau, keep no candidates
     uint32_t* floor_ord;       // COARSE_TOP2: [nq] f2ord of the best coarse score left out of the candidate lists (0: none), or NULL;
                                // final_kernel reads its query's word and clears it for the next search (no memset launch per call)
+    uint32_t floor_with_tau;   // != 0: the floor comes from an EMITTING SAMPLE (tile_epilogue, SAMPLE mode) and bounds only the rows of
+                               // the sampled tiles; the launches behind it had thresholds (tau[] is meaningful, unlike COARSE_TOP2)
     uint64_t* trace;           // diagnostics (CGV_TRACE=1): [nq][8] wall-clock stamps of the kernel's phases, or NULL
 };
 
@@ -357,15 +359,25 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
 // rank hi_rank of the sample's maxima - tau0): the sample's own spread between two of its order statistics, scaled by the host
 // to a quarter of 1.25 x the distance at which the final k'-th best is expected under a normal tail (plan_ladder_scale, cgvec.hip)
 // - only the tightness of the thresholds depends on that guess, never their validity. Spread 0 / no sample: delta 0, no ladder.
+// Emitting sample (round 6, tile_epilogue's SAMPLE mode): dense[q][M .. M + floor_n) holds, per cell of the sample, the best coarse
+// score the cell left out of the candidate lists; their maximum is the query's floor word (f2ord; 0 = nothing left out), which
+// the final kernel folds into the threshold of its guarantee check.
 __global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
                                                   uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest,
                                                   float4* __restrict__ ladc = nullptr, unsigned long long* __restrict__ lad = nullptr,
-                                                  float lad_scale = 0.0f, uint32_t hi_rank = 0) {
+                                                  float lad_scale = 0.0f, uint32_t hi_rank = 0, uint32_t floor_n = 0,
+                                                  uint32_t* __restrict__ floor_ord = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (q >= nq) return;
     float hi = -INFINITY;
     const float t = kth_largest_wave(dense + (uint64_t)q * ld, M, kprime, lane, hi_rank, ladc ? &hi : nullptr);   // common.h
+    if (floor_ord) {
+        float fl = -INFINITY;
+        for (uint32_t i = (uint32_t)lane; i < floor_n; i += 64u) fl = fmaxf(fl, dense[(uint64_t)q * ld + M + i]);
+        const uint32_t fo = wave_max_u32(fl > -INFINITY ? f2ord(fl + 0.0f) : 0u);
+        if (lane == 0) floor_ord[q] = fo;
+    }
     if (lane == 0) {
         tau[q] = t;
         nbest[q] = 0u;
@@ -743,7 +755,7 @@ __global__ __launch_bounds__(256) void final_kernel(const SelectArgs sa, const R
     float tau = (M >= sa.kprime) ? key_score(outk[sa.kprime - 1]) : sa.tau[q];
     float tau_lists = INFINITY;   // (COARSE_TOP2 only: the threshold of the candidate lists alone, without the floor)
     if (sa.floor_ord) {   // COARSE_TOP2: rows no cell kept score at most the floor; the lists hold no threshold of their own
-        if (M < sa.kprime) tau = -INFINITY;
+        if (M < sa.kprime && !sa.floor_with_tau) tau = -INFINITY;
         tau_lists = tau;
         const uint32_t fo = sa.floor_ord[q];
         if (fo != 0u) tau = fmaxf(tau, ord2f(fo));

@@ -18,8 +18,8 @@ def _plan(L, n, k, nq, n_cu=256, shadow=0):
     L.cgv_debug_plan_.restype = C.c_uint32
     L.cgv_debug_plan_.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_uint32]
     w = L.cgv_debug_plan_(n, k, nq, n_cu, shadow, out, 64)
-    assert w >= 2
-    return out[0], list(out[2:w])
+    assert w >= 2 and (out[1] & 0xFFFF) == w - 2
+    return out[0], list(out[2:w]), bool(out[1] & 0x10000)
 
 
 @pytest.mark.parametrize("n,k,nq,shadow", [
@@ -29,10 +29,15 @@ def _plan(L, n, k, nq, n_cu=256, shadow=0):
 ])
 def test_plan_covers_every_tile_once(n, k, nq, shadow):
     L = pkg().cgvec.lib()
-    sample, counts = _plan(L, n, k, nq, shadow=shadow)
+    sample, counts, emits = _plan(L, n, k, nq, shadow=shadow)
     ntiles = (n + 255) // 256
     assert 0 < sample <= 256 and sample <= ntiles         # 16 / 8 / 4 group maxima per tile -> <= 1024 values per query
-    assert all(c > 0 for c in counts) and sum(counts) == ntiles
+    # round 6: a sample that emits its own candidates is not scored again - the launches cover the tiles behind it
+    assert all(c > 0 for c in counts) and sum(counts) + (sample if emits else 0) == ntiles
+    kprime = min((4 * k + 16 + 7) // 8 * 8, 256) if shadow else (k + max(6, k // 8) + 7) // 8 * 8
+    assert emits == (nq > 64 and kprime <= 64 and ntiles >= 2 * sample and counts[0] >= min(sample, max(1, 256 // ((nq + 255) // 256))))
+    if emits:
+        assert min(counts[0], max(1, 256 // ((nq + 255) // 256))) >= sample    # the first launch continues every sampled tile's lists
     assert len(counts) <= 8
     # thresholds tighten launch by launch: the rows behind a launch's threshold never shrink relative to its size
     seen = sample
@@ -43,10 +48,12 @@ def test_plan_covers_every_tile_once(n, k, nq, shadow):
 
 def test_plan_shapes_of_the_baseline_configs():
     L = pkg().cgvec.lib()
-    assert _plan(L, 1_000_000, 10, 1024) == (64, [448, 3459])   # C2: sample, 112 k rows, the dominant launch
-    assert _plan(L, 125_000, 10, 1024) == (64, [489])           # C2's 8-GPU shard: ONE emitting launch
-    assert _plan(L, 4096, 10, 64)[0] == 0                        # <= 16 tiles: the dense boot stage covers the corpus
-    assert _plan(L, 1_000_000, 10, 256) == (256, [3907])        # C4, one query tile: the sample uses every CU
+    assert _plan(L, 1_000_000, 10, 1024) == (64, [448, 3395], True)   # C2: emitting sample, 112 k rows, the dominant launch
+    assert _plan(L, 125_000, 10, 1024) == (64, [425], True)           # C2's 8-GPU shard: ONE launch behind the sample
+    assert _plan(L, 4096, 10, 64)[0] == 0                              # <= 16 tiles: the dense boot stage covers the corpus
+    assert _plan(L, 1_000_000, 10, 256) == (256, [3651], True)        # C4, one query tile: the sample uses every CU
+    assert _plan(L, 1_000_000, 10, 64) == (256, [3907], False)        # <= 64 queries take COARSE_TOP2 anyway: the old form
+    assert _plan(L, 1_000_000, 200, 1024)[2] is False                  # k' > 64: the final selection is not fused, no floor there
 
 
 def test_rccl_loader_failure_is_reported_not_fatal():
