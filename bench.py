@@ -478,6 +478,9 @@ def main():
                          "(traits.rs:14; search.rs:358-361 issues B of them concurrently); the library merges concurrent callers into "
                          "shared device batches (csrc/coalesce.h). 0 = skip")
     ap.add_argument("--coalesced-calls", type=int, default=0, help="calls per thread of `coalesced_callers` (0 = sized for ~0.3 s)")
+    ap.add_argument("--latency-tail", type=int, default=20000,
+                    help="N = 1: single-query calls (distinct queries, one native thread) behind latency.nq1_tail's p50 / p99 / p99.9 / "
+                         "p99.99 (a twentieth of it on corpora beyond 2M rows); 0 = skip")
     ap.add_argument("--latency", type=int, default=1,
                     help="N = 1: side fields with the median latency of nq = 1 / 8 / 32 searches through cgv_search_f32 (pageable "
                          "and pinned buffers) on this workload's index (0 = skip)")
@@ -1002,6 +1005,31 @@ def run(args, wd, world, rank, local_rank):
             latency["cgvs_search_similar_nq1"] = {"median_us": round(1e6 * float(np.median(ts[10:])), 1),
                                                   "p99_us": round(1e6 * float(np.percentile(ts[10:], 99)), 1), "hits": len(got)}
             vs.close()
+        # the TAIL of the single-query call: many DISTINCT queries (the loops above repeat one), native caller thread. What sits
+        # out there: a small batch keeps two rows per 1/1024 of the corpus, and a query with three of its best rows in one cell
+        # fails its check (5e-4 per query on C2's corpus) - round 5 sent it through the exact scan of the whole corpus (+0.4 ms),
+        # round 6 re-scans the offending cells only (kernels_repair.h); small_batch_stats counts both kinds.
+        if args.latency_tail > 0 and st["last_path"] == 1:
+            try:
+                CLt = load_callers_lib(m)
+                ncalls = args.latency_tail if n_total <= 2_000_000 else max(200, args.latency_tail // 20)
+                if RNG == "counter":
+                    qtail = m.cgvec.synth_rows_dev(SEED_QUERY, 1 << 24, ncalls, dim, device=dev_index).cpu().numpy()
+                else:
+                    qtail = np.ascontiguousarray(torch.cat(qpool).cpu().numpy())
+                sb0 = ix.small_batch_stats()
+                ix.set_coalesce(0, 0, 0)       # lone calls
+                _, _, latt, _ = run_native_callers(CLt, ix, qtail, k, 1, ncalls)
+                ix.set_coalesce()
+                sb1 = ix.small_batch_stats()
+                latency["nq1_tail"] = {"calls": int(ncalls), "distinct_queries": int(qtail.shape[0]),
+                                       **{f"p{str(p_).replace('.', '_')}_us": round(float(np.percentile(latt, p_)), 1) for p_ in (50, 99, 99.9, 99.99)},
+                                       "max_us": round(float(latt.max()), 1),
+                                       "queries_that_failed_the_small_batch_check": sb1["failed_queries"] - sb0["failed_queries"],
+                                       "answered_by_cell_rescan": sb1["repaired_by_cell_rescan"] - sb0["repaired_by_cell_rescan"],
+                                       "answered_by_exact_scan": sb1["exact_scans"] - sb0["exact_scans"]}
+            except Exception as e:   # noqa: BLE001 - a side field must not take the line down
+                latency["nq1_tail"] = {"error": f"{type(e).__name__}: {e}"}
         latency["note"] = ("median wall time of one cgv_search_f32 call (host buffers in, host results out), path 0 = exact scan, "
                            "1 = MFMA coarse + exact re-score; corpus_stream_gb_per_s = rows x dim x s / best median")
     wd.kick("side measurements done")

@@ -1431,7 +1431,7 @@ const float* fetch_host_queries(cgv_index* h, SearchCtx* c, const float* q, uint
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 7u; }  // 0.7: + cgv_set_coalesce, cgv_get_coalesce_stats
+uint32_t cgv_version(void) { return (0u << 16) | 8u; }  // 0.8: + scalar-arm normalise, small-batch stats, phase times, synthetic inputs
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }

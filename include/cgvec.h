@@ -89,7 +89,9 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_MAX_K 2048u
 #define CGV_FAST_MAX_K 228u
 
-/* Library/ABI version (major<<16 | minor). Minor 7 (round 6): cgv_set_coalesce / cgv_get_coalesce_stats (concurrent small
+/* Library/ABI version (major<<16 | minor). Minor 8 (round 6): cgv_normalize_rows_scalar_f32 (the scalar arm of
+ * parallel_normalize_vectors), cgv_get_small_batch_stats, cgv_get_phase_times (profiling level 3), cgv_synth_rows_f32_dev (the
+ * bench's counter-based inputs). Minor 7 (round 6): cgv_set_coalesce / cgv_get_coalesce_stats (concurrent small
  * cgv_search_f32 calls share one device batch). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
  * environment variable; cgv_alloc_pinned / cgv_free_pinned. Minor 4 (round 3): cgv_sharded_search_begin_f32 / _end / _max_batches_in_flight,
  * cgv_set_profiling levels, pinned host buffers used in place by cgv_search_f32. Minor 5 (round 4): cgv_search_packed_begin_f32_dev
