@@ -90,7 +90,7 @@ WORKLOADS = {
     "mid": (300_000, 768, "bf16", "cosine", 1024, 10),
     "c2shard8": (125_000, 768, "bf16", "cosine", 1024, 10),    # one rank's share of C2 at 8 GPUs (fixed-cost probe)
     # C2 with HALF the batch: two of these in flight (`pipelined`) are the proxy for running one cgv_search_f32 batch as two
-    # 512-query halves on two contexts (VERDICT r3 'Next' 2b) - DESIGN.md §9.1 has what it measured
+    # 512-query halves on two contexts (VERDICT r3 'Next' 2b) - HISTORY.md §9.1 has what it measured
     "c2half": (1_000_000, 768, "bf16", "cosine", 512, 10),
     # C5 = 500M x 768 fp8 over 8 GPUs, batch 8192: one GPU's share is 62.5M rows = 48 GB of codes
     "c5shard": (62_500_000, 768, "fp8", "cosine", 8192, 10),

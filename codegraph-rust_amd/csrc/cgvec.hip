@@ -819,7 +819,7 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
 
         // Fused form (round 4, MEASUREMENT FLAVOUR ONLY): the first emitting launch takes its own first threshold from the first
         // tile of every workgroup (COARSE_EMIT_BOOT, kernels_coarse.h) - no sample launch, no tau_kernel, the sample tiles scored
-        // once. Measured break-even at best against the three launches it replaces (profiles/r04_fused_launch_ab.txt:
+        // once. Measured break-even at best against the three launches it replaces (HISTORY.md §9.1, profiles/r04_fused_launch_ab.txt:
         // a rendezvous right behind the first tile exposes the launch's ramp skew, and 128 accumulators per lane held across it
         // either spill or, stashed, cost more L2 / HBM traffic than scoring the tile again), so the production library does not
         // carry it; knob `fuse_sample` of scripts/ab.py.

@@ -8,7 +8,7 @@
 // per-tile epilogue (256 v_accvgpr_read + the maxima) - and removed in round 3. VERDICT r3 'Next' 3 asked for the A/B that
 // was never run: THIS layout with the fp8 one-wave kernel's FOLDED epilogue (kernels_coarse_fp8_w4.h): at a tile boundary the
 // next tile's zero-C k-step copies a block's 16 accumulators to VGPRs, issues the MFMA that overwrites them and filters the
-// copy while that MFMA occupies the matrix pipe. Resurrected from 559d79f^ with that fold; DESIGN.md §9.2 has the result.
+// copy while that MFMA occupies the matrix pipe. Resurrected from 559d79f^ with that fold; HISTORY.md §9.2 has the result.
 // Everything else is the 8-wave kernel's round-2 design (kernels_coarse.h): B32 blocked operands, 4-slot LDS ring filled by
 // buffer_load ... lds three stages ahead and retired by a counted vmcnt, one barrier per stage, tile-structured loop with
 // zero-C MFMAs at the tile boundary, XCD-aware workgroup mapping (block_to_work), dynamic issue side. Differences:

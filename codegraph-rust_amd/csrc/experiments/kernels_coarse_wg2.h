@@ -3,7 +3,7 @@
 //
 // coarse_kernel (kernels_coarse.h) runs ONE workgroup of 8 waves per CU: the two waves of a SIMD belong to the same workgroup,
 // meet at the same stage barrier and filter at the same tile boundary, so whatever one of them waits for, the other usually
-// waits for too (barrier ~9.5 % of the main launch's cycles, epilogue ~5.8 %: DESIGN.md §9.2). Here a workgroup is 4 waves
+// waits for too (barrier ~9.5 % of the main launch's cycles, epilogue ~5.8 %: HISTORY.md §9.2). Here a workgroup is 4 waves
 // (1(M) x 4(N), the SAME 128 x 64 wave tile = the same registers, fragment reads and k-step as coarse_kernel) over a
 // 128 x 256 output tile, its ring is three 24-KiB stages (79 KiB of LDS with the side data: two workgroups fit the CU's 160 KiB),
 // and the SIMD's second wave comes from ANOTHER workgroup with its own barrier and its own tile boundaries.

@@ -666,7 +666,7 @@ __device__ __forceinline__ void tile_filter_emit(const CoarseArgs& a, f32x16_t (
 
 // ---- COARSE_EMIT_BOOT: sample + first threshold + first emitting pass in ONE launch (round 4) --------------------------
 // MEASUREMENT FLAVOUR ONLY (make ABLATE=1; knob `fuse_sample` of scripts/ab.py): a measured negative result, kept so that
-// the A/B in profiles/r04_fused_launch_ab.txt can be repeated. DESIGN.md §9.1 has the numbers.
+// the A/B in profiles/r04_fused_launch_ab.txt can be repeated. HISTORY.md §9.1 has the numbers.
 // Round 3 spends three launches on the first threshold: a sample launch (one tile per workgroup, block maxima only), tau_kernel,
 // then the first emitting launch, which scores the sample tiles AGAIN - 32 + 7 us + two launch boundaries + a second ramp per
 // batch. Here the first tile of every workgroup's walk IS its sample: at the tile's end the workgroup publishes the tile's group
@@ -732,7 +732,7 @@ __device__ inline bool boot_wait(uint32_t* counter, uint32_t* degraded, uint32_t
 // 1 = skip the epilogue, 2 = skip the DMA, 4 = skip the barrier, 8 = skip the fragment reads
 // (MFMA on zeros), 16 = skip the vmcnt wait; 32 = global_load...lds instead of buffer_load...lds
 // (results stay correct for 32); 64 = DMA for the first ring of stages only (the LDS keeps REAL data);
-// 128 = fragments read once, before the loop (MFMA on real data without LDS reads). DESIGN.md §10.2 quotes the numbers.
+// 128 = fragments read once, before the loop (MFMA on real data without LDS reads). HISTORY.md §10.2 quotes the numbers.
 // 1024 = the query (B) operand for free: no B DMA, no B fragment reads (an upper bound of what feeding B through registers could buy);
 // 2048 = only the B DMA goes (the B fragment reads stay, on stale LDS); 4096 = only the B fragment reads go (the DMA stays).
 // 256 / 512 / 768 = the stage's counted wait is vmcnt(4) / (6) / (2) instead of (8): results stay correct, the DMA lead shrinks
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(512) void coarse_kernel(const CoarseArgs a) {
     // The 6 fragment reads go right behind the first MFMA (hipcc waits lgkmcnt(0), so they get 7 MFMAs to land;
     // the partner wave of the SIMD covers their issue), a DMA piece behind MFMAs 4 and 6. (One read per gap
     // measured the same: 1.003 vs 1.004 ms on the C2 main launch; giving the two waves of a SIMD different DMA
-    // gaps - waves 0-3 early, 4-7 late in the k-step - measured 4-8 % SLOWER: DESIGN.md §10.2.)
+    // gaps - waves 0-3 early, 4-7 late in the k-step - measured 4-8 % SLOWER: HISTORY.md §10.2.)
 #define CGV_KSTEP(MMA, FA, FB, NA, NB_, NBASE, NKK, Q0, FIRST)                                                   \
     {                                                                                                            \
         /* serpentine block order: consecutive MFMAs share one operand block (0.5 % on the C2 main launch) */    \

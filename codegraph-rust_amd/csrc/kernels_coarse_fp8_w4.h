@@ -12,7 +12,7 @@
 // (tile_epilogue), XCD-aware workgroup mapping (block_to_work). A stage is ONE K=64 k-step, so both phases of a
 // loop body are whole stages with their own counted wait + barrier (needs an even kc >= 4; the host falls back
 // to the 8-wave kernel otherwise).
-// Row scales: the E8M0 scale operand of a lane is 127 - e of its row, 4 corpus bytes (one per
+// Row scales (HISTORY.md §4.1): the E8M0 scale operand of a lane is 127 - e of its row, 4 corpus bytes (one per
 // 32-row block of the wave tile) + 4 query bytes. The corpus bytes of a tile are needed by its FIRST MFMA, so a
 // tile's 256 exponents are DMA'd into the 8-deep LDS ring one tile boundary EARLIER than its inverse norms
 // (which only the epilogue needs).

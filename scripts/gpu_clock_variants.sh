@@ -1,7 +1,7 @@
 #!/bin/bash
 # Cycles / clock / MFMA busy of the C2 main coarse launch for the round-4 kernel variants (measurement flavour, CGV_EPI):
 #   1 = the production 8-wave kernel, 65 = + static priority for waves 4-7, 129 = one wave per SIMD (128 x 128 per wave) with the
-#   folded epilogue, 385 = the same with its epilogue as one block at the tile boundary.  DESIGN.md §9.2
+#   folded epilogue, 385 = the same with its epilogue as one block at the tile boundary.  HISTORY.md §9.2
 export CGV_LIB_PATH=${GRAFT_REPO_ROOT:-.}/codegraph-rust_amd/lib/libcgvec_hip_ablate.so
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,4 @@
-"""Stress for the flaky abort of the full GPU suite: register a HEAP numpy buffer with
+"""Stress for the flaky abort of the full GPU suite (HISTORY.md §9.5): register a HEAP numpy buffer with
 hipHostRegister, let the library read queries from it, unregister, free it, then hand fresh heap buffers (likely the same
 addresses) to cgv_add_f32 / cgv_search_f32 as pageable memory. Prints one line per phase; an abort shows the runtime's message."""
 import importlib

@@ -1,4 +1,4 @@
-"""Stress for the intermittent abort of the full GPU suite: the WHOLE pinned / registered host-buffer test
+"""Stress for the intermittent abort of the full GPU suite (HISTORY.md §9.5): the WHOLE pinned / registered host-buffer test
 case, in this process, followed by what the suite ran next when it died (a fresh index, cgv_add_f32 of 3*4096+77 x 64
 pageable rows, a search), in a loop. tests/c_client/abort_bt.c is hooked in, so an abort names the native stack that raised it.
 

@@ -86,7 +86,7 @@ def test_product_never_imports_oracle():
 def test_abort_bt_names_the_native_stack(tmp_path):
     """tests/c_client/abort_bt.c (hooked into the pytest process by conftest.py): a child that calls abort() from native
     code leaves the C-level stack of the raising thread on stderr - with abort() itself in it - before Python's faulthandler
-    prints the Python frames. (What round 3's two suite aborts lacked: DESIGN.md §9.5.)"""
+    prints the Python frames. (What round 3's two suite aborts lacked: HISTORY.md §9.5.)"""
     import subprocess
     import sys
     code = ("import sys, ctypes, faulthandler; sys.path.insert(0, %r); faulthandler.enable(); "

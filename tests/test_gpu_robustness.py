@@ -226,7 +226,7 @@ def test_pinned_host_buffers_are_used_in_place(oracle):
     the exact-scan fallback (it writes into the caller's pinned arrays too), a non-finite query (error, index intact),
     an f32 index (exact path only), and a registered (hipHostRegister) buffer.
     Runs IN THE SUITE'S PROCESS (round 3 moved it into a child after two unexplained aborts of the full suite in the test
-    that followed it; DESIGN.md §9.5 has what the hunt for them found). tests/conftest.py hooks tests/c_client/abort_bt.c into
+    that followed it; HISTORY.md §9.5 has what the hunt for them found). tests/conftest.py hooks tests/c_client/abort_bt.c into
     the process, so a recurrence leaves the native stack of the raising thread in the log. CGV_PINNED_CHILD=1 restores the
     isolated form (a child that leaves through os._exit)."""
     if not os.environ.get("CGV_PINNED_CHILD"):
