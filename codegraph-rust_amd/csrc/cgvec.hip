@@ -141,7 +141,7 @@ struct SearchCtx {
     bool flags_clean = false;     // device flag + pacing words are known to be zero (the last kernel resets them)
     bool published = false;       // the search in flight publishes its flags itself (no D2H copy enqueued)
     DevBuf qstage, qrows, qnorm, qinvn, qrexp, tau, nbest, best, overflow, fbflag, qlist, cand, candcnt, scores,
-        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone, qspread, cellb, reptheta, repkeys, repn, scand;
+        keysA, keysB, outidx, outscore, dump, qshadow, qres, trace, floor, lad, ladc, qstat, xdone, qspread, cellb, reptheta, repkeys, repn, scand, repnew, repcnt;
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: host timeline of the last cgv_search_f32 (CGV_TRACE=1)
     bool busy = false, split = false;
     hipEvent_t copied = nullptr;   // batches in flight: the copy engine has fetched this batch's host queries (fetch_host_queries)
@@ -165,7 +165,7 @@ struct SearchCtx {
     size_t bytes() const {
         const DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                                 &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn, &scand};
+                                &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn, &scand, &repnew, &repcnt};
         size_t b = 0;
         for (const DevBuf* d : bufs) b += d->bytes;
         return b;
@@ -173,11 +173,13 @@ struct SearchCtx {
     void release_all() {
         DevBuf* bufs[] = {&qstage, &qrows, &qnorm, &qinvn, &qrexp, &tau, &nbest, &best, &overflow, &fbflag,
                           &qlist, &cand, &candcnt, &scores, &keysA, &keysB, &outidx, &outscore, &dump,
-                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn, &scand};
+                          &qshadow, &qres, &trace, &floor, &lad, &ladc, &qstat, &xdone, &qspread, &cellb, &reptheta, &repkeys, &repn, &scand, &repnew, &repcnt};
         for (DevBuf* d : bufs) d->release();
     }
 };
 
+constexpr uint32_t TOP2_MAX_NQ_C = 64;                 // queries of a small batch (COARSE_TOP2)
+constexpr size_t REPAIR_LDS_BYTES = 60u << 10;         // staged rows + the query row of top2_repair_scan_kernel (within the 64 KiB default)
 constexpr int N_CTX = 3;
 constexpr size_t SMALL_Q_BYTES = 256u << 10, SMALL_OUT_BYTES = 128u << 10;   // SearchCtx::h_stage
 
@@ -523,6 +525,12 @@ int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), lds, s, sa);
     HIPCHK(hipGetLastError());
     return CGV_OK;
+}
+
+// two device flag words -> the context's pinned, device-mapped mirror (plain stores, as publish_flags_kernel does)
+__global__ void mirror_words_kernel(const uint32_t* __restrict__ dev, uint32_t* __restrict__ host, uint32_t w0, uint32_t w1) {
+    if (threadIdx.x == 0) host[w0] = dev[w0];
+    if (threadIdx.x == 1) host[w1] = dev[w1];
 }
 
 __global__ void iota_kernel(uint32_t* p, uint32_t n) {
@@ -883,7 +891,14 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                 if ((rc = c->reptheta.ensure((size_t)TOP2_MAX_NQ * 4))) return rc;
                 if ((rc = c->repkeys.ensure((size_t)TOP2_MAX_NQ * REPAIR_KEYS * 8))) return rc;
                 if ((rc = c->repn.ensure((size_t)TOP2_MAX_NQ * 4 + 16))) return rc;
-                a.cellb = c->cellb.as<float>();
+                if ((rc = c->repnew.ensure((size_t)TOP2_MAX_NQ * REPAIR_NEW_KEYS * 8))) return rc;
+                if (c->repcnt.bytes == 0) {   // scan -> merge hand-over words: zero when idle (the merge kernel clears what it read)
+                    if ((rc = c->repcnt.ensure((size_t)TOP2_MAX_NQ * 2 * 4))) return rc;
+                    HIPCHK(hipMemsetAsync(c->repcnt.p, 0, c->repcnt.bytes, s));
+                }
+                // (rows too long to stage even one beside the query row: the exact scan takes floor violations, as before round 6)
+                if ((size_t)2 * h->ld * h->esize + 16 > REPAIR_LDS_BYTES) c->repair = false;
+                a.cellb = c->repair ? c->cellb.as<float>() : nullptr;
                 c->t2_nsplit = a.nsplit;
                 c->t2_cnt = a.cnt;
                 c->t2_R = a.R;
@@ -1245,19 +1260,31 @@ int search_finish(cgv_index* h, SearchCtx* c) {
             ra.out_score = c->out_score;
             ra.fb_flag = c->fbflag.as<uint32_t>();
             ra.repaired = c->flags + F_MAXEPS;   // (a free word here: the flag words were published and cleared; read back below)
-            HIPCHK(hipMemsetAsync(c->flags + F_MAXEPS, 0, 4, s));
-            switch (h->dtype) {
-                case CGV_DTYPE_F32: hipLaunchKernelGGL(top2_repair_kernel<DT_F32>, dim3(nq), dim3(256), 0, s, ra); break;
-                case CGV_DTYPE_BF16: hipLaunchKernelGGL(top2_repair_kernel<DT_BF16>, dim3(nq), dim3(256), 0, s, ra); break;
-                case CGV_DTYPE_FP16: hipLaunchKernelGGL(top2_repair_kernel<DT_FP16>, dim3(nq), dim3(256), 0, s, ra); break;
-                default: hipLaunchKernelGGL(top2_repair_kernel<DT_FP8>, dim3(nq), dim3(256), 0, s, ra); break;
+            ra.newkeys = c->repnew.as<uint64_t>();
+            ra.nnew = c->repcnt.as<uint32_t>();
+            ra.bad = c->repcnt.as<uint32_t>() + TOP2_MAX_NQ_C;
+            {
+                const size_t rowb = (size_t)h->ld * h->esize, pitch = rowb + 16;
+                ra.rows_pp = (uint32_t)std::max<size_t>(1, std::min<size_t>(REPAIR_ROWS, (REPAIR_LDS_BYTES - rowb) / pitch));
+                ra.qoff = (uint32_t)(ra.rows_pp * pitch);
             }
+            const size_t rlds = (size_t)ra.qoff + (size_t)h->ld * h->esize;
+            HIPCHK(hipMemsetAsync(c->flags + F_MAXEPS, 0, 4, s));
+            const dim3 rgrid(nq, REPAIR_GRID);
+            switch (h->dtype) {
+                case CGV_DTYPE_F32: hipLaunchKernelGGL(top2_repair_scan_kernel<DT_F32>, rgrid, dim3(256), rlds, s, ra); break;
+                case CGV_DTYPE_BF16: hipLaunchKernelGGL(top2_repair_scan_kernel<DT_BF16>, rgrid, dim3(256), rlds, s, ra); break;
+                case CGV_DTYPE_FP16: hipLaunchKernelGGL(top2_repair_scan_kernel<DT_FP16>, rgrid, dim3(256), rlds, s, ra); break;
+                default: hipLaunchKernelGGL(top2_repair_scan_kernel<DT_FP8>, rgrid, dim3(256), rlds, s, ra); break;
+            }
+            hipLaunchKernelGGL(top2_repair_merge_kernel, dim3(nq), dim3(256), 0, s, ra);
             hipLaunchKernelGGL(compact_flags_kernel, dim3((nq + 255) / 256), dim3(256), 0, s,
                                c->fbflag.as<uint32_t>(), nq, c->qlist.as<uint32_t>(), c->flags + F_COMPACT);
+            // the two counters reach the pinned mirror by plain stores of a one-wave kernel (two copy-engine launches cost ~20 us)
+            hipLaunchKernelGGL(mirror_words_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)c->flags, c->h_flags_dev,
+                               (uint32_t)F_COMPACT, (uint32_t)F_MAXEPS);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(c->h_flags + F_COMPACT, c->flags + F_COMPACT, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(c->h_flags + F_MAXEPS, c->flags + F_MAXEPS, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            if (int wrc = wait_stream(s, h->spin_us)) return wrc;
             nscan = c->h_flags[F_COMPACT];
             nrepaired = c->h_flags[F_MAXEPS];
             if (nscan > 0) {

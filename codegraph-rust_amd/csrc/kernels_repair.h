@@ -12,8 +12,9 @@
 // cellb. A row that is neither a candidate nor in a cell with b > theta has coarse <= theta, hence exact <= theta + eps < e_k:
 // it cannot be in the top-k. So: the cells with b > theta (usually one: ~1000 rows) are scored with the reference's arithmetic
 // (8 lanes per row), rows that beat the current k-th key join the candidates' keys, and the top-k of the union is the exact
-// top-k - no second check needed (the k-th score can only rise). One workgroup per flagged query; anything unusual (too many
-// cells or keys, a NaN) leaves the query to the exact scan (flag 1), which is always right.
+// top-k - no second check needed (the k-th score can only rise). Two kernels: a scan over (query, REPAIR_GRID) workgroups that
+// stages the cells' rows through LDS, and a merge per query; anything unusual (too many cells or keys, a NaN) leaves the query
+// to the exact scan (flag 1), which is always right.
 #pragma once
 #include "common.h"
 #include "kernels_coarse.h"
@@ -23,6 +24,8 @@ namespace cgv {
 
 constexpr uint32_t REPAIR_MAX_CELLS = 48;    // offending cells per query at most (each ~ rows / 1024 rows to score)
 constexpr uint32_t REPAIR_NEW_KEYS = 192;    // rows of those cells that beat the current k-th key, at most
+constexpr uint32_t REPAIR_GRID = 64;         // workgroups per flagged query of the scan
+constexpr uint32_t REPAIR_ROWS = 32;         // rows staged in LDS per pass and workgroup (fewer when rows are long: rows_pp)
 
 struct Top2RepairArgs {
     const char* rows;        // the index' exact rows (f32 + shadow: the f32 rows)
@@ -38,87 +41,187 @@ struct Top2RepairArgs {
     float* out_score;
     uint32_t* fb_flag;       // 2 -> 0 (repaired) or 1 (left to the exact scan)
     uint32_t* repaired;      // counter (statistics)
+    // scan -> merge hand-over (zero when idle: the merge kernel clears what it read)
+    uint64_t* newkeys;       // [nq][REPAIR_NEW_KEYS] keys of re-scanned rows above the query's k-th key
+    uint32_t* nnew;          // [nq] how many (may exceed REPAIR_NEW_KEYS: then the exact scan takes the query)
+    uint32_t* bad;           // [nq] != 0: too many cells (value = count) or a NaN score (0xFFFFFFFF) - the exact scan takes the query
+    uint32_t rows_pp;        // rows staged per pass (host: what fits the LDS budget, <= REPAIR_ROWS)
+    uint32_t qoff;           // LDS offset of the query row (behind the staged rows)
 };
 
+// the query row -> LDS (linear element order), 256 threads
 template <int DT>
-__global__ __launch_bounds__(256) void top2_repair_kernel(const Top2RepairArgs a) {
-    __shared__ uint64_t keys[512];
-    __shared__ uint32_t cells[REPAIR_MAX_CELLS];
-    __shared__ uint32_t ncell_s, nnew_s, bad_s;
+__device__ inline void stage_query_row_plain(const char* qrows, uint32_t q, uint32_t ld, char* qs, int tid) {
+    const uint32_t pieces = ld * Elem<DT>::bytes / 16;
+    const Row<DT> qr = make_row<DT>(qrows, q, ld);
+    for (uint32_t pc = (uint32_t)tid; pc < pieces; pc += 256u) *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)piece_ptr<DT>(qr, pc);
+}
+
+// First kernel: grid (nq, REPAIR_GRID). The cells of a flagged query whose left-out score may reach its top-k are scored again with
+// the reference's arithmetic. A cell's ~1000 rows are scattered over its workgroup's tiles in groups of 4, so the scan is a
+// gather bound by memory latency: the first form (one workgroup per query, element-wise global reads, 32 rows per pass) took
+// 350-600 us for one or two cells - more than the exact scan it replaced (profiles/r06_repair_ab.txt). Here REPAIR_GRID workgroups
+// share a query's passes; a pass stages rows_pp rows in LDS with 16-byte loads issued together (one memory round trip, as
+// rescore_body does) and 8 lanes per row run the reference's chains out of LDS. Every workgroup derives the SAME cell list (cells
+// in index order: flags + prefix, no atomics), so the passes partition the rows exactly.
+template <int DT>
+__global__ __launch_bounds__(256) void top2_repair_scan_kernel(const Top2RepairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t cells[REPAIR_MAX_CELLS], cstart[REPAIR_MAX_CELLS + 1];
+    __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x;
     const uint32_t q = blockIdx.x;
     if (a.fb_flag[q] != 2u) return;   // uniform
     const float theta = a.theta[q];
-    const uint32_t nk = a.nkeys[q] < REPAIR_KEYS ? a.nkeys[q] : REPAIR_KEYS;
-    if (tid == 0) {
-        ncell_s = 0;
-        nnew_s = 0;
-        bad_s = 0;
-    }
-    for (uint32_t i = tid; i < 512; i += 256) keys[i] = i < nk ? a.keys[(uint64_t)q * REPAIR_KEYS + i] : 0ull;
-    __syncthreads();
-    const uint64_t kth = keys[a.k - 1];   // (nk >= k: final_kernel only flags 2 then) - a row enters the top-k only above this key
-    // (1) the cells whose left-out score may reach the top-k
+    const uint64_t kth = a.keys[(uint64_t)q * REPAIR_KEYS + (a.k - 1)];   // (nkeys >= k: final_kernel only flags 2 then)
+    stage_query_row_plain<DT>(a.qrows, q, a.ld, smem + a.qoff, tid);
+    // (1) the offending cells, in index order: thread t owns cells 4t .. 4t + 3 (4 * nsplit <= 1024)
     const uint32_t ncells = 4u * a.nsplit;
-    for (uint32_t c = tid; c < ncells; c += 256)
-        if (a.cellb[(uint64_t)c * 64u + q] > theta) {
-            const uint32_t p = atomicAdd(&ncell_s, 1u);
-            if (p < REPAIR_MAX_CELLS) cells[p] = c;
+    uint32_t mine = 0, flags = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t c = (uint32_t)tid * 4u + j;
+        if (c < ncells && a.cellb[(uint64_t)c * 64u + q] > theta) {
+            flags |= 1u << j;
+            ++mine;
         }
+    }
+    uint32_t incl = mine;   // inclusive prefix over the wave, then over the 4 waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
-    const uint32_t ncell = ncell_s;
+    uint32_t base = 0, ncell = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < (tid >> 6)) base += wsum[w];
+        ncell += wsum[w];
+    }
     if (ncell > REPAIR_MAX_CELLS) {   // uniform: a heavily clustered neighbourhood - the exact scan takes it
-        if (tid == 0) a.fb_flag[q] = 1u | (1u << 8) | (ncell << 16);   // (non-zero = exact scan; the upper bits say why - diagnostics)
+        if (blockIdx.y == 0 && tid == 0) a.bad[q] = ncell;
         return;
     }
-    // (2) their rows, with the reference's arithmetic: 8 lanes per row, 32 rows per pass
-    const Row<DT> qr = make_row<DT>(a.qrows, q, a.ld);
-    const int grp = tid >> 3, l = tid & 7;
-    for (uint32_t ci = 0; ci < ncell; ++ci) {
-        const uint32_t c = cells[ci], g = c >> 2, wm = (c >> 1) & 1u, half = c & 1u;
-        const uint32_t jlo = (uint32_t)(((uint64_t)g * a.cnt) / a.nsplit), jhi = (uint32_t)(((uint64_t)(g + 1) * a.cnt) / a.nsplit);
-        const uint32_t items = (jhi - jlo) * 64u;   // 64 rows of the cell per tile
-        for (uint32_t i0 = 0; i0 < items; i0 += 32u) {
-            const uint32_t it = i0 + (uint32_t)grp;
-            if (it < items) {   // uniform within the 8-lane group
-                const uint32_t tile = stage_tile(0u, a.R, a.P, jlo + it / 64u), i = it % 64u, mb = i >> 4, r = i & 15u;
+    uint32_t pos = base + incl - mine;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (flags & (1u << j)) cells[pos++] = (uint32_t)tid * 4u + j;
+    __syncthreads();
+    if (tid == 0) {   // rows per cell: 64 per tile of its workgroup's walk
+        uint32_t run = 0;
+        for (uint32_t ci = 0; ci < ncell; ++ci) {
+            const uint32_t g = cells[ci] >> 2;
+            const uint32_t jlo = (uint32_t)(((uint64_t)g * a.cnt) / a.nsplit), jhi = (uint32_t)(((uint64_t)(g + 1) * a.cnt) / a.nsplit);
+            cstart[ci] = run;
+            run += (jhi - jlo) * 64u;
+        }
+        cstart[ncell] = run;
+    }
+    __syncthreads();
+    const uint32_t total = cstart[ncell], rpp = a.rows_pp;
+    const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16u, pieces = rowb / 16u;
+    const uint32_t passes = (total + rpp - 1u) / rpp;
+    __shared__ uint32_t prow[REPAIR_ROWS];   // corpus row of each staged slot (0xFFFFFFFF: none)
+    for (uint32_t ps = blockIdx.y; ps < passes; ps += gridDim.y) {
+        __syncthreads();   // (the previous pass' LDS reads are done)
+        if ((uint32_t)tid < rpp) {
+            const uint32_t it = ps * rpp + (uint32_t)tid;
+            uint32_t row = 0xFFFFFFFFu;
+            if (it < total) {
+                uint32_t ci = 0;
+                while (ci + 1u < ncell && cstart[ci + 1u] <= it) ++ci;
+                const uint32_t c = cells[ci], g = c >> 2, wm = (c >> 1) & 1u, half = c & 1u, li = it - cstart[ci];
+                const uint32_t jlo = (uint32_t)(((uint64_t)g * a.cnt) / a.nsplit);
+                const uint32_t tile = stage_tile(0u, a.R, a.P, jlo + li / 64u), i = li % 64u, mb = i >> 4, r = i & 15u;
                 // MFMA C layout (kernels_coarse.h): register r of block mb = row (r & 3) + 8 (r >> 2) + 4 * lane half of the block
-                const uint64_t row = (uint64_t)tile * 256u + wm * 128u + mb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
-                if (row < a.n) {
-                    const float s = exact_score_group8((int)a.metric, qr, make_row<DT>(a.rows, row, a.ld), a.D, l);
-                    if (l == 0) {
-                        if (s != s) bad_s = 1u;
-                        const uint64_t key = make_key(s, (uint32_t)row);
-                        if (key > kth) {
-                            const uint32_t p = atomicAdd(&nnew_s, 1u);
-                            if (p < REPAIR_NEW_KEYS) keys[REPAIR_KEYS + p] = key;
-                        }
-                    }
+                const uint64_t rw = (uint64_t)tile * 256u + wm * 128u + mb * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+                if (rw < a.n) row = (uint32_t)rw;
+            }
+            prow[tid] = row;
+        }
+        __syncthreads();
+        // gather: all 16-byte pieces of the pass, up to 8 independent loads per thread in flight before the first LDS store
+        const uint32_t nload = rpp * pieces;
+        for (uint32_t i0 = (uint32_t)tid; i0 < nload; i0 += 256u * 8u) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                if (i < nload) {
+                    const uint32_t slot = i / pieces, pc = i - slot * pieces, row = prow[slot];
+                    if (row != 0xFFFFFFFFu) v[u] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                if (i < nload) {
+                    const uint32_t slot = i / pieces, pc = i - slot * pieces;
+                    if (prow[slot] != 0xFFFFFFFFu) *(uint4*)(smem + (size_t)slot * pitch + (size_t)pc * 16u) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const LdsRow<DT> ql{smem + a.qoff};
+        const uint32_t slot = (uint32_t)tid >> 3;
+        if (slot < rpp && prow[slot] != 0xFFFFFFFFu) {   // uniform within the 8-lane group
+            const LdsRow<DT> cl{smem + (size_t)slot * pitch};
+            const float s = exact_score_group8((int)a.metric, ql, cl, a.D, tid & 7);
+            if ((tid & 7) == 0) {
+                if (s != s) a.bad[q] = 0xFFFFFFFFu;
+                const uint64_t key = make_key(s, prow[slot]);
+                if (key > kth) {
+                    const uint32_t p = atomicAdd(a.nnew + q, 1u);
+                    if (p < REPAIR_NEW_KEYS) a.newkeys[(uint64_t)q * REPAIR_NEW_KEYS + p] = key;
                 }
             }
         }
     }
-    __syncthreads();
-    if (bad_s != 0u || nnew_s > REPAIR_NEW_KEYS) {   // uniform
-        if (tid == 0) a.fb_flag[q] = 1u | ((bad_s != 0u ? 2u : 3u) << 8) | (nnew_s << 16);
+}
+
+// Second kernel: one workgroup per flagged query - the top-k of (re-scored candidates + the rows the scan found above the k-th
+// key) is the exact top-k: no second check needed, the k-th score can only rise. Anything unusual leaves the query to the exact
+// scan (flag 1), which is always right. Clears the hand-over words it read.
+__global__ __launch_bounds__(256) void top2_repair_merge_kernel(const Top2RepairArgs a) {
+    __shared__ uint64_t keys[512];
+    __shared__ uint32_t pos[512];
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (a.fb_flag[q] != 2u) return;   // uniform
+    const uint32_t nk = a.nkeys[q] < REPAIR_KEYS ? a.nkeys[q] : REPAIR_KEYS;
+    const uint32_t nnew = a.nnew[q], bad = a.bad[q];
+    __syncthreads();   // (every thread has read the hand-over words)
+    if (tid == 0) {
+        a.nnew[q] = 0u;
+        a.bad[q] = 0u;
+    }
+    if (bad != 0u || nnew > REPAIR_NEW_KEYS) {   // uniform (upper bits of the flag word: why - diagnostics)
+        if (tid == 0) a.fb_flag[q] = 1u | ((bad == 0xFFFFFFFFu ? 2u : (bad != 0u ? 1u : 3u)) << 8) | ((bad != 0u && bad != 0xFFFFFFFFu ? bad : nnew) << 16);
         return;
     }
-    // (3) top-k of the union. A re-scanned row that was a re-scored candidate already has the identical key (same arithmetic on
-    // the same values): sorted, the two copies are neighbours - the second one is dropped.
-    bitonic_sort_desc<256>(keys, 512u, tid);
-    __shared__ uint32_t pos[512];
-    for (uint32_t i = tid; i < 512; i += 256) pos[i] = (keys[i] != 0ull && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+    // (dense: the usual case is k' re-scored keys + a handful of new ones - 32 or 64 keys to sort, not 512)
+    const uint32_t P = next_pow2(nk + nnew < 2u ? 2u : nk + nnew);   // <= 64 + 192 = 256
+    for (uint32_t i = tid; i < P; i += 256)
+        keys[i] = i < nk ? a.keys[(uint64_t)q * REPAIR_KEYS + i]
+                         : (i - nk < nnew ? a.newkeys[(uint64_t)q * REPAIR_NEW_KEYS + (i - nk)] : 0ull);
     __syncthreads();
-    if (tid == 0) {   // 512 flags: a serial prefix is a few hundred cycles on the rare path
+    // A re-scanned row that was a re-scored candidate already has the identical key (same arithmetic on the same values): sorted,
+    // the two copies are neighbours - the second one is dropped.
+    bitonic_sort_desc<256>(keys, P, tid);
+    for (uint32_t i = tid; i < P; i += 256) pos[i] = (keys[i] != 0ull && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+    __syncthreads();
+    if (tid == 0) {   // <= 256 flags: a serial prefix is a few hundred cycles on the rare path
         uint32_t run = 0;
-        for (uint32_t i = 0; i < 512; ++i) {
+        for (uint32_t i = 0; i < P; ++i) {
             const uint32_t f = pos[i];
             pos[i] = f ? run : 0xFFFFFFFFu;
             run += f;
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < 512; i += 256) {
+    for (uint32_t i = tid; i < P; i += 256) {
         const uint32_t j = pos[i];
         if (j < a.k) {
             a.out_idx[(uint64_t)q * a.k + j] = map_id(a.idmap, key_row(keys[i]));

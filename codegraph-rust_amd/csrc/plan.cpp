@@ -201,7 +201,7 @@ float plan_ladder_scale(double S_rows, double N_rows, uint32_t kprime, uint32_t 
 
 // allow_emit (round 6): the sample launch may emit its own candidates (kernels_coarse.h, SAMPLE mode of tile_epilogue), so that the
 // emitting launches start BEHIND it in the visiting order instead of scoring its tiles again: 64 of C2's 3907 tiles, 64 of the
-// 489 of its 8-GPU shard. Taken when the corpus is at least twice the sample (else the old form: the launches cover everything).
+// 489 of its 8-GPU shard. Taken when the corpus is at least four times the sample (else the old form: the launches cover everything).
 StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, uint32_t nsplit_max, int force_m, bool allow_emit) {
     const Tunables& t = tun();
     StagePlan p;
@@ -220,7 +220,10 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, 
     p.T1 = 0;
     p.R = p.ntiles;
     p.P = golden_stride(p.R);
-    p.sample_emits = allow_emit && t.sample_emit != 0 && kprime <= 64 && p.ntiles >= 2 * S;
+    // (>= 4 S tiles: three of a query's top-(k + 1) rows in one 64-row cell of the sample send it to the exact scan, with
+    // probability C(k + 1, 3) (S / R)^3 / 256^2 per query - 3e-4 at R = 2 S, i.e. an exact scan in every third 1024-query batch,
+    // which eats the tile-time the emitting sample saves; 4e-5 at 4 S, 6e-6 on C2's 8-GPU shard, 1e-8 on C2)
+    p.sample_emits = allow_emit && t.sample_emit != 0 && kprime <= 64 && p.ntiles >= 4 * S;
     const uint32_t emit_tiles = p.sample_emits ? p.ntiles - S : p.ntiles;   // tiles the emitting launches cover
     const double seen0 = (double)S * BM, total = (double)emit_tiles * BM;
     const double kappa = (double)nqt * kprime * 4.0 * hit_us / (double)std::max<uint32_t>(n_cu, 1u);

@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): top-k row ids bit-exact under (score desc, id asc);
 scores bit-exact too, because the re-score kernel reproduces the reference's f32 lane
 order (tolerance stated where it is not zero)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -685,3 +687,102 @@ def test_many_queries_more_query_tiles_than_corpus_splits(oracle):
     (k' = 40), dot metric on un-normalised rows."""
     st = _run(oracle, n=12_000, d=96, nq=2100, k=30, dtype="bf16", metric="dot", seed=77, unit=False)
     assert st["last_path"] == 1 and st["fallback_queries"] <= 5
+
+
+def _golden_stride(R):
+    """csrc/plan.cpp golden_stride: P ~ 0.618 R, coprime to R (the visiting order of the corpus tiles is j * P mod R)."""
+    from math import gcd
+    if R <= 2:
+        return 1
+    P = max(1, int(R * 0.6180339887498949))
+    while gcd(P, R) != 1:
+        P += 1
+    return P
+
+
+@pytest.mark.parametrize("dtype,odt", [("bf16", 1), ("fp8", 3)])
+def test_emitting_sample_floor_sends_a_crowded_cell_to_the_exact_scan(oracle, dtype, odt):
+    """Round 6: the sample launch emits - per query and CELL of a sampled tile ((tile, 128-row half, rows with row % 8 < 4 or
+    >= 4): 64 rows) its two best rows, and the best score it left out goes to the query's floor. Three near-copies of a query
+    in ONE cell of a sampled tile leave the third out: the floor rises above the k-th exact score, the check fails and the query -
+    only that one - is answered by the exact scan; two in a cell are both kept; three in a cell of a tile the sample does not
+    visit are emitted by the ordinary threshold path. Every answer is the oracle's."""
+    m = pkg()
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 80_000, 64, 1024, 10                       # 313 tiles, 4 query tiles -> the sample takes 64 tiles, the plan emits (>= 4 S)
+    R = (n + 255) // 256
+    P = _golden_stride(R)
+    order = [(j * P) % R for j in range(R)]
+    t_in, t_in2, t_out = order[1], order[40], order[100]      # two sampled tiles (positions < 64) and one the sample never sees
+    rows = _unit(rng, n, d)
+    q = _unit(rng, nq, d)
+
+    def plant(tile, qi, offsets):
+        for j, off in enumerate(offsets):
+            v = q[qi] + 0.02 * (j + 1) * _unit(rng, 1, d)[0]
+            rows[tile * 256 + off] = v / np.linalg.norm(v)
+    plant(t_in, 5, (0, 1, 2))             # three in one cell of a sampled tile (rows 0..2: first half, row % 8 < 4) -> floor violation
+    plant(t_in2, 300, (130, 131))         # two in one cell: both kept
+    plant(t_in2, 301, (0, 4, 128))        # three in three different cells of one sampled tile: all kept
+    plant(t_out, 700, (8, 9, 10))         # three in one cell of a tile behind the sample: the threshold path emits them
+    ix = m.HipKnnIndex(d, dtype=dtype)
+    try:
+        ix.add(rows)
+        assert m.cgvec.lib().cgv_debug_last_top2_(ix._h) == 0
+        f0 = ix.stats()["fallback_queries"]
+        gi, gs = ix.search(q, k)
+        ri, rs = oracle.batch_top_k(q, rows, k, dtype=odt)
+        assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+        st = ix.stats()
+        assert st["last_path"] == 1
+        # query 5 took the exact scan; the planted neighbours did not. (A random query may too: three of its top-16 in one cell of
+        # the sample - 2e-5 per query on a corpus this small - so the batch's count is 1, very rarely 2.)
+        fl = (C.c_uint32 * nq)()
+        L = m.cgvec.lib()
+        L.cgv_debug_fbflags_.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
+        assert L.cgv_debug_fbflags_(ix._h, 0, fl, nq) == 0
+        assert fl[5] != 0 and fl[300] == 0 and fl[301] == 0 and fl[700] == 0, [i for i in range(nq) if fl[i]]
+        assert 1 <= st["fallback_queries"] - f0 <= 2, st
+        assert set(gi[5][:3].tolist()) == {t_in * 256, t_in * 256 + 1, t_in * 256 + 2}
+        assert set(gi[700][:3].tolist()) == {t_out * 256 + 8, t_out * 256 + 9, t_out * 256 + 10}
+        # the same batch again (floor words, scand and lists are reused), and without the planted triple: no fallback at all
+        gi2, gs2 = ix.search(q, k)
+        assert np.array_equal(gi2, ri) and np.array_equal(gs2, rs)
+        q2 = q.copy()
+        q2[5] = _unit(rng, 1, d)[0]
+        f1 = ix.stats()["fallback_queries"]
+        gi3, gs3 = ix.search(q2, k)
+        r3 = oracle.batch_top_k(q2, rows, k, dtype=odt)
+        assert np.array_equal(gi3, r3[0]) and np.array_equal(gs3, r3[1])
+        assert ix.stats()["fallback_queries"] - f1 <= 1
+    finally:
+        ix.close()
+
+
+def test_phase_times_of_the_mfma_pipeline(oracle):
+    """cgv_set_profiling(3) + cgv_get_phase_times: HIP events at the phase boundaries of the MFMA pipeline, on the stream the batch
+    runs on - conversion | first threshold | emitting launches | final + publish. What bench.py's N > 1 line prints per rank."""
+    m = pkg()
+    rng = np.random.default_rng(3)
+    n, d = 60_000, 128
+    rows, q = _unit(rng, n, d), _unit(rng, 512, d)
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        ix.search(q, 10)
+        assert all(v == 0.0 for v in ix.phase_times_us().values())            # profiling off: zeros
+        ix.set_profiling(3)
+        for nq in (512, 8):                                                    # staged thresholds; one COARSE_TOP2 launch
+            ix.search(q[:nq], 10)                                              # (first use of a path allocates its scratch: host time inside the span)
+            gi, gs = ix.search(q[:nq], 10)
+            ri, rs = oracle.batch_top_k(q[:nq], rows, 10, dtype=1)
+            assert np.array_equal(gi, ri) and np.array_equal(gs, rs)
+            ph, st = ix.phase_times_us(), ix.stats()
+            assert ph["prep"] > 0 and ph["emitting"] > 0 and ph["final_publish"] > 0, ph
+            assert (ph["first_threshold"] > 15.0) == (nq > 64), ph             # (a small batch has no threshold phase: two adjacent events)
+            assert abs(sum(ph.values()) - 1e3 * st["last_total_ms"]) < 0.05 * 1e3 * st["last_total_ms"] + 5.0, (ph, st["last_total_ms"])
+        ix.set_force_exact(True)
+        ix.search(q[:4], 10)
+        assert all(v == 0.0 for v in ix.phase_times_us().values())            # exact scan: no MFMA phases
+    finally:
+        ix.close()

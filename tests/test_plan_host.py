@@ -35,7 +35,7 @@ def test_plan_covers_every_tile_once(n, k, nq, shadow):
     # round 6: a sample that emits its own candidates is not scored again - the launches cover the tiles behind it
     assert all(c > 0 for c in counts) and sum(counts) + (sample if emits else 0) == ntiles
     kprime = min((4 * k + 16 + 7) // 8 * 8, 256) if shadow else (k + max(6, k // 8) + 7) // 8 * 8
-    assert emits == (nq > 64 and kprime <= 64 and ntiles >= 2 * sample and counts[0] >= min(sample, max(1, 256 // ((nq + 255) // 256))))
+    assert emits == (nq > 64 and kprime <= 64 and ntiles >= 4 * sample and counts[0] >= min(sample, max(1, 256 // ((nq + 255) // 256))))
     if emits:
         assert min(counts[0], max(1, 256 // ((nq + 255) // 256))) >= sample    # the first launch continues every sampled tile's lists
     assert len(counts) <= 8
