@@ -94,7 +94,7 @@ class Coalescer {
     std::atomic<uint32_t> max_batch_q{64};  // one COARSE_TOP2 launch holds 64 query columns
     int max_leaders = 1;                    // batches on the device at once (CGV_COALESCE_BATCHES_IN_FLIGHT)
     uint32_t window_us = 250, gap_us = 0;    // CGV_COALESCE_WINDOW_US; gap_us == 0: a third of the window
-    size_t max_q_bytes = 0, max_out_bytes = 0;   // pinned staging area of a search context (cgvec.hip: SearchCtx::h_stage); set once
+    size_t max_q_bytes = 0, max_out_bytes = 0;   // pinned staging area of a search context (cgvec_internal.h: SearchCtx::h_stage); set once
 
     bool eligible(uint32_t nq, uint32_t k, uint32_t dim) const {
         return enabled.load(std::memory_order_relaxed) && nq >= 1 && nq <= max_req_nq.load(std::memory_order_relaxed) &&

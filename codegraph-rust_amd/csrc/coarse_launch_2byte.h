@@ -72,7 +72,7 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
             hipLaunchKernelGGL((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 0>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (top-2 cells)");
     }
-    if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (cgvec.hip: can_fuse)
+    if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (search.hip: can_fuse)
 #ifdef CGV_ABLATE_BUILD
         if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.tau_out && a.dump && a.cnt >= 2 * a.nsplit))
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT launched on a shape it does not serve");

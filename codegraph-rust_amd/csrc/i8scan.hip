@@ -22,7 +22,7 @@
 #include "../../include/cgvec.h"
 #include "../../include/cgvec_i8.h"
 
-extern "C" int cgv_set_error_(int code, const char* msg);  // cgvec.hip (shared thread-local message)
+extern "C" int cgv_set_error_(int code, const char* msg);  // abi.hip (shared thread-local message)
 
 namespace {
 

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const char* __restric
 template <int DT>
 // qsel == NULL: the dense [nq][m] form (pair p belongs to query p / m); else a PAIR LIST: pair p = (query qsel[p], ids[p]) -
 // what one shard of a cgv_sharded handle scores (only the pairs whose rows it owns, sharded.hip).
-__global__ __launch_bounds__(256) void score_ids_kernel(const char* __restrict__ rows, const float* __restrict__ queries,
+static __global__ __launch_bounds__(256) void score_ids_kernel(const char* __restrict__ rows, const float* __restrict__ queries,
                                                         const uint64_t* __restrict__ ids, const uint32_t* __restrict__ qsel,
                                                         uint64_t npairs, uint32_t m,
                                                         uint64_t n, uint32_t D, uint32_t ld, int op,
@@ -61,7 +61,7 @@ constexpr uint32_t TOPK_CHUNK = 4096;
 
 // Level-0: chunk of f32 scores -> sorted top-K keys. Level>0: chunk of keys -> top-K keys.
 // grid = (nchunks, nql). out[qi][chunk][K].
-__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ scores,
+static __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ scores,
                                                          const uint64_t* __restrict__ in_keys,
                                                          uint32_t M, uint32_t K,
                                                          uint64_t* __restrict__ out,
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
 }
 
 // Final keys [nql][K] -> caller's out arrays at query slot qlist[qi] (or qi).
-__global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, uint32_t k,
+static __global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, uint32_t k,
                                  const uint32_t* __restrict__ qlist, uint32_t nql,
                                  IdMap idmap, uint64_t* __restrict__ out_idx,
                                  float* __restrict__ out_score) {
@@ -112,7 +112,7 @@ __global__ void emit_topk_kernel(const uint64_t* __restrict__ keys, uint32_t K, 
 // normalize_avx2 (simd_ops.rs:189-222) / parallel_normalize_vectors (:386-419), in place on a
 // flat f32 [n][dim] matrix: nsq = dot_product_avx2(v, v) (8 lane chains + h-sum + tail), zero
 // vectors untouched, every element MULTIPLIED by 1/sqrt(nsq). 8 lanes per row.
-__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
+static __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
     const int l = threadIdx.x & 7;
     const uint64_t row = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (row >= n) return;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__
 // happens unless norm_squared > 0.0 (a NaN sum leaves the row alone), then every element is DIVIDED by sqrt(norm_squared) - the
 // AVX2 arm multiplies by the reciprocal, which rounds differently. One lane owns a row's sum (the order is the contract); a
 // wave stages 64 rows x 64 columns through LDS so that global reads stay coalesced (row pitch 65 words: conflict-free walks).
-__global__ __launch_bounds__(256) void normalize_rows_scalar_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
+static __global__ __launch_bounds__(256) void normalize_rows_scalar_kernel(float* __restrict__ rows, uint64_t n, uint32_t dim) {
     __shared__ float tile[4][64][65];
     __shared__ float nrm[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void normalize_rows_scalar_kernel(float* __res
 }
 
 // Compact the flagged query ids: qlist[0..count) (order irrelevant).
-__global__ void compact_flags_kernel(const uint32_t* __restrict__ flag, uint32_t nq,
+static __global__ void compact_flags_kernel(const uint32_t* __restrict__ flag, uint32_t nq,
                                      uint32_t* __restrict__ qlist, uint32_t* __restrict__ count) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nq && flag[q]) qlist[atomicAdd(count, 1u)] = q;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
 // which bound how far a coarse score can be from the exact f32 score (kernels_select.h). Per-row values
 // go to res[2*row..] when res != NULL (queries); the maxima over all rows are folded into
 // res_max[0] (rel) and res_max[1] (abs) as non-negative float bits (corpus).
-__global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restrict__ in, uint64_t n, uint32_t D,
+static __global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restrict__ in, uint64_t n, uint32_t D,
                                                           uint32_t lds, uint64_t row0, char* __restrict__ out,
                                                           float* __restrict__ norm, float* __restrict__ invn,
                                                           float* __restrict__ res, uint32_t* __restrict__ res_max) {
@@ -217,7 +217,7 @@ __global__ void gather_row_kernel(const char* __restrict__ rows, uint64_t R, uin
 
 // Per aligned 32-row block: min and max row norm over the valid rows (used by the
 // conservative fast filter of the coarse kernel's epilogue).
-__global__ __launch_bounds__(256) void block_norm_stats_kernel(const float* __restrict__ norm,
+static __global__ __launch_bounds__(256) void block_norm_stats_kernel(const float* __restrict__ norm,
                                                                uint64_t n, uint64_t blk0,
                                                                uint64_t blk1,
                                                                float* __restrict__ blk_min,
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void block_norm_stats_kernel(const float* __re
 }
 
 // max over all rows of norm (dot-product error bound); single block, grid-stride.
-__global__ __launch_bounds__(1024) void max_norm_kernel(const float* __restrict__ norm, uint64_t n0,
+static __global__ __launch_bounds__(1024) void max_norm_kernel(const float* __restrict__ norm, uint64_t n0,
                                                         uint64_t n1, float* __restrict__ out_max) {
     __shared__ float red[16];
     float m = 0.0f;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void max_norm_kernel(const float* __restrict_
 
 // COARSE_TOP2 with more than 16 queries: the spread copy of the (single) query tile - query j's 64-byte row chunks go to row
 // top2_col_of(j) of `dst` (same blocked layout, kc_count blocks of 16 KiB). One thread per 16-byte piece.
-__global__ void top2_spread_queries_kernel(const char* __restrict__ src, char* __restrict__ dst, uint32_t nq, uint32_t kc_count) {
+static __global__ void top2_spread_queries_kernel(const char* __restrict__ src, char* __restrict__ dst, uint32_t nq, uint32_t kc_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * kc_count * 4u) return;
     const uint32_t j = i / (kc_count * 4u), rem = i % (kc_count * 4u), kc = rem >> 2, pc = rem & 3u;
@@ -263,7 +263,7 @@ __global__ void top2_spread_queries_kernel(const char* __restrict__ src, char* _
     *(uint4*)(dst + (uint64_t)kc * BLOCK_BYTES + (uint64_t)top2_col_of(j) * CHUNK_BYTES + pc * 16u) = v;
 }
 
-__global__ void fill_f32_kernel(float* p, float v, uint32_t n) {
+static __global__ void fill_f32_kernel(float* p, float v, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }

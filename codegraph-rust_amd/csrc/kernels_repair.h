@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void top2_repair_scan_kernel(const Top2RepairA
 // Second kernel: one workgroup per flagged query - the top-k of (re-scored candidates + the rows the scan found above the k-th
 // key) is the exact top-k: no second check needed, the k-th score can only rise. Anything unusual leaves the query to the exact
 // scan (flag 1), which is always right. Clears the hand-over words it read.
-__global__ __launch_bounds__(256) void top2_repair_merge_kernel(const Top2RepairArgs a) {
+static __global__ __launch_bounds__(256) void top2_repair_merge_kernel(const Top2RepairArgs a) {
     __shared__ uint64_t keys[512];
     __shared__ uint32_t pos[512];
     const int tid = threadIdx.x;

@@ -259,7 +259,7 @@ __device__ inline void extract_topk(uint64_t* keys, uint32_t M, uint32_t keep, u
 // sorts its <= 16 keys in registers, K rounds of wave maximum, a 4-way merge) - the same keys, the same total order (keys are
 // unique), ~3x shorter on the latency-bound single-query path (BASELINE config 1: 10k x 384 f32, one query per call).
 // Level 0: chunk of f32 scores -> top-K keys; level > 0: chunk of keys -> top-K keys. grid = (nchunks, nql), out[qi][chunk][K].
-__global__ __launch_bounds__(256) void topk_chunk_small_kernel(const float* __restrict__ scores, const uint64_t* __restrict__ in_keys,
+static __global__ __launch_bounds__(256) void topk_chunk_small_kernel(const float* __restrict__ scores, const uint64_t* __restrict__ in_keys,
                                                                uint32_t M, uint32_t K, uint64_t* __restrict__ out,
                                                                uint32_t* __restrict__ nan_flag) {
     __shared__ uint64_t part[4 * 64];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void topk_chunk_small_kernel(const float* __re
 // sub-lists written by the last coarse launch (or with the dense boot scores), keep the
 // top-k', publish tau[q] = the k'-th best coarse score seen so far (a valid lower bound of
 // the final k'-th best). k' <= 64: register-resident extraction; larger k': LDS bitonic sort.
-__global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
+static __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* keys = (uint64_t*)smem;                            // [lds_keys]
     uint32_t* pre = (uint32_t*)(smem + (size_t)a.lds_keys * 8);  // [nsplit + 1]
@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a) {
 // k' rounds of wave maximum + pop. Also clears nbest / overflow of the query (the launches that follow append).
 // Threshold ladder (kernels_coarse.h): also the query's {tau0, delta} and a cleared counter word. delta = lad_scale x (value at
 // rank hi_rank of the sample's maxima - tau0): the sample's own spread between two of its order statistics, scaled by the host
-// to a quarter of 1.25 x the distance at which the final k'-th best is expected under a normal tail (plan_ladder_scale, cgvec.hip)
+// to a quarter of 1.25 x the distance at which the final k'-th best is expected under a normal tail (plan_ladder_scale, plan.cpp)
 // - only the tightness of the thresholds depends on that guess, never their validity. Spread 0 / no sample: delta 0, no ladder.
 // Emitting sample (round 6, tile_epilogue's SAMPLE mode): dense[q][M .. M + floor_n) holds, per cell of the sample, the best coarse
 // score the cell left out of the candidate lists; their maximum is the query's floor word (f2ord; 0 = nothing left out), which
 // the final kernel folds into the threshold of its guarantee check.
-__global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
+static __global__ __launch_bounds__(256) void tau_kernel(const float* __restrict__ dense, uint32_t M, uint32_t ld, uint32_t nq,
                                                   uint32_t kprime, float* __restrict__ tau, uint32_t* __restrict__ nbest,
                                                   float4* __restrict__ ladc = nullptr, unsigned long long* __restrict__ lad = nullptr,
                                                   float lad_scale = 0.0f, uint32_t hi_rank = 0, uint32_t floor_n = 0,
@@ -442,7 +442,7 @@ constexpr uint32_t REPAIR_KEYS = 64;
 // the last kernel instead - 1024 returning atomics on one word - cost 25 us: r03b.)
 // qstat (optional): the per-query {max observed error, eps} words of the final kernel ([nq]; RescoreArgs::qstat): their maxima
 // are folded into flag words err_word / eps_word here (both are bit patterns of non-negative floats: unsigned order = float order).
-__global__ void publish_flags_kernel(uint32_t* __restrict__ flags, uint32_t* __restrict__ host, uint32_t n_flags,
+static __global__ void publish_flags_kernel(uint32_t* __restrict__ flags, uint32_t* __restrict__ host, uint32_t n_flags,
                                      uint32_t done_word, uint32_t marker, uint32_t* __restrict__ extra = nullptr,
                                      uint32_t n_extra = 0u, const uint2* __restrict__ qstat = nullptr, uint32_t nq = 0u,
                                      uint32_t err_word = 0u, uint32_t eps_word = 0u) {
@@ -773,7 +773,7 @@ constexpr uint64_t PROVISIONAL_ID = 0xFFFFFFFFFFFFFFFEull;  // == CGV_PROVISIONA
 // like a G-way merge - lane g holds the head of list g, a round is a wave maximum of the ordered scores, then the smallest
 // id among the lanes that hold it, and the winner advances. k dependent rounds: slow (k = 2048: a few ms per batch), but
 // any k up to CGV_MAX_K on any number of shards is served (the LDS merge alone rejected n_shards * k > 4096).
-__global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
+static __global__ __launch_bounds__(256) void merge_topk_wave_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
                                                               const char* __restrict__ score_base, uint64_t score_stride,
                                                               uint32_t G, uint32_t nq, uint32_t k,
                                                               uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
@@ -833,7 +833,7 @@ __host__ __device__ inline uint32_t packed_width(uint32_t k) { return 3u * k + (
 // (prov[q] != 0: it will be re-run through the exact scan once the host looks at the flags) - or every query when
 // prov_all is set (an exact-scan-only index) - is packed with id slot 0 = PROVISIONAL_ID. The merge kernels raise their redo
 // word when they meet one: every rank merges the same gathered records, so all ranks learn it without another collective.
-__global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ score, uint32_t nq,
+static __global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ score, uint32_t nq,
                                  uint32_t k, uint32_t* __restrict__ out, const uint32_t* __restrict__ prov = nullptr,
                                  uint32_t prov_all = 0u) {
     const uint32_t w = packed_width(k);
@@ -856,7 +856,7 @@ __global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* 
 // SURVEY.md §8(e)). Input [g][nq][k]; one workgroup per query; G*k <= 4096.
 // (rank g, query q) lists are addressed as base + (g*nq + q) * stride bytes, so the same kernel reads
 // separate [g][nq][k] id / score arrays or the packed records of the all-gather (pack_topk_kernel).
-__global__ __launch_bounds__(256) void merge_topk_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
+static __global__ __launch_bounds__(256) void merge_topk_kernel(const char* __restrict__ idx_base, uint64_t idx_stride,
                                                          const char* __restrict__ score_base,
                                                          uint64_t score_stride, uint32_t G, uint32_t nq,
                                                          uint32_t k, uint64_t* __restrict__ out_idx,

@@ -42,9 +42,9 @@
 
 #include "../../include/cgvec.h"
 
-extern "C" int cgv_set_error_(int code, const char* msg);  // cgvec.hip: the library's thread-local error message
+extern "C" int cgv_set_error_(int code, const char* msg);  // abi.hip: the library's thread-local error message
 extern "C" int cgv_score_pairs_f32_(cgv_index* h, const float* queries_host, uint32_t nq, int op, const uint32_t* qsel_host,
-                                    const uint64_t* ids_host, uint64_t npairs, float* out_host);  // cgvec.hip
+                                    const uint64_t* ids_host, uint64_t npairs, float* out_host);  // abi.hip
 
 namespace {
 

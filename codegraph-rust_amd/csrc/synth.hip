@@ -18,7 +18,7 @@
 
 #include "../../include/cgvec.h"
 
-extern "C" int cgv_set_error_(int code, const char* msg);  // cgvec.hip
+extern "C" int cgv_set_error_(int code, const char* msg);  // abi.hip
 
 namespace {
 

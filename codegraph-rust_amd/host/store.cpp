@@ -23,7 +23,7 @@
 #include "../../include/cgvec.h"
 #include "../../include/cgvec_store.h"
 
-extern "C" int cgv_set_error_(int code, const char* msg);  // defined in cgvec.hip (shared thread-local message)
+extern "C" int cgv_set_error_(int code, const char* msg);  // defined in abi.hip (shared thread-local message)
 
 namespace {
 

@@ -249,7 +249,7 @@ class ShardedKnn:
     def _wait(event, spin_s=0.005):
         """The batch's ONE host synchronisation: poll its event for a few milliseconds before blocking - a batch takes 0.3-1.5
         ms, and the wake-up of a blocked synchronize costs tens of microseconds of it (the library waits for its own
-        streams the same way, cgvec.hip: wait_stream)."""
+        streams the same way, search.hip: wait_stream)."""
         import time
         t0 = time.perf_counter()
         while not event.query():

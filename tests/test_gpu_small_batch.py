@@ -49,7 +49,7 @@ def test_small_batches_equal_the_oracle(oracle, dtype, odt, metric):
             fb0 = st["fallback_queries"]
         # larger k on the path (k' <= 64) and just off it
         q = rng.standard_normal((5, d)).astype(np.float32)
-        # (fp8 keeps k' = 2k + 12 candidates - its coarse error bound does not shrink with D, cgvec.hip coarse_eps_scale (1') -
+        # (fp8 keeps k' = 2k + 12 candidates - its coarse error bound does not shrink with D, plan.cpp coarse_eps_scale (1') -
         # so k' <= 64 holds up to k = 26)
         for kk, on in (((26, 1), (27, 0)) if dtype == "fp8" else ((50, 1), (60, 0))):
             if dtype == "f32s" and kk > 12:
