@@ -11,13 +11,16 @@ brute-force cosine kNN at BASELINE.json config C2 (1M x 768 bf16, batch = 1024, 
   with the full query batch, the per-shard top-k are combined with one RCCL all-gather of packed
   12-byte records + a merge kernel.
 
-A "step" is SURVEY.md §8(d)'s unit: ONE batched search of 1024 queries against the whole corpus,
-corpus resident in HBM, queries starting in (pinned) HOST memory and the B*k results ending in
-host memory — H2D of the queries and D2H of the results are inside the step; steps are strictly
-serial (one batch at a time). `value` = batch * K / wall time of the K timed steps (max over
-ranks); `median_qps` is the same from the median step. Beside it, never as `value`: `hbm_resident_serial`
-(the same serial steps with the batch already in HBM and the results left there: what the PCIe hop
-costs) and `pipelined_qps` (device-resident, two batches in flight: round 1's headline).
+A "step" is ONE batched search of 1024 queries against the whole corpus, corpus resident in HBM, batches strictly
+serial (one at a time). `value` = batch * K / wall time of the K timed steps (max over ranks); `median_qps` is the same from
+the median step. By default (`--queries hbm`) the query batch is ALREADY RESIDENT IN HBM when the timed region starts - the
+measurement contract's form: throughput with the inputs in device memory (N > 1: every rank's copy of the replicated batch
+in its own HBM) - and the B*k results end in pinned HOST memory inside the step (cgv_search_f32_dev on the device aliases
+of the caller's pinned arrays). SURVEY.md §8(d)'s PCIe-inclusive form - the batch starts in pinned host memory, H2D inside
+the step (cgv_search_f32; `value` of rounds 1-5) - is timed in the same run over the same K steps and reported beside it as
+`pcie_inclusive_serial` (never as `value`); `--queries host` swaps the two. Also beside it: `hbm_resident_results_in_hbm`
+(results left in HBM too), `pipelined_host` / `pipelined` (three batches in flight), `concurrent_callers`,
+`coalesced_callers`, `latency`.
 `--force-dist` (under `torch.distributed.run --nproc-per-node 1`) runs the N > 1 code path with one rank:
 the dry run of the multi-GPU bench on a single-GPU box.
 Other workloads (--workload): c4, c3shard, c5shard, c5mini, c2shard8, small, c2f32 — parity /
@@ -469,6 +472,12 @@ def main():
                          "(replicated), or each rank moves 1/N of it and one all-gather of the f32 slices over xGMI completes it "
                          "(sharded; ShardedKnn.query_exchange). auto = both forms are timed in a short trial before the warm-up "
                          "(multi_gpu.query_exchange) and the faster one runs the timed steps")
+    ap.add_argument("--queries", default="hbm", choices=("hbm", "host"),
+                    help="where a timed step's query batch starts. hbm (default) = already resident in device memory when the timed "
+                         "region starts (the measurement contract: `value` = throughput with the inputs in HBM); the B*k results "
+                         "still end in pinned HOST memory inside the step. host = the batch starts in pinned host memory and "
+                         "crosses PCIe inside the step (SURVEY.md 8(d)'s form, `value` of rounds 1-5); whichever form is not "
+                         "`value` is timed as well and reported beside it (`pcie_inclusive_serial` / `hbm_resident_serial`)")
     ap.add_argument("--dist-timeout", type=float, default=180.0,
                     help="seconds: process-group timeout AND the no-progress limit of the watchdog - a hung collective ends the "
                          "run with a JSON line carrying an `error` field instead of hanging the launcher")
@@ -626,21 +635,34 @@ def run(args, wd, world, rank, local_rank):
         return float(t.item())
 
     L, C = m.cgvec.lib(), m.cgvec.C
+    hbm = args.queries == "hbm"
     if dist is None:
         oi_p, os_p = C.c_void_p(out_i.data_ptr()), C.c_void_p(out_s.data_ptr())
+        oi_a, os_a = C.c_void_p(ix.device_alias(out_i)), C.c_void_p(ix.device_alias(out_s))
+        ix.use_own_stream()
 
-        def step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
+        def host_step(i):   # cgv_search_f32: host queries in, host results out (H2D + D2H inside)
             m.cgvec._check(L.cgv_search_f32(ix._h, C.c_void_p(qhost[i % npool].data_ptr()), batch, k, oi_p, os_p))
+
+        def hbm_step(i):    # cgv_search_f32_dev: the batch is in HBM already; the last kernel writes the caller's pinned host arrays
+            m.cgvec._check(L.cgv_search_f32_dev(ix._h, C.c_void_p(qpool[i % npool].data_ptr()), batch, k, oi_a, os_a))
     else:
         exchange_ms = []
         searcher.time_exchange = True
 
-        def step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link by the shard search,
+        def host_step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link by the shard search,
             #                its top-k packed behind the search's last kernel, ONE RCCL all-gather of the packed records + the
             #                merge kernel (writes the pinned host result arrays in place) in line on the batch's stream - no host
             #                join between the search and the collective, ONE synchronisation per batch (ShardedKnn.step_packed)
             searcher.step_packed(qhost[i % npool], k, out=(out_i, out_s), device=dev)
             exchange_ms.append(searcher.last_exchange_ms)
+
+        def hbm_step(i):    # the same with every rank's copy of the batch resident in ITS HBM (queries are replicated:
+            #                SURVEY.md 8(e)); results still end in the pinned host arrays
+            searcher.step_packed(qpool[i % npool], k, out=(out_i, out_s), device=dev)
+            exchange_ms.append(searcher.last_exchange_ms)
+    step = hbm_step if hbm else host_step
+    other_step = host_step if hbm else hbm_step
 
     # The interpreter's cyclic garbage collector stays out of the timed regions: with torch imported a full collection walks
     # ~10^6 objects (tens of milliseconds) - one of them inside a 200-step region of 1.4 ms steps showed up as a mean 12 % above
@@ -674,11 +696,11 @@ def run(args, wd, world, rank, local_rank):
         def trial(mode, nsteps=30):
             searcher.query_exchange = mode
             for i in range(3):
-                step(i)
+                host_step(i)
             sync_all()
             tq = time.perf_counter()
             for i in range(nsteps):
-                step(i)
+                host_step(i)
             sync_all()
             wd.kick(f"query-exchange trial: {mode}")
             return 1e3 * max_over_ranks(time.perf_counter() - tq) / nsteps
@@ -688,7 +710,9 @@ def run(args, wd, world, rank, local_rank):
         # inside the noise should not flip the form from run to run)
         chosen = args.query_exchange if args.query_exchange != "auto" else ("sharded" if sha_ms < 0.97 * rep_ms else "replicated")
         searcher.query_exchange = chosen
-        query_exchange = {"replicated_ms": round(rep_ms, 4), "sharded_ms": round(sha_ms, 4), "timed_steps_use": chosen,
+        query_exchange = {"replicated_ms": round(rep_ms, 4), "sharded_ms": round(sha_ms, 4),
+                          "timed_steps_use": "n/a (the timed steps' batch is resident in every rank's HBM)" if hbm else chosen,
+                          "host_batch_steps_use": chosen,
                           "selection": args.query_exchange + (" (sharded when >= 3 % faster)" if args.query_exchange == "auto" else ""),
                           "note": "ms per serial step, 30 steps each, max over ranks; replicated = every rank reads the whole pinned "
                                   "batch over its own PCIe link; sharded = each rank copies batch/N rows to its device and ONE "
@@ -753,8 +777,32 @@ def run(args, wd, world, rank, local_rank):
                               "nccl = RCCL) + merge kernel in line on the batch's stream (no host join), timed with events on "
                               "the stream they run on")}
 
-    # side measurement: the same SERIAL steps with the query batch already in HBM and the results left in HBM
-    # (cgv_search_f32_dev): what the PCIe hop of the host boundary costs per batch
+    # side measurement: the OTHER form of the serial step (--queries): with `value` on HBM-resident batches this is SURVEY.md 8(d)'s
+    # PCIe-inclusive form (pinned host batch in, host results out: `value` of rounds 1-5), and the other way round
+    other_serial = None
+    if args.steps > 0:
+        for i in range(max(args.warmup, 1)):
+            other_step(i)
+        sync_all()
+        tr = time.perf_counter()
+        for i in range(args.steps):
+            other_step(i)
+        sync_all()
+        dto = max_over_ranks(time.perf_counter() - tr)
+        other_step(0)
+        oi2, os2 = out_i.clone(), out_s.clone()
+        step(0)
+        other_serial = {"queries_per_sec": round(batch * args.steps / dto, 1), "ms_per_step": round(1e3 * dto / args.steps, 4),
+                        "same_results_as_value_step": bool(torch.equal(oi2, out_i) and torch.equal(os2, out_s)),
+                        "note": ("serial batches that START IN PINNED HOST MEMORY and cross PCIe inside the step (cgv_search_f32; N > 1: "
+                                 "the query exchange form multi_gpu.query_exchange.host_batch_steps_use), results to host memory - "
+                                 "SURVEY.md 8(d)'s form, `value` of rounds 1-5") if hbm else
+                                ("serial batches already resident in HBM when the step starts (cgv_search_f32_dev), results written to "
+                                 "pinned host memory")}
+        wd.kick("other serial form timed")
+
+    # side measurement: serial steps with the query batch in HBM AND the results left in HBM (cgv_search_f32_dev on device
+    # arrays): what delivering the B*k results to the host costs per batch
     resident = None
     if dist is None and args.steps > 0:
         d_i = torch.empty((batch, k), dtype=torch.int64, device=dev)
@@ -775,9 +823,8 @@ def run(args, wd, world, rank, local_rank):
         step(0)
         same = bool(torch.equal(d_i.cpu(), out_i) and torch.equal(d_s.cpu(), out_s))
         resident = {"queries_per_sec": round(batch * args.steps / dtr, 1), "ms_per_step": round(1e3 * dtr / args.steps, 4),
-                    "same_results_as_host_step": same,
-                    "note": "serial batches, queries already in HBM, results left in HBM (cgv_search_f32_dev); "
-                            "`value` above includes the PCIe hop of both"}
+                    "same_results_as_value_step": same,
+                    "note": "serial batches, queries already in HBM, results LEFT in HBM (cgv_search_f32_dev on device arrays)"}
 
     # side measurement: THE SAME WORK AS A STEP - pinned host batch in, host results out, and (N > 1) the exchange + merge of
     # every batch - with `depth` batches in flight: each batch's whole pipeline is enqueued on its own stream, the host only
@@ -833,12 +880,12 @@ def run(args, wd, world, rank, local_rank):
                           "ms_per_batch": round(1e3 * dtp / args.pipelined_steps, 4), "batches_in_flight": depth,
                           "batches": args.pipelined_steps, "same_results_as_serial_step": same,
                           "redo_batches": (searcher.redo_batches - redo_before) if dist is not None else None,
-                          "note": ("the same work as `value` - pinned host batch in (fetched by the copy engine while the batches before "
+                          "note": ("the same work as a host-batch serial step (`pcie_inclusive_serial`) - pinned host batch in (fetched by the copy engine while the batches before "
                                    "it compute), shard search, packed records, all-gather, merge into pinned host arrays - with batches in "
                                    "flight on their own streams (ShardedKnn.step_packed_begin / _end); the host waits for the oldest "
                                    "batch only")
                           if dist is not None else
-                          ("the same work as `value` - pinned host batch in (fetched by the copy engine while the batches before it "
+                          ("the same work as a host-batch serial step (`pcie_inclusive_serial`) - pinned host batch in (fetched by the copy engine while the batches before it "
                            "compute), host results written in place - with batches in flight (cgv_search_begin_f32_dev on the "
                            "buffers' device aliases / cgv_search_end)")}
 
@@ -907,7 +954,7 @@ def run(args, wd, world, rank, local_rank):
                       "ms_per_batch": round(1e3 * dtc / (T * per), 4), "same_results_as_serial_step": same_c,
                       "errors": errs or None,
                       "note": "host threads in serial cgv_search_f32 loops on one index (pinned host batch in, host results out: the same "
-                              "work as `value` per call); the library fetches a caller's batch with the copy engine while other callers' "
+                              "work as `pcie_inclusive_serial` per call); the library fetches a caller's batch with the copy engine while other callers' "
                               "batches compute"}
         wd.kick("concurrent callers")
 
@@ -1114,7 +1161,10 @@ def run(args, wd, world, rank, local_rank):
                        "metric": metric, "sharding": f"rows/{world}" if world > 1 else "none",
                        "rng": ("counter-based (Philox4x32-10 keyed seed,row,col -> N(0,1) f32 -> unit norm; corpus seed 0xC0DE6001, "
                                "queries 0xC0DE6002: SURVEY.md 8(d))") if RNG == "counter" else "torch.randn per 125 k-row chunk",
-                       "step": "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
+                       "step": ("one batch of queries ALREADY RESIDENT IN HBM (every rank's copy, N > 1) -> search (-> all-gather + merge) "
+                                "-> results written to pinned host memory; serial batches") if hbm else
+                               "one batch: pinned host queries -> H2D -> search -> D2H host results, serial batches",
+                       "queries_start_in": "hbm" if hbm else "pinned host memory",
                        "exchange": "RCCL all-gather of per-shard top-k + merge (see multi_gpu)" if world > 1 else "none",
                        "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}},
             "median_ms_per_step": round(med, 4), "median_qps": round(batch / (med * 1e-3), 1),
@@ -1125,7 +1175,8 @@ def run(args, wd, world, rank, local_rank):
             "coalesced_callers": coalesced,
             "pipelined_qps": pipelined["queries_per_sec"] if pipelined else None,
             "pipelined": pipelined,
-            "hbm_resident_serial": resident,
+            ("pcie_inclusive_serial" if hbm else "hbm_resident_serial"): other_serial,
+            "hbm_resident_results_in_hbm": resident,
             "latency": latency,
             "roofline": roof,
             "multi_gpu": multi,

@@ -159,6 +159,8 @@ def lib():
     L.cgv_get_phase_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.cgv_get_phase_times.restype = i32
     L.cgv_get_small_batch_stats.restype = i32
+    L.cgv_get_sample_repair_stats.argtypes = [vp, C.POINTER(u64)]
+    L.cgv_get_sample_repair_stats.restype = i32
     L.cgv_alloc_pinned.argtypes = [C.c_size_t]
     L.cgv_alloc_pinned.restype = vp
     L.cgv_free_pinned.argtypes = [vp]
@@ -292,6 +294,13 @@ class HipKnnIndex:
         out = (C.c_uint64 * 4)()
         _check(lib().cgv_get_small_batch_stats(self._h, out))
         return {"searches": int(out[0]), "failed_queries": int(out[1]), "repaired_by_cell_rescan": int(out[2]), "exact_scans": int(out[3])}
+
+    def sample_repairs(self):
+        """Queries of large batches whose check failed on one cell of the emitting sample and that the final kernel put right by
+        itself (cgv_get_sample_repair_stats); not part of stats()['fallback_queries']."""
+        out = (C.c_uint64 * 1)()
+        _check(lib().cgv_get_sample_repair_stats(self._h, out))
+        return int(out[0])
 
     def synchronize(self):
         _check(lib().cgv_synchronize(self._h))

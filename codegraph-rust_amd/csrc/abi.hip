@@ -12,7 +12,7 @@ static __global__ void f64_to_f32_kernel(const double* __restrict__ in, uint64_t
 
 extern "C" {
 
-uint32_t cgv_version(void) { return (0u << 16) | 8u; }  // 0.8: + scalar-arm normalise, small-batch stats, phase times, synthetic inputs
+uint32_t cgv_version(void) { return (0u << 16) | 9u; }  // 0.9: + sample-repair stats (0.8: scalar-arm normalise, small-batch stats, phase times, synthetic inputs)
 
 // internal: lets the host mirror (host/store.cpp) share this library's thread-local error message
 int cgv_set_error_(int code, const char* msg) {
@@ -54,6 +54,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "top2")) t.top2 = (int)v;
     else if (!strcmp(key, "sample_emit")) t.sample_emit = (int)v;
     else if (!strcmp(key, "top2_repair")) t.top2_repair = (int)v;
+    else if (!strcmp(key, "sample_repair")) t.sample_repair = (int)v;
     else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
     else if (!strcmp(key, "self_publish")) t.self_publish = (int)v;
     else if (!strcmp(key, "fetch_queries")) t.fetch_queries = (int)v;
@@ -835,6 +836,13 @@ int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batc
     if (max_batches_in_flight > (uint32_t)N_CTX) return fail(CGV_ERR_INVALID_ARG, "at most cgv_max_batches_in_flight() batches");
     // (applies to calls that arrive from now on; requests already queued are served under whichever values their leader reads)
     h->co.configure(max_batch_queries != 0 && max_batches_in_flight != 0, max_batch_queries, (int)max_batches_in_flight, window_us);
+    return CGV_OK;
+}
+
+int cgv_get_sample_repair_stats(cgv_index* h, uint64_t* out1) {
+    if (!h || !out1) return fail(CGV_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    out1[0] = h->sample_repairs;
     return CGV_OK;
 }
 

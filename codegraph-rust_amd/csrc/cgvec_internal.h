@@ -207,6 +207,7 @@ struct cgv_index {
     bool force_exact = false;
     bool wide_range = false;  // a stored row's magnitude is outside [2^-40, 2^40]: searches take the exact scan (kernels_prep.h)
     bool last_top2 = false;   // the last finished search took the small-batch form (cgv_debug_last_top2_)
+    uint64_t sample_repairs = 0;          // queries whose check failed on a cell of the emitting sample and were put right inside the final kernel
     uint64_t top2_stats[3] = {0, 0, 0};   // COARSE_TOP2 searches, their queries that failed the check, of those repaired by a cell re-scan
     cgv_stats st;
     uint64_t last_coarse_rows = 0;

@@ -432,8 +432,17 @@ struct RescoreArgs {
     float* rep_theta;       // [nq]
     uint64_t* rep_keys;     // [nq][REPAIR_KEYS] exact keys (score, LOCAL row), descending
     uint32_t* rep_n;        // [nq] how many
+    // Emitting sample: a query whose check fails ONLY because of the sample's floor - one of the sample's 64-row
+    // cells left out a row that may belong to the top-k - is put right inside this kernel: the cells whose left-out score may
+    // reach the top-k (usually one) are scored again with the reference's arithmetic and merged with the re-scored candidates
+    // (sample_floor_repair below). No flag, no host round trip, no second exchange on the row-sharded path. NULL: off.
+    const float* sfloor;    // the floor area of the sample's dump rows: sfloor[q * sfloor_ld + seq * 4 + cell]
+    uint32_t sfloor_ld, sfloor_n;          // row pitch (floats); 4 x sample tiles
+    uint32_t s_T1, s_R, s_P;               // the visiting order (stage_tile): sample position seq -> corpus tile
+    uint32_t* sfix_count;   // [1] queries put right that way (statistics)
 };
 constexpr uint32_t REPAIR_KEYS = 64;
+constexpr uint32_t SFIX_MAX_CELLS = 24;   // offending sample cells per query at most (64 rows each); more: the exact scan takes it
 
 // End-of-search publication (one wave, launched behind the last kernel of a search): the flag words (fallback count,
 // non-finite bits, error maxima, ...) go to the pinned, device-mapped host mirror and are cleared for the next search,
@@ -494,13 +503,113 @@ __device__ inline void stage_query_row(const RescoreArgs& a, uint32_t q, char* q
     for (uint32_t pc = tid; pc < pieces; pc += 256) *(uint4*)(qs + (size_t)pc * 16) = *(const uint4*)piece_ptr<DT>(qr, pc);
 }
 
+// The emitting sample's way out of a floor violation, inside the final kernel (one workgroup per query; rare: 6e-6 per query on
+// C2's 8-GPU shard - but a bench that cycles through four query batches meets the same query every fourth step, and on the
+// row-sharded path every such query cost an exact scan AND a second exchange, on every rank).
+// theta = e_k - eps: a sampled row outside the candidates and outside a cell with left-out score > theta has coarse <= theta,
+// hence exact <= theta + eps < e_k. The offending cells' rows (cell = (sample position, M-half, lane half): 64 rows in the MFMA
+// C layout, kernels_coarse.h tile_epilogue) are staged through the re-score's LDS region, 8 lanes per row run the reference's
+// chains, rows above the current k-th key that are not candidates already join the keys; the top-k of the union is the exact
+// top-k (the k-th score can only rise: no second check). Returns false (uniform) when it gives up: too many cells or keys, a NaN.
+template <int DT>
+__device__ inline bool sample_floor_repair(const RescoreArgs& a, uint32_t q, uint32_t nres, uint64_t* ekeys /* LDS [CAND_CAPS] */,
+                                                 float theta, char* rs, const char* qs, int tid) {
+    __shared__ uint32_t fcells[SFIX_MAX_CELLS];
+    __shared__ uint32_t fn, fnew, fbad;
+    if (tid == 0) {
+        fn = 0;
+        fnew = 0;
+        fbad = 0;
+    }
+    __syncthreads();
+    const float* fl = a.sfloor + (uint64_t)q * a.sfloor_ld;
+    for (uint32_t c = (uint32_t)tid; c < a.sfloor_n; c += 256u)
+        if (fl[c] > theta) {
+            const uint32_t p = atomicAdd(&fn, 1u);
+            if (p < SFIX_MAX_CELLS) fcells[p] = c;
+        }
+    __syncthreads();
+    const uint32_t ncell = fn;
+    if (ncell > SFIX_MAX_CELLS) return false;   // uniform
+    const uint64_t kth = ekeys[a.k - 1];
+    const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
+    const uint32_t total = ncell * 64u, rpb = a.rows_per_batch;
+    auto row_of = [&](uint32_t it) -> uint32_t {   // item -> corpus row (0xFFFFFFFF: beyond the corpus' last row)
+        const uint32_t c = fcells[it >> 6], i = it & 63u, lg = c & 3u;
+        const uint32_t tile = stage_tile(a.s_T1, a.s_R, a.s_P, c >> 2);
+        const uint64_t rw = (uint64_t)tile * 256u + (lg >> 1) * 128u + (i >> 4) * 32u + (i & 3u) + 8u * ((i >> 2) & 3u) + 4u * (lg & 1u);
+        return rw < a.n ? (uint32_t)rw : 0xFFFFFFFFu;
+    };
+    for (uint32_t r0 = 0; r0 < total; r0 += rpb) {
+        const uint32_t nbat = (total - r0) < rpb ? (total - r0) : rpb;
+        __syncthreads();   // (the previous pass' LDS reads are done)
+        const uint32_t nload = nbat * pieces;
+        for (uint32_t i0 = (uint32_t)tid; i0 < nload; i0 += 256u * 8u) {   // up to 8 independent 16-byte loads per thread in flight
+            uint4 v[8];
+            uint32_t ok = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                if (i < nload) {
+                    const uint32_t slot = i / pieces, pc = i - slot * pieces, row = row_of(r0 + slot);
+                    if (row != 0xFFFFFFFFu) {
+                        v[u] = *(const uint4*)piece_ptr<DT>(make_row<DT>(a.rows, row, a.ld), pc);
+                        ok |= 1u << u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                if (ok & (1u << u)) {
+                    const uint32_t slot = i / pieces, pc = i - slot * pieces;
+                    *(uint4*)(rs + (size_t)slot * pitch + (size_t)pc * 16u) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const LdsRow<DT> ql{qs};
+        for (uint32_t sl = (uint32_t)tid >> 3; sl < nbat; sl += 32u) {   // uniform within an 8-lane group
+            const uint32_t row = row_of(r0 + sl);
+            if (row == 0xFFFFFFFFu) continue;
+            const LdsRow<DT> cl{rs + (size_t)sl * pitch};
+            const float sc = exact_score_group8((int)a.metric, ql, cl, a.D, tid & 7);
+            if ((tid & 7) == 0) {
+                if (sc != sc) fbad = 1u;
+                const uint64_t key = make_key(sc, row);
+                if (key > kth) {
+                    bool have = false;   // a candidate already (its key is the same: the same arithmetic on the same values)
+                    for (uint32_t j = 0; j < nres; ++j) have = have || key_row(ekeys[j]) == row;
+                    if (!have) {
+                        const uint32_t p = atomicAdd(&fnew, 1u);
+                        if (nres + p < CAND_CAPS) ekeys[nres + p] = key;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nnew = fnew;
+    if (fbad != 0u || nres + nnew > CAND_CAPS) return false;   // uniform
+    const uint32_t nall = nres + nnew, P = next_pow2(nall < 2u ? 2u : nall);
+    for (uint32_t i = nall + (uint32_t)tid; i < P; i += 256u) ekeys[i] = 0ull;
+    __syncthreads();
+    bitonic_sort_desc<256>(ekeys, P, tid);
+    for (uint32_t j = (uint32_t)tid; j < a.k; j += 256u) {
+        a.out_idx[(uint64_t)q * a.k + j] = map_id(a.idmap, key_row(ekeys[j]));   // (nall >= nres >= k)
+        a.out_score[(uint64_t)q * a.k + j] = key_score(ekeys[j]);
+    }
+    return true;
+}
+
 template <int DT>
 __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t nb, const uint64_t* ckeys /* LDS [nb] */,
                                     float tau, bool overflow, char* rs /* LDS: staged candidate rows */,
                                     const char* qs /* LDS: the query row (stage_query_row) */, int tid,
                                     float tau_lists = INFINITY /* COARSE_TOP2: the threshold WITHOUT the floor (else unused) */) {
     __shared__ uint64_t ekeys[CAND_CAPS];
-    __shared__ uint32_t maxerr, tripped, repair_s;
+    __shared__ uint32_t maxerr, tripped, repair_s, fix_s;
+    __shared__ float fix_theta;
     const uint32_t rowb = a.ld * Elem<DT>::bytes, pitch = rowb + 16, pieces = rowb / 16;
     if (tid == 0) {
         maxerr = 0;
@@ -658,28 +767,46 @@ __device__ inline void rescore_body(const RescoreArgs& a, uint32_t q, uint32_t n
         // left-out score could reach the top-k are re-scanned exactly (top2_repair_kernel) instead of the whole corpus.
         // Rows outside the candidates and outside a re-scanned cell have coarse <= theta, hence exact <= theta + eps < e_k.
         uint32_t flag = fb ? 1u : 0u;
-        if (fb && a.rep_theta && tau_lists != INFINITY) {
+        bool fix = false;
+        if (fb && (a.rep_theta || a.sfloor) && tau_lists != INFINITY) {
             const float ek = nres >= a.k ? key_score(ekeys[a.k - 1]) : -INFINITY;
             // (why not, in the upper bits of the word - diagnostics only; any non-zero word means "exact scan")
             const uint32_t why = (overflow ? 1u : 0u) | (tripped ? 2u : 0u) | ((nb_all < a.k || nres < a.k) ? 4u : 0u) |
                                  (!(ek > tau_eff_lists + eps) ? 8u : 0u) | (nres > REPAIR_KEYS ? 16u : 0u) |
                                  (!(fabsf(ek) < INFINITY) ? 32u : 0u);
-            if (why == 0u) {
+            if (why == 0u && a.rep_theta) {
                 a.rep_theta[q] = ek - 1.001f * eps - 1e-30f;
                 a.rep_n[q] = nres;
                 flag = 2u;
                 repair_s = 1u;
+            } else if (why == 0u) {   // emitting sample: put right below, by this workgroup
+                fix_theta = ek - 1.001f * eps - 1e-30f;
+                fix = true;
             } else {
                 flag = 1u | (why << 8);
             }
         }
-        a.fb_flag[q] = flag;
-        if (fb) atomicAdd(a.fb_count, 1u);
+        fix_s = fix ? 1u : 0u;
+        if (!fix) {
+            a.fb_flag[q] = flag;
+            if (fb) atomicAdd(a.fb_count, 1u);
+        }
     }
     if (a.rep_theta) {   // uniform
         __syncthreads();
         if (repair_s != 0u)
             for (uint32_t j = tid; j < nres; j += 256) a.rep_keys[(uint64_t)q * REPAIR_KEYS + j] = ekeys[j];
+    }
+    if (a.sfloor) {   // uniform
+        __syncthreads();
+        if (fix_s != 0u) {   // uniform (LDS)
+            const bool done = sample_floor_repair<DT>(a, q, nres, ekeys, fix_theta, rs, qs, tid);
+            if (tid == 0) {
+                a.fb_flag[q] = done ? 0u : (1u | (64u << 8));
+                if (done) atomicAdd(a.sfix_count, 1u);
+                else atomicAdd(a.fb_count, 1u);
+            }
+        }
     }
     phase_stamp(a.trace, q, 7, tid);
     if (a.pub_host) {   // uniform: a small batch publishes its own flags (RescoreArgs::pub_*)

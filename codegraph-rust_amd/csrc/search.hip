@@ -612,6 +612,8 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         c->repair = false;
         a.lad = nullptr;
         a.ladc = nullptr;
+        const float* sfloor_p = nullptr;   // emitting sample: the floor area of its dump rows (final_kernel's in-kernel repair)
+        uint32_t sfloor_ld = 0, sfloor_n = 0;
         // Small batches (one query tile of <= 64 queries - the trait-level call is ONE query, traits.rs:14): the corpus streams at the
         // HBM rate whatever happens to the scores, so the staged thresholds (sample launch, tau_kernel, emitting launches, select)
         // are pure latency. COARSE_TOP2 visits all tiles in ONE launch without a threshold: per-cell top-2 + floor (kernels_coarse.h).
@@ -689,6 +691,11 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             sa.sample_vals = vals;
             sa.sample_emit = p.sample_emits ? 1u : 0u;
             sa.sample_floor = M;
+            if (p.sample_emits) {
+                sfloor_p = c->dump.as<float>() + M;
+                sfloor_ld = dump_ld;
+                sfloor_n = floor_n;
+            }
             sa.j0 = 0;
             sa.cnt = p.sample_tiles;
             sa.nsplit = std::min<uint32_t>(p.sample_tiles, nsplit_max);
@@ -812,6 +819,13 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
         r.rep_theta = (top2 && c->repair) ? c->reptheta.as<float>() : nullptr;
         r.rep_keys = c->repkeys.as<uint64_t>();
         r.rep_n = c->repn.as<uint32_t>();
+        r.sfloor = (semit && tun().sample_repair != 0) ? sfloor_p : nullptr;
+        r.sfloor_ld = sfloor_ld;
+        r.sfloor_n = sfloor_n;
+        r.s_T1 = a.T1;
+        r.s_R = a.R;
+        r.s_P = a.P;
+        r.sfix_count = c->flags + F_COMPACT;   // (a free word while the pipeline runs: published and cleared with the others)
         if ((rc = c->qstat.ensure((size_t)nq * 8))) return rc;
         r.qstat = c->qstat.as<uint2>();   // per-query statistics, folded into the flag words by publish_flags_kernel
         // ... or, for a small batch, by the last workgroup of the final kernel itself (RescoreArgs::pub_*)
@@ -977,7 +991,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         return fail(CGV_ERR_NONFINITE, "query contains NaN/Inf (the reference panics at simd_ops.rs:379)");
     if (c->h_flags[F_NONFINITE_Q] & 2u)
         return fail(CGV_ERR_INVALID_ARG, "fp8 index: a query's largest magnitude is outside [2^-48, 2^48]");
-    uint32_t nfb = 0, nrepaired = 0;
+    uint32_t nfb = 0, nrepaired = 0, nsfix = 0;
     float me = 0.0f;
     if (!c->mfma && c->exact_enqueued) {
         // the scan ran behind the query conversion on the same stream: nothing left to do
@@ -990,6 +1004,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
         memcpy(&me, &c->h_flags[F_MAXERR], 4);
         if (h->shadow) memcpy(&c->eps, &c->h_flags[F_MAXEPS], 4);  // largest per-query bound of this batch
         nfb = c->h_flags[F_FB_COUNT];
+        if (c->published && !c->top2) nsfix = c->h_flags[F_COMPACT];   // queries put right inside the final kernel (emitting sample)
         uint32_t nscan = nfb;   // queries left for the exact scan
         if (nfb > 0 && c->top2 && c->repair) {
             // COARSE_TOP2: a query that failed on its floor alone (flag 2) gets the offending cells re-scanned (kernels_repair.h);
@@ -1083,6 +1098,7 @@ int search_finish(cgv_index* h, SearchCtx* c) {
     h->top2_stats[0] += (c->mfma && c->top2) ? 1u : 0u;
     h->top2_stats[1] += (c->mfma && c->top2) ? nfb : 0u;
     h->top2_stats[2] += nrepaired;
+    h->sample_repairs += nsfix;
     h->st.last_path = (c->mfma && h->n) ? 1u : 0u;
     h->last_top2 = c->mfma && c->top2;
     h->st.last_kprime = c->kprime;

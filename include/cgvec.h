@@ -89,7 +89,7 @@ typedef struct cgv_index cgv_index; /* opaque handle */
 #define CGV_MAX_K 2048u
 #define CGV_FAST_MAX_K 228u
 
-/* Library/ABI version (major<<16 | minor). Minor 8 (round 6): cgv_normalize_rows_scalar_f32 (the scalar arm of
+/* Library/ABI version (major<<16 | minor). Minor 9 (round 6): cgv_get_sample_repair_stats. Minor 8 (round 6): cgv_normalize_rows_scalar_f32 (the scalar arm of
  * parallel_normalize_vectors), cgv_get_small_batch_stats, cgv_get_phase_times (profiling level 3), cgv_synth_rows_f32_dev (the
  * bench's counter-based inputs). Minor 7 (round 6): cgv_set_coalesce / cgv_get_coalesce_stats (concurrent small
  * cgv_search_f32 calls share one device batch). Minor 6 (round 5): cgv_set_spin_us, cgv_sharded_force_exchange - the library reads no
@@ -183,6 +183,11 @@ int cgv_set_coalesce(cgv_index* h, uint32_t max_batch_queries, uint32_t max_batc
  * near-duplicates do it), of those answered by re-scanning only the offending cells, of those sent to the exact scan of the whole
  * corpus}. Results are exact either way. */
 int cgv_get_small_batch_stats(cgv_index* h, uint64_t* out4);
+/* Large batches whose first threshold comes from an EMITTING sample launch (the sampled tiles are not scored again): out1[0] = queries
+ * whose check failed only because one 64-row cell of the sample left out a row that may belong to the top-k, and that the final
+ * kernel put right by itself (the offending cells re-scored with the reference's arithmetic) - no exact scan, no host round trip,
+ * no second exchange on the row-sharded path. Not counted in cgv_stats.fallback_queries. */
+int cgv_get_sample_repair_stats(cgv_index* h, uint64_t* out1);
 int cgv_get_coalesce_stats(cgv_index* h, uint64_t* out8);
 
 /* Same with DEVICE pointers for queries and outputs (results stay in HBM; the call

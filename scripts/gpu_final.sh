@@ -29,6 +29,6 @@ for f in sorted(glob.glob('gpurun_out/profiles_'"$TAG"'/*_bench.json')):
         print(f, 'unreadable', e); continue
     r=d.get('roofline') or {}
     print(f.split('/')[-1], 'ms/step', d.get('ms_per_step'), 'median', d.get('median_ms_per_step'), 'launch', r.get('avg_launch_ms'), 'frac', r.get('frac'),
-          'pipelined', (d.get('pipelined') or {}).get('ms_per_batch'), 'resident', (d.get('hbm_resident_serial') or {}).get('ms_per_step'),
+          'pipelined', (d.get('pipelined') or {}).get('ms_per_batch'), 'pcie_inclusive', (d.get('pcie_inclusive_serial') or {}).get('ms_per_step'),
           'xch', (d.get('multi_gpu') or {}).get('exchange_ms'), d.get('last_exchange_ms'), 'recall', d.get('recall_at_10'), 'cpu', (d.get('cpu_baseline') or {}).get('value'))
 PY

@@ -60,9 +60,9 @@ def _check_diagnostics(mg, world, dry_run):
     """Round 6: what makes the first real multi-GPU run readable in one shot - both query-exchange forms timed in the line, the
     per-rank phase breakdown from HIP events, the all-gather micro-latency, the ranks' device identities."""
     qx = mg["query_exchange"]
-    assert qx["replicated_ms"] > 0 and qx["sharded_ms"] > 0 and qx["timed_steps_use"] in ("replicated", "sharded")
+    assert qx["replicated_ms"] > 0 and qx["sharded_ms"] > 0 and qx["host_batch_steps_use"] in ("replicated", "sharded")
     if qx["selection"].startswith("auto"):
-        assert qx["timed_steps_use"] == ("sharded" if qx["sharded_ms"] < 0.97 * qx["replicated_ms"] else "replicated")
+        assert qx["host_batch_steps_use"] == ("sharded" if qx["sharded_ms"] < 0.97 * qx["replicated_ms"] else "replicated")
     ph = mg["per_rank_phases_us"]
     for name in ("prep", "sample_tau", "emitting", "final_publish", "pack_and_gaps", "query_exchange", "all_gather", "merge",
                  "search_device_total"):
@@ -88,6 +88,9 @@ def test_bench_one_rank_nccl_pipelined_host_step():
     assert "error" not in d and d["multi_gpu"]["rccl_ranks_seen"] == 1 and d["multi_gpu"]["backend"].startswith("nccl")
     assert d["recall_at_10"] == d["ordered_match_rate"] == d["score_bit_exact_rate"] == 1.0
     assert d["pipelined_host"]["same_results_as_serial_step"] is True
+    # the timed steps' batch is resident in HBM (the default); the host-batch form is timed beside it, same results
+    assert d["config"]["queries_start_in"] == "hbm" and d["pcie_inclusive_serial"]["same_results_as_value_step"] is True
+    assert d["pcie_inclusive_serial"]["ms_per_step"] > 0
     ex = d["exact_check"]
     assert ex["recall_at_10"] == ex["ordered_match_rate"] == ex["score_bit_exact_rate"] == 1.0
     _check_diagnostics(d["multi_gpu"], 1, dry_run=False)
@@ -97,10 +100,11 @@ def test_bench_one_rank_nccl_sharded_query_exchange():
     """--query-exchange sharded over RCCL with one rank: the slice copy, the all-gather of the f32 slices and the shard search
     reading the gathered batch from HBM are what the timed steps run; parity fields as in the replicated form."""
     p, lines = _run(1, ["--force-dist", "--workload", "c2shard8", "--steps", "20", "--warmup", "3", "--settle-ms", "50",
-                        "--pipelined-steps", "30", "--check-queries", "16", "--query-exchange", "sharded"])
+                        "--pipelined-steps", "30", "--check-queries", "16", "--query-exchange", "sharded", "--queries", "host"])
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = lines[-1]
     assert "error" not in d and d["multi_gpu"]["query_exchange"]["timed_steps_use"] == "sharded"
+    assert d["config"]["queries_start_in"] == "pinned host memory" and d["hbm_resident_serial"]["same_results_as_value_step"] is True
     assert d["multi_gpu"]["per_rank_phases_us"]["query_exchange"]["min"] > 0.0
     assert d["recall_at_10"] == d["ordered_match_rate"] == d["score_bit_exact_rate"] == 1.0
     assert d["pipelined_host"]["same_results_as_serial_step"] is True
