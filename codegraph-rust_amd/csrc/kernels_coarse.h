@@ -506,8 +506,9 @@ __device__ __forceinline__ void tile_epilogue(const CoarseArgs& a, f32x16_t (&ac
         // scand (the first emitting launch moves those above the threshold - which exists by then - into its candidate lists:
         // append_sample_candidates), the left-out score to the floor area of the query's dump row; tau_kernel folds the 4 x S floor values of a query into
         // floor_ord[q] and the final kernel checks its guarantee against max(tau, floor), as it does for COARSE_TOP2: a sampled row
-        // that is in no list scores at most its cell's left-out score. (Three of a query's final top-k' rows in one 64-row cell of
-        // the sample raise the floor above e_k: the query takes the exact scan - C(k + 1, 3) x (S / R)^3 / 256^2 per query.)
+        // that is in no list scores at most its cell's left-out score. (Three of a query's top-(k + 1) rows in one 64-row cell of
+        // the sample raise the floor above e_k - C(k + 1, 3) x (S / R)^3 / 256^2 per query: the final kernel re-scores the offending
+        // cell itself, sample_floor_repair in kernels_select.h.)
         static_assert(MODE != 2 || MB == 4, "sample layout assumes 4 M-blocks per wave");
         const bool emit = a.sample_emit != 0u;   // uniform
         // The cell's three best values by a max / med3 / min network on floats whose 6 low mantissa bits carry the value's

@@ -220,10 +220,12 @@ StagePlan plan_stages(uint64_t n, uint32_t kprime, uint32_t nqt, uint32_t n_cu, 
     p.T1 = 0;
     p.R = p.ntiles;
     p.P = golden_stride(p.R);
-    // (>= 4 S tiles: three of a query's top-(k + 1) rows in one 64-row cell of the sample send it to the exact scan, with
-    // probability C(k + 1, 3) (S / R)^3 / 256^2 per query - 3e-4 at R = 2 S, i.e. an exact scan in every third 1024-query batch,
-    // which eats the tile-time the emitting sample saves; 4e-5 at 4 S, 6e-6 on C2's 8-GPU shard, 1e-8 on C2)
-    p.sample_emits = allow_emit && t.sample_emit != 0 && kprime <= 64 && p.ntiles >= 4 * S;
+    // (Three of a query's top-(k + 1) rows in one 64-row cell of the sample fail its floor check: C(k + 1, 3) (S / R)^3 / 256^2 per
+    // query - 3e-4 at R = 2 S, 4e-5 at 4 S, 6e-6 on C2's 8-GPU shard, 1e-8 on C2. While such a query cost the exact scan of the whole
+    // corpus the sample only emitted from 4 S tiles on; the final kernel now re-scores the offending cell itself
+    // (sample_floor_repair, kernels_select.h: one workgroup, 64 rows), so from 2 S on the tile-time saved - up to a third of the
+    // GEMM of a mid-size corpus - is kept. Below 2 S the launch behind the sample would be shorter than the sample.)
+    p.sample_emits = allow_emit && t.sample_emit != 0 && kprime <= 64 && p.ntiles >= 2 * S;
     const uint32_t emit_tiles = p.sample_emits ? p.ntiles - S : p.ntiles;   // tiles the emitting launches cover
     const double seen0 = (double)S * BM, total = (double)emit_tiles * BM;
     const double kappa = (double)nqt * kprime * 4.0 * hit_us / (double)std::max<uint32_t>(n_cu, 1u);

@@ -25,7 +25,7 @@ def _plan(L, n, k, nq, n_cu=256, shadow=0):
 @pytest.mark.parametrize("n,k,nq,shadow", [
     (1_000_000, 10, 1024, 0), (125_000, 10, 1024, 0), (250_000, 10, 1024, 0), (500_000, 10, 1024, 0),
     (1_000_000, 10, 256, 0), (1_250_000, 10, 4096, 0), (62_500_000, 10, 8192, 0), (1_000_000, 10, 1024, 1),
-    (4097, 10, 1, 0), (10_000, 200, 16, 0), (999_999, 228, 1024, 0), (70_000, 1, 1, 0), (300_000, 60, 7, 1),
+    (40_000, 10, 1024, 0), (100_000, 10, 300, 0), (200_000, 10, 256, 0), (4097, 10, 1, 0), (10_000, 200, 16, 0), (999_999, 228, 1024, 0), (70_000, 1, 1, 0), (300_000, 60, 7, 1),
 ])
 def test_plan_covers_every_tile_once(n, k, nq, shadow):
     L = pkg().cgvec.lib()
@@ -35,7 +35,7 @@ def test_plan_covers_every_tile_once(n, k, nq, shadow):
     # round 6: a sample that emits its own candidates is not scored again - the launches cover the tiles behind it
     assert all(c > 0 for c in counts) and sum(counts) + (sample if emits else 0) == ntiles
     kprime = min((4 * k + 16 + 7) // 8 * 8, 256) if shadow else (k + max(6, k // 8) + 7) // 8 * 8
-    assert emits == (nq > 64 and kprime <= 64 and ntiles >= 4 * sample and counts[0] >= min(sample, max(1, 256 // ((nq + 255) // 256))))
+    assert emits == (nq > 64 and kprime <= 64 and ntiles >= 2 * sample and counts[0] >= min(sample, max(1, 256 // ((nq + 255) // 256))))
     if emits:
         assert min(counts[0], max(1, 256 // ((nq + 255) // 256))) >= sample    # the first launch continues every sampled tile's lists
     assert len(counts) <= 8
