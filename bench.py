@@ -648,7 +648,8 @@ def run(args, wd, world, rank, local_rank):
             m.cgvec._check(L.cgv_search_f32_dev(ix._h, C.c_void_p(qpool[i % npool].data_ptr()), batch, k, oi_a, os_a))
     else:
         exchange_ms = []
-        searcher.time_exchange = True
+        # (the all-gather + merge are timed with stream events in the two diagnostic steps behind the timed region, not in it: an
+        #  event pair is two more packets on the batch's stream - a few microseconds of a 0.3 ms step on an 8-GPU shard)
 
         def host_step(i):   # every rank: the (replicated) pinned batch read in place over its own PCIe link by the shard search,
             #                its top-k packed behind the search's last kernel, ONE RCCL all-gather of the packed records + the
@@ -739,6 +740,8 @@ def run(args, wd, world, rank, local_rank):
     ix.set_profiling(3)       # two un-timed steps with the whole-pipeline event pair (side field device_ms_last_step) and the phase events
     if dist is not None:
         searcher.time_phases = True
+    if dist is not None:
+        del exchange_ms[:]
     step(0)
     step(1)
     st = ix.stats()
@@ -746,6 +749,7 @@ def run(args, wd, world, rank, local_rank):
     ix.set_profiling(1)
     if dist is not None:
         searcher.time_phases = False
+        exchange_steps = list(exchange_ms)   # all-gather + merge of the two diagnostic steps (events on the batch's stream)
     multi = None
     if dist is not None:
         diag = rank_diagnostics(dist, searcher, phases, st, dev, dev_index, ctl, world, gloo, batch, dim, k, wd)
@@ -754,7 +758,7 @@ def run(args, wd, world, rank, local_rank):
         ones = torch.ones(1, device=ctl)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         mine = torch.tensor([float(np.mean([c for c in coarse_ms if c > 0] or [0.0])), float(coarse_rows),
-                             float(np.mean(exchange_ms[-args.steps:] or [0.0])), float(hi - lo), float(dev_index)],
+                             float(np.mean(exchange_steps or [0.0])), float(hi - lo), float(dev_index)],
                             dtype=torch.float64, device=ctl)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
