@@ -55,6 +55,7 @@ int cgv_debug_set_(const char* key, double v) {
     else if (!strcmp(key, "sample_emit")) t.sample_emit = (int)v;
     else if (!strcmp(key, "top2_repair")) t.top2_repair = (int)v;
     else if (!strcmp(key, "sample_repair")) t.sample_repair = (int)v;
+    else if (!strcmp(key, "launch_events")) t.launch_events = (int)v;
     else if (!strcmp(key, "exact_small")) t.exact_small = (int)v;
     else if (!strcmp(key, "self_publish")) t.self_publish = (int)v;
     else if (!strcmp(key, "fetch_queries")) t.fetch_queries = (int)v;

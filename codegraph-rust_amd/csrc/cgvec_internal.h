@@ -243,7 +243,7 @@ int ingest_rollback(cgv_index* h, const IngestSnapshot& snap);
 int ingest_finish(cgv_index* h, uint64_t n_new);
 int add_dev_locked(cgv_index* h, const float* rows_dev, uint64_t cnt);
 int ensure_kernel_attrs(int device);
-int launch_coarse(int dtype, int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
+int launch_coarse(int dtype, int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 SelectArgs make_select_args(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,
                             const float* dense, uint32_t n_dense, uint64_t expected, size_t* lds_out, uint32_t extra_keys = 0);
 int launch_select(SearchCtx* c, uint32_t nq, uint32_t nqt, uint32_t nsplit, uint32_t kprime,

@@ -3,11 +3,11 @@
 
 namespace cgv {
 int coarse_attrs_bf16() { return coarse_attrs_2byte<DT_BF16>(); }
-int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #ifdef CGV_ABLATE_BUILD   // `make ABLATE=1`: + the timing-only ablations and the A/B reference instantiations
-    return launch_coarse_2byte<DT_BF16, true>(mode, a, W, s);
+    return launch_coarse_2byte<DT_BF16, true>(mode, a, W, s, ev0, ev1);
 #else
-    return launch_coarse_2byte<DT_BF16, false>(mode, a, W, s);
+    return launch_coarse_2byte<DT_BF16, false>(mode, a, W, s, ev0, ev1);
 #endif
 }
 }  // namespace cgv

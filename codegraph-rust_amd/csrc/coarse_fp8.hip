@@ -37,20 +37,20 @@ int coarse_attrs_fp8() {
     return CGV_OK;
 }
 
-int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr size_t lds = COARSE_LDS_BYTES;
     if (mode == COARSE_DUMP) {
-        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_DUMP>, dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH(coarse_fp8s_kernel<COARSE_DUMP>, dim3(W), dim3(512), lds, s, a);
         return status("coarse_fp8s_kernel (dump)");
     }
     if (mode == COARSE_SAMPLE) {
-        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_SAMPLE>, dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH(coarse_fp8s_kernel<COARSE_SAMPLE>, dim3(W), dim3(512), lds, s, a);
         return status("coarse_fp8s_kernel (sample)");
     }
     if (mode == COARSE_TOP2) {   // small batches (kernels_coarse.h: Top2): the 8-wave kernel, whose epilogue is tile_epilogue
         if (a.nqt != 1 || a.nq > 64 || !a.floor_ord)
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_TOP2 launched on a shape it does not serve");
-        hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_TOP2>, dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH(coarse_fp8s_kernel<COARSE_TOP2>, dim3(W), dim3(512), lds, s, a);
         return status("coarse_fp8s_kernel (top-2 cells)");
     }
     if (mode != COARSE_EMIT) return cgv_set_error_(CGV_ERR_INTERNAL, "fp8 coarse kernels: unknown launch mode");
@@ -68,7 +68,7 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
     case N: {                                                                  \
         auto k2 = coarse_fp8s_w4_kernel<N>;                                    \
         if (int rc = set_lds((const void*)k2)) return rc;                      \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);                 \
+        CGV_KLAUNCH(k2, dim3(W), dim3(256), lds, s, a);                 \
         break;                                                                 \
     }
             switch (abl4) {
@@ -83,18 +83,18 @@ int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) 
         if (a.kc % 4 == 0 && (a.epi & 512u) != 0) {   // A/B: the epilogue spread over two k-steps (EPI2; knob epi = 513)
             auto k2 = coarse_fp8s_w4_kernel<0, 2, true>;
             if (int rc = set_lds((const void*)k2)) return rc;
-            hipLaunchKernelGGL(k2, dim3(W), dim3(256), lds, s, a);
+            CGV_KLAUNCH(k2, dim3(W), dim3(256), lds, s, a);
             return status("coarse_fp8s_w4_kernel (si, epi2)");
         }
 #endif
         if (a.kc % 4 == 0 && (a.epi & 8u) == 0) {   // static issue side, ring-unrolled (epi bit 3 = the dynamic form, for A/B)
-            hipLaunchKernelGGL((coarse_fp8s_w4_kernel<0, 2>), dim3(W), dim3(256), lds, s, a);
+            CGV_KLAUNCH((coarse_fp8s_w4_kernel<0, 2>), dim3(W), dim3(256), lds, s, a);
             return status("coarse_fp8s_w4_kernel (si)");
         }
-        hipLaunchKernelGGL(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
+        CGV_KLAUNCH(coarse_fp8s_w4_kernel<0>, dim3(W), dim3(256), lds, s, a);
         return status("coarse_fp8s_w4_kernel");
     }
-    hipLaunchKernelGGL(coarse_fp8s_kernel<COARSE_EMIT>, dim3(W), dim3(512), lds, s, a);
+    CGV_KLAUNCH(coarse_fp8s_kernel<COARSE_EMIT>, dim3(W), dim3(512), lds, s, a);
     return status("coarse_fp8s_kernel");
 }
 

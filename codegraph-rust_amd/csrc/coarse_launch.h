@@ -2,6 +2,7 @@
 // kernels live in their own translation unit (coarse_bf16.hip, coarse_fp16.hip, coarse_fp8.hip): they are
 // the expensive instantiations of the library, and separate objects build in parallel.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include "kernels_coarse.h"
@@ -28,9 +29,15 @@ int coarse_attrs_bf16();
 int coarse_attrs_fp16();
 int coarse_attrs_fp8();
 
-// W workgroups on stream s; status = CGV_OK or a CGV_ERR_* with the thread's error message set
-int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
-int launch_coarse_fp16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
-int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s);
+// W workgroups on stream s; status = CGV_OK or a CGV_ERR_* with the thread's error message set.
+// ev0 / ev1 (optional): HIP events that take the START and the END of this very dispatch (hipExtLaunchKernelGGL: the timestamps of
+// the kernel's own completion signal) instead of hipEventRecord in front of and behind the launch (two marker packets on the
+// stream). In-process A/B, profiles/r06_launch_events_ab.txt: a 125 k-row shard's batch 0.3263 (markers) -> 0.3234 ms (0.3190 with
+// no events at all), C2 1.3312 -> 1.3304 (1.3226): a timed dispatch costs a few microseconds either way, the markers ~3 more.
+int launch_coarse_bf16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int launch_coarse_fp16(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int launch_coarse_fp8(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// (inside the launch functions: ev0 / ev1 are their parameters; null events = a plain launch)
+#define CGV_KLAUNCH(kern, grid, block, lds, s, a) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), s, ev0, ev1, 0u, a)
 
 }  // namespace cgv

@@ -53,30 +53,30 @@ int coarse_attrs_2byte() {
 
 // ABLATE: the timing-only ablation instantiations (bf16 only; scripts/gpu_ablate.sh, gpu_clock.sh)
 template <int DT, bool ABLATE>
-int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
+int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr size_t lds = COARSE_LDS_BYTES;  // attribute set per device by ensure_kernel_attrs()
     if (mode == COARSE_DUMP) {
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_DUMP>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_DUMP>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (dump)");
     }
     if (mode == COARSE_SAMPLE) {
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_SAMPLE>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_SAMPLE>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (sample)");
     }
     if (mode == COARSE_TOP2) {  // small batches: one query tile, every corpus tile read once -> non-temporal corpus stream
         if (a.nqt != 1 || a.nq > 64 || !a.floor_ord)
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_TOP2 launched on a shape it does not serve");
         if (a.kc >= 4 && a.kc % 4 == 0)
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
         else
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 0>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_TOP2, 0, 1, true, 0>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (top-2 cells)");
     }
     if (mode == COARSE_EMIT_BOOT) {  // the fused sample + emit launch: the ring-unrolled, shared-tile form only (search.hip: can_fuse)
 #ifdef CGV_ABLATE_BUILD
         if (!(a.kc >= 4 && a.kc % 4 == 0 && a.nqt > 1 && a.boot_sync && a.tau_out && a.dump && a.cnt >= 2 * a.nsplit))
             return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT launched on a shape it does not serve");
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT_BOOT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (emit + boot)");
 #else
         return cgv_set_error_(CGV_ERR_INTERNAL, "COARSE_EMIT_BOOT exists in the measurement flavour only (make ABLATE=1)");
@@ -90,7 +90,7 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     case N: {                                                                  \
         auto k2 = coarse_kernel<DT, COARSE_EMIT, N, 1, false, 2>;              \
         if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                 \
+        CGV_KLAUNCH(k2, dim3(W), dim3(512), lds, s, a);                 \
         break;                                                                 \
     }
             switch (abl) {
@@ -106,7 +106,7 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
     case N: {                                                                  \
         auto k2 = coarse_kernel<DT, COARSE_EMIT, N>;                           \
         if (int rc = coarse_set_lds((const void*)k2)) return rc;               \
-        hipLaunchKernelGGL(k2, dim3(W), dim3(512), lds, s, a);                 \
+        CGV_KLAUNCH(k2, dim3(W), dim3(512), lds, s, a);                 \
         break;                                                                 \
     }
             switch (abl) {
@@ -130,18 +130,18 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
             return nb;
         }();
         (void)per_cu;
-        hipLaunchKernelGGL(kw, dim3(W), dim3(256), COARSE_WG2_LDS_BYTES, s, a);
+        CGV_KLAUNCH(kw, dim3(W), dim3(256), COARSE_WG2_LDS_BYTES, s, a);
         return coarse_hip_status("coarse_wg2_kernel");
     }
     if ((a.epi & 128u) != 0 && a.kc >= 4) {  // A/B: one wave per SIMD with the folded epilogue (bit 8 = its boundary-block form)
         if ((a.epi & 256u) != 0) {
             auto kw = coarse_w4_kernel<DT, false>;
             if (int rc = coarse_set_lds((const void*)kw)) return rc;
-            hipLaunchKernelGGL(kw, dim3(W), dim3(256), lds, s, a);
+            CGV_KLAUNCH(kw, dim3(W), dim3(256), lds, s, a);
         } else {
             auto kw = coarse_w4_kernel<DT, true>;
             if (int rc = coarse_set_lds((const void*)kw)) return rc;
-            hipLaunchKernelGGL(kw, dim3(W), dim3(256), lds, s, a);
+            CGV_KLAUNCH(kw, dim3(W), dim3(256), lds, s, a);
         }
         return coarse_hip_status("coarse_w4_kernel");
     }
@@ -150,7 +150,7 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         if ((a.epi & 1u) == 0) {
             auto k0 = coarse_kernel<DT, COARSE_EMIT, 0, 0>;
             if (int rc = coarse_set_lds((const void*)k0)) return rc;
-            hipLaunchKernelGGL(k0, dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH(k0, dim3(W), dim3(512), lds, s, a);
             return coarse_hip_status("coarse_kernel (epi 0)");
         }
     }
@@ -163,39 +163,39 @@ int launch_coarse_2byte(int mode, const CoarseArgs& a, uint32_t W, hipStream_t s
         if (u4 && (a.epi & 32u) != 0 && !nt) {
             auto kp = coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 3>;
             if (int rc = coarse_set_lds((const void*)kp)) return rc;
-            hipLaunchKernelGGL(kp, dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH(kp, dim3(W), dim3(512), lds, s, a);
             return coarse_hip_status("coarse_kernel (reads in the barrier gap)");
         }
     }
 #ifdef CGV_ABLATE_BUILD
     if (u4 && a.lad && a.ladc) {   // the threshold ladder: the ring-unrolled form only (every headline shape); knob `ladder`
         if (nt)
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2, true>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2, true>), dim3(W), dim3(512), lds, s, a);
         else
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2, true>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2, true>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (si, ring-unrolled, ladder)");
     }
 #endif
     if (u4) {
         if (nt)
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 2>), dim3(W), dim3(512), lds, s, a);
         else
-            hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
+            CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 2>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (si, ring-unrolled)");
     }
     if (nt && si) {
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, true, 1>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (nt, si)");
     }
     if (si) {
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, false, 1>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (si)");
     }
     if (nt) {
-        hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT, 0, 1, true>), dim3(W), dim3(512), lds, s, a);
+        CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT, 0, 1, true>), dim3(W), dim3(512), lds, s, a);
         return coarse_hip_status("coarse_kernel (nt)");
     }
-    hipLaunchKernelGGL((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);
+    CGV_KLAUNCH((coarse_kernel<DT, COARSE_EMIT>), dim3(W), dim3(512), lds, s, a);
     return coarse_hip_status("coarse_kernel");
 }
 

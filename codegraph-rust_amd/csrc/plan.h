@@ -68,6 +68,7 @@ struct Tunables {
     int fuse_sample = CGV_ENV_INT("CGV_FUSE_SAMPLE", 0);      // sample + tau + first emitting launch as ONE launch (measurement flavour only)
     int sample_emit = CGV_ENV_INT("CGV_SAMPLE_EMIT", 1);      // the sample launch emits its own candidates; the launches behind it skip its tiles (A/B: 0)
     int top2 = CGV_ENV_INT("CGV_TOP2", 1);                    // small batches (nq <= 64): COARSE_TOP2, one launch without thresholds (A/B: 0)
+    int launch_events = CGV_ENV_INT("CGV_LAUNCH_EVENTS", 1);  // profiling: the timed launch carries its own start / end events (A/B: 0 = marker events around it)
     int sample_repair = CGV_ENV_INT("CGV_SAMPLE_REPAIR", 1);  // emitting sample: floor violations put right inside the final kernel (A/B: 0 = exact scan)
     int top2_repair = CGV_ENV_INT("CGV_TOP2_REPAIR", 1);      // COARSE_TOP2 floor violations: re-scan the offending cells only (A/B: 0 = exact scan)
     int exact_small = CGV_ENV_INT("CGV_EXACT_SMALL", 1);      // exact scan of <= 8 queries as ONE kernel (kernels_exact_small.h; A/B: 0)

@@ -237,10 +237,10 @@ int ensure_kernel_attrs(int device) {
     return CGV_OK;
 }
 
-int launch_coarse(int dtype, int mode, const CoarseArgs& a, uint32_t W, hipStream_t s) {
-    if (dtype == CGV_DTYPE_BF16) return launch_coarse_bf16(mode, a, W, s);
-    if (dtype == CGV_DTYPE_FP16) return launch_coarse_fp16(mode, a, W, s);
-    if (dtype == CGV_DTYPE_FP8E4M3) return launch_coarse_fp8(mode, a, W, s);
+int launch_coarse(int dtype, int mode, const CoarseArgs& a, uint32_t W, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (dtype == CGV_DTYPE_BF16) return launch_coarse_bf16(mode, a, W, s, ev0, ev1);
+    if (dtype == CGV_DTYPE_FP16) return launch_coarse_fp16(mode, a, W, s, ev0, ev1);
+    if (dtype == CGV_DTYPE_FP8E4M3) return launch_coarse_fp8(mode, a, W, s, ev0, ev1);
     return fail(CGV_ERR_INTERNAL, "coarse path: unsupported dtype");
 }
 
@@ -664,10 +664,12 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
                 c->t2_P = a.P;
             }
             if (h->profiling > 2) HIPCHK(hipEventRecord(c->pev[1], s));   // (no threshold phase: the one launch counts as emitting)
-            if (h->profiling) HIPCHK(hipEventRecord(c->ev[1], s));
-            if ((rc = launch_coarse(cdt, COARSE_TOP2, a, a.nsplit, s))) return rc;
+            // (the timed launch carries its own event pair: the dispatch's start / end, no marker packets on the stream - coarse_launch.h)
+            const bool ext_ev = h->profiling && tun().launch_events != 0, rec_ev = h->profiling && !ext_ev;   // (A/B: marker events)
+            if (rec_ev) HIPCHK(hipEventRecord(c->ev[1], s));
+            if ((rc = launch_coarse(cdt, COARSE_TOP2, a, a.nsplit, s, ext_ev ? c->ev[1] : nullptr, ext_ev ? c->ev[2] : nullptr))) return rc;
+            if (rec_ev) HIPCHK(hipEventRecord(c->ev[2], s));
             if (h->profiling) {
-                HIPCHK(hipEventRecord(c->ev[2], s));
                 c->timed_coarse = true;
                 c->coarse_rows = h->n;
             }
@@ -755,19 +757,21 @@ int search_enqueue(cgv_index* h, SearchCtx* c, const float* qdev, uint32_t nq, u
             // costs (r03b: C2 step 1.458 -> 1.453 ms, the 125 k-row shard 0.381 -> 0.378 without it).
             a.pace = (cnt / a.nsplit >= 128u || tun().pace > 1) ? const_cast<uint32_t*>(pace_words) : nullptr;
             const bool dominant = (st + 1 == p.counts.size());
-            if (h->profiling && dominant) HIPCHK(hipEventRecord(c->ev[1], s));
+            const bool timed_any = h->profiling && dominant;
+            const bool timed = timed_any && tun().launch_events != 0;   // the dispatch's own start / end events (coarse_launch.h)
+            if (timed_any && !timed) HIPCHK(hipEventRecord(c->ev[1], s));   // (A/B: marker events in front of and behind the launch)
             if (st == 0 && fuse) {
                 CoarseArgs fa = a;
                 fa.dump = c->dump.as<float>();
                 fa.sample_vals = fvals;
                 fa.sample_ld = nsplit0 * fvals;
                 fa.pace = nullptr;
-                if ((rc = launch_coarse(cdt, COARSE_EMIT_BOOT, fa, nqt * fa.nsplit, s))) return rc;
-            } else if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s))) {
+                if ((rc = launch_coarse(cdt, COARSE_EMIT_BOOT, fa, nqt * fa.nsplit, s, timed ? c->ev[1] : nullptr, timed ? c->ev[2] : nullptr))) return rc;
+            } else if ((rc = launch_coarse(cdt, COARSE_EMIT, a, nqt * a.nsplit, s, timed ? c->ev[1] : nullptr, timed ? c->ev[2] : nullptr))) {
                 return rc;
             }
-            if (h->profiling && dominant) {
-                HIPCHK(hipEventRecord(c->ev[2], s));
+            if (timed_any) {
+                if (!timed) HIPCHK(hipEventRecord(c->ev[2], s));
                 c->timed_coarse = true;
                 c->coarse_rows = std::min<uint64_t>((uint64_t)cnt * BM, h->n);
             }

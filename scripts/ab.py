@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("CGV_LIB_PATH", os.path.join(ROOT, "codegraph-rust_amd", "lib", "libcgvec_hip_ablate.so"))  # knobs live there
 import bench  # noqa: E402  (workload table + generators)
 
-KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1, "fuse_sample": 0, "top2": 1, "sample_emit": 1, "top2_repair": 1, "fetch_queries": 1, "ladder": 0, "exact_small": 1, "self_publish": 1, "profiling": 2}
+KNOBS = {"plan_legacy": 0, "sample_tiles": 0, "plan_launches": 0, "hit_us": 1.7, "launch_us": 40.0, "zero_copy": 3, "pace": 1, "epi": 1, "fuse_sample": 0, "top2": 1, "sample_emit": 1, "top2_repair": 1, "fetch_queries": 1, "ladder": 0, "exact_small": 1, "self_publish": 1, "sample_repair": 1, "launch_events": 1, "profiling": 2}
 
 
 def main():

@@ -15,9 +15,9 @@ rocprofv3 -L 2>/dev/null | grep -io "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQC_IN
 for wl in $WLS; do
   K="coarse"
   python $R/bench.py --workload $wl $( [ $wl = c2 ] || echo --cpu-seconds 0 ) 2>/dev/null | tail -1 > $R/$OUT/${wl}_bench.json
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -o $wl -- python $R/bench.py --workload $wl --cpu-seconds 0 --pipelined-steps 0 --latency 0 --check-queries 0 > $R/$OUT/${wl}_rocprof_stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -o $wl -- python $R/bench.py --workload $wl --cpu-seconds 0 --pipelined-steps 0 --latency 0 --check-queries 0 --coalesced-threads 0 --callers 0 > $R/$OUT/${wl}_rocprof_stats.log 2>&1
   pmc() { name=$1; shift
-    timeout 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$K" --output-format csv -d $R/$OUT/$wl -o $name -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --settle-ms 0 --cpu-seconds 0 --pipelined-steps 0 --latency 0 --check-queries 0 > $R/$OUT/${wl}_$name.log 2>&1; }
+    timeout 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$K" --output-format csv -d $R/$OUT/$wl -o $name -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --settle-ms 0 --cpu-seconds 0 --pipelined-steps 0 --latency 0 --check-queries 0 --coalesced-threads 0 --callers 0 > $R/$OUT/${wl}_$name.log 2>&1; }
   mkdir -p $R/$OUT/$wl
   pmc p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
   pmc p2 FETCH_SIZE TCC_HIT_sum

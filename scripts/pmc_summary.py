@@ -1,6 +1,7 @@
 import csv, glob, collections, sys, os
 d = sys.argv[1]
 allc = {}
+main_p1 = None
 for f in sorted(glob.glob(os.path.join(d, 'p*_counter_collection.csv'))):
     rows = list(csv.DictReader(open(f)))
     by = collections.defaultdict(dict)
@@ -9,7 +10,18 @@ for f in sorted(glob.glob(os.path.join(d, 'p*_counter_collection.csv'))):
         by[int(r['Dispatch_Id'])]['_grid'] = int(r['Grid_Size'])
     if not by:
         print(f, 'EMPTY'); continue
-    last = by[max(by)]          # the last dispatch = the main (stage 3) launch of the last search
+    # the dominant launch = the LONGEST coarse dispatch of this pass' own kernel trace (the main stage of a full batch; the side
+    # measurements of the bench also launch coarse kernels - small batches - so "the last dispatch" is not it)
+    pick = max(by)
+    tr = f.replace('_counter_collection.csv', '_kernel_trace.csv')
+    if os.path.exists(tr):
+        rows_t = [r for r in csv.DictReader(open(tr)) if 'coarse' in r.get('Kernel_Name', '') and int(r['Dispatch_Id']) in by]
+        if rows_t:
+            best = max(rows_t, key=lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+            pick = int(best['Dispatch_Id'])
+            if os.path.basename(f).startswith('p1_'):
+                main_p1 = (best['Kernel_Name'], int(best['End_Timestamp']) - int(best['Start_Timestamp']))
+    last = by[pick]
     for k, v in last.items():
         allc[k] = v
 for k in sorted(allc):
@@ -34,12 +46,9 @@ if g('TCC_REQ_sum'):
 
 # duration of the same dispatch in the pass that carried GRBM_GUI_ACTIVE (the PMC passes run with --kernel-trace): the clock the
 # launch ran at = cycles per XCD / duration (say what limits the launch - the nominal peaks assume 2.4 GHz)
-dur_ns = None
-for f in sorted(glob.glob(os.path.join(d, 'p1_kernel_trace.csv'))):
-    rows = [r for r in csv.DictReader(open(f)) if 'coarse' in r.get('Kernel_Name', '')]
-    if rows:
-        last = max(rows, key=lambda r: int(r['Dispatch_Id']))
-        dur_ns = int(last['End_Timestamp']) - int(last['Start_Timestamp'])
+dur_ns = main_p1[1] if main_p1 else None
+if main_p1:
+    print("-- dominant launch:", main_p1[0][:90])
 if dur_ns and g('GRBM_GUI_ACTIVE'):
     clk = g('GRBM_GUI_ACTIVE') / 8 / dur_ns
     print("-- profiled duration %.1f us ; clock %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration)" % (dur_ns / 1e3, clk))
