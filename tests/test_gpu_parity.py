@@ -822,6 +822,50 @@ def test_emitting_sample_clustered_corpus_many_repairs(oracle, dtype, odt):
         ix.close()
 
 
+@pytest.mark.parametrize("n,nq,k,d,dtype,metric", [
+    (33_000, 1024, 10, 64, "bf16", "cosine"),      # R = 129 tiles = 2 S + 1: the smallest corpus whose sample emits
+    (40_000, 700, 30, 96, "fp16", "dot"),          # 3 query tiles -> S = 85; k' = 40; un-normalised rows
+    (70_000, 1024, 57, 64, "bf16", "cosine"),      # k' = 64: the largest the fused final selection takes
+    (140_000, 300, 10, 64, "fp8", "cosine"),       # 2 query tiles -> S = 128, R = 547; k' = 32 (fp8)
+    (66_000, 130, 5, 100, "f32s", "cosine"),       # one query tile -> S = 256, R = 258; ragged D; f32 rows + bf16 shadow
+])
+def test_emitting_sample_regime_sweep(oracle, n, nq, k, d, dtype, metric):
+    """Corpora between 2 S and a few S tiles (S = sample tiles = CUs / query tiles): the sample launch emits and the launch behind
+    it covers as few as S + 1 tiles - shapes the headline configs never produce (round 6 lowered the limit from 4 S to 2 S once a
+    crowded sample cell no longer cost an exact scan). Planted near-duplicate runs make some queries fail the floor check."""
+    m = pkg()
+    rng = np.random.default_rng(n + nq)
+    unit = metric == "cosine"
+    rows = _unit(rng, n, d) if unit else (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    q = _unit(rng, nq, d) if unit else rng.standard_normal((nq, d)).astype(np.float32)
+    for j in range(0, min(nq, 200), 2):            # runs of 6 adjacent near-copies of a query, anywhere in the corpus
+        r0 = int(rng.integers(0, n - 8)) & ~7
+        for t in range(6):
+            v = q[j] + 0.02 * (t + 1) * _unit(rng, 1, d)[0] * np.linalg.norm(q[j])
+            rows[r0 + t] = v / (np.linalg.norm(v) if unit else 1.0)
+    ix = m.HipKnnIndex(d, metric=metric, dtype=dtype)
+    try:
+        ix.add(rows)
+        emits = bool(_plan_emits(m, n, k, nq, dtype == "f32s"))
+        assert emits
+        gi, gs = ix.search(q, k)
+        _check(oracle, rows, q, k, dtype, metric, gi, gs, f"n={n} nq={nq} k={k} d={d} {dtype} {metric}")
+        st = ix.stats()
+        assert st["last_path"] == 1 and st["fallback_queries"] <= max(8, nq // 10), st   # (near-ties of the planted runs, mostly fp8)
+    finally:
+        ix.close()
+
+
+def _plan_emits(m, n, k, nq, shadow):
+    L = m.cgvec.lib()
+    out = (C.c_uint32 * 64)()
+    L.cgv_debug_plan_.restype = C.c_uint32
+    L.cgv_debug_plan_.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_uint32]
+    n_cu = m.cgvec.device_properties(0)["multiProcessorCount"] if hasattr(m.cgvec, "device_properties") else 256
+    L.cgv_debug_plan_(n, k, nq, n_cu, 1 if shadow else 0, out, 64)
+    return out[1] & 0x10000
+
+
 def test_phase_times_of_the_mfma_pipeline(oracle):
     """cgv_set_profiling(3) + cgv_get_phase_times: HIP events at the phase boundaries of the MFMA pipeline, on the stream the batch
     runs on - conversion | first threshold | emitting launches | final + publish. What bench.py's N > 1 line prints per rank."""
