@@ -472,12 +472,13 @@ def main():
                          "(replicated), or each rank moves 1/N of it and one all-gather of the f32 slices over xGMI completes it "
                          "(sharded; ShardedKnn.query_exchange). auto = both forms are timed in a short trial before the warm-up "
                          "(multi_gpu.query_exchange) and the faster one runs the timed steps")
-    ap.add_argument("--queries", default="hbm", choices=("hbm", "host"),
-                    help="where a timed step's query batch starts. hbm (default) = already resident in device memory when the timed "
+    ap.add_argument("--queries", default=None, choices=("hbm", "host"),
+                    help="where a timed step's query batch starts. hbm (default for batched workloads) = already resident in device memory when the timed "
                          "region starts (the measurement contract: `value` = throughput with the inputs in HBM); the B*k results "
                          "still end in pinned HOST memory inside the step. host = the batch starts in pinned host memory and "
                          "crosses PCIe inside the step (SURVEY.md 8(d)'s form, `value` of rounds 1-5); whichever form is not "
-                         "`value` is timed as well and reported beside it (`pcie_inclusive_serial` / `hbm_resident_serial`)")
+                         "`value` is timed as well and reported beside it (`pcie_inclusive_serial` / `hbm_resident_serial`). "
+                         "Single-query workloads (c1: the trait-level call hands over ONE host slice, traits.rs:14) default to host")
     ap.add_argument("--dist-timeout", type=float, default=180.0,
                     help="seconds: process-group timeout AND the no-progress limit of the watchdog - a hung collective ends the "
                          "run with a JSON line carrying an `error` field instead of hanging the launcher")
@@ -505,6 +506,8 @@ def main():
         args.warmup = 3 if big else 10
     if args.pipelined_steps is None:
         args.pipelined_steps = min(args.steps, 200)
+    if args.queries is None:
+        args.queries = "hbm" if WORKLOADS[args.workload][4] >= 64 else "host"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_under_launcher(args.gpus))
