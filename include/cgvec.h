@@ -370,9 +370,10 @@ typedef struct cgv_stats {
 } cgv_stats;
 int cgv_get_stats(cgv_index* h, cgv_stats* out);
 
-/* HIP-event timing of each search, on the stream its kernels are launched on: 0 = off; 1 = two event records around
- * the dominant coarse launch (cgv_stats.last_coarse_ms); 2 = also around the whole pipeline (last_total_ms). Each
- * record is a packet on the stream: level 2 measured ~10 us per batch on short searches. */
+/* HIP-event timing of each search, on the stream its kernels are launched on: 0 = off; 1 = the dominant coarse launch
+ * carries a start / end event pair of its own (the dispatch's timestamps, hipExtLaunchKernelGGL: cgv_stats.last_coarse_ms;
+ * ~4-8 us per batch); 2 = also two event records around the whole pipeline (last_total_ms). Each record is a packet on
+ * the stream: level 2 measured ~10 us per batch on short searches. */
 int cgv_set_profiling(cgv_index* h, int enabled);
 /* Level 3 adds three more records per search, at the phase boundaries of the MFMA pipeline; out_us4 = device microseconds of
  * the last finished search's {query conversion, first threshold (sample launch + tau, or boot + select), emitting coarse
