@@ -466,7 +466,7 @@ class HipKnnIndex:
             raise CgvError(CGV_ERR_INVALID_ARG, "the tensor is not (wholly) pinned / registered host memory")
         return alias
 
-    def search_packed_begin(self, queries, k, rec):
+    def search_packed_begin(self, queries, k, rec, stream=None):
         """One rank's share of a batch without a host join before the exchange (cgv_search_packed_begin_f32_dev): the shard
         search is enqueued, its top-k are packed into `rec` (CUDA int32 [nq, packed_width(k)]) on the library's stream, and
         torch's CURRENT stream is made to wait for them - enqueue the all-gather + merge_packed(..., redo=flag) next and
@@ -478,8 +478,11 @@ class HipKnnIndex:
             raise CgvError(CGV_ERR_DIM_MISMATCH, f"query batch {tuple(queries.shape)} {queries.dtype} != [nq, {self.dim}] f32")
         if not rec.is_cuda or rec.dtype != torch.int32 or rec.numel() != nq * packed_width(k) or not rec.is_contiguous():
             raise CgvError(CGV_ERR_INVALID_ARG, "rec must be a contiguous CUDA int32 tensor of nq * packed_width(k) words")
-        self.use_torch_stream()   # the search orders after what torch queued so far (the producer of a CUDA batch)
-        stream = torch.cuda.current_stream(rec.device).cuda_stream
+        if stream is None:        # the search orders after what torch queued so far on its CURRENT stream (the producer of a CUDA batch)
+            stream = torch.cuda.current_stream(rec.device).cuda_stream
+        # (stream given: the raw handle of the stream the batch runs on - the caller has ordered it behind the producer itself and
+        #  spares the interpreter the stream context around this call: the first kernel leaves ~10 us earlier, ShardedKnn)
+        self.set_stream(stream)
         t = C.c_uint64(0)
         if nq and k:
             _check(lib().cgv_search_packed_begin_f32_dev(self._h, C.c_void_p(self.device_alias(queries)), nq, k,

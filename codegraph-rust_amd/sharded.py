@@ -74,8 +74,8 @@ class _Batch:
     """One batch in flight of ShardedKnn.step_packed_begin / _end: its record / gather buffers, the pinned redo word the merge
     kernel raises, the stream the whole batch is enqueued on (shard search, packing, all-gather, merge - in line, no hop) and
     the event behind its last kernel. Reused round-robin; `busy` between begin and end."""
-    __slots__ = ("key", "rec", "gathered", "redo", "stream", "done", "ev", "ticket", "k", "nq", "out", "res", "busy",
-                 "mode", "timed", "queries", "qkey", "qslice", "qfull")
+    __slots__ = ("key", "rec", "gathered", "redo", "redo_np", "stream", "stream_ptr", "done", "ev", "ticket", "k", "nq", "out", "res",
+                 "busy", "mode", "timed", "queries", "qkey", "qslice", "qfull")
 
     def __init__(self):
         self.key = self.qkey = None
@@ -150,7 +150,7 @@ class ShardedKnn:
                 break
         else:
             raise RuntimeError(f"ShardedKnn: {len(self._slots)} batches already in flight - call step_packed_end first")
-        key = (nq, w, str(like.device) if like.is_cuda else "cpu", self.world)
+        key = (nq, w, like.device if like.is_cuda else None, self.world)
         if b.key != key:
             dev = like.device if like.is_cuda else torch.device("cpu")
             b.rec = torch.empty((nq, w), dtype=torch.int32, device=dev)
@@ -159,8 +159,10 @@ class ShardedKnn:
             if like.is_cuda:
                 b.redo = b.redo.pin_memory()   # written in place by the merge kernel, read by the host after the batch's event
                 b.stream = torch.cuda.Stream(device=dev)
+                b.stream_ptr = b.stream.cuda_stream
                 b.done = torch.cuda.Event()
                 b.ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(5))   # start | queries | search + pack | all-gather | merge
+            b.redo_np = b.redo.numpy()         # (the same word: the interpreter reads and clears it without a tensor op)
             b.key = key
         return b
 
@@ -269,21 +271,28 @@ class ShardedKnn:
         like = queries if queries.is_cuda else (torch.empty(0, device=device) if device is not None else queries)
         b = self._take_slot(nq, int(k), like)
         b.k, b.nq, b.out, b.res, b.queries = int(k), nq, out, None, queries
-        b.redo.zero_()                       # (the slot is idle: no kernel writes it)
+        b.redo_np[0] = 0                     # (the slot is idle: no kernel writes it)
         b.timed = 2 if (b.rec.is_cuda and self.time_phases) else (1 if (b.rec.is_cuda and self.time_exchange) else 0)
         if b.rec.is_cuda:
             coll = self._collective()
             b.mode = "host" if coll == "gloo" else "stream"
-            if queries.is_cuda:              # the producer of a CUDA batch comes first
-                b.stream.wait_stream(torch.cuda.current_stream(b.rec.device))
+            if queries.is_cuda:              # the producer of a CUDA batch comes first - when it still has work in flight
+                cur = torch.cuda.current_stream(b.rec.device)
+                if not cur.query():
+                    b.stream.wait_stream(cur)
             sharded_q = self.query_exchange == "sharded" and not queries.is_cuda and coll is not None
+            early = not sharded_q and b.timed != 2 and hasattr(self.local, "set_stream")
+            if early:   # the shard search goes onto the batch's stream before the interpreter enters the stream context (which only
+                #         the collective and the merge need): step_packed spent 24 us before this call, scripts/step_packed_probe.py
+                b.ticket = self.local.search_packed_begin(queries, k, b.rec, stream=b.stream_ptr)
             with torch.cuda.stream(b.stream):
                 if b.timed == 2:
                     b.ev[0].record()
                 q_in = self._gather_queries(b, queries, device) if sharded_q else queries
                 if b.timed == 2:
                     b.ev[1].record()
-                b.ticket = self.local.search_packed_begin(q_in, k, b.rec)
+                if not early:
+                    b.ticket = self.local.search_packed_begin(q_in, k, b.rec)
                 if b.mode == "stream":
                     if b.timed:
                         b.ev[2].record()
@@ -328,9 +337,9 @@ class ShardedKnn:
                 self.local.search_packed_end(b.ticket)
             except Exception as e:   # noqa: BLE001 - re-raised below, after the collective
                 err = e
-            if int(b.redo[0]) != 0:
+            if int(b.redo_np[0]) != 0:
                 self.redo_batches += 1
-                b.redo.zero_()
+                b.redo_np[0] = 0
                 if cuda:
                     with torch.cuda.stream(b.stream):
                         b.res = self._gather_merge(b)
@@ -338,7 +347,7 @@ class ShardedKnn:
                     self._wait(b.done)
                 else:
                     b.res = self._gather_merge(b)
-                if err is None and int(b.redo[0]) != 0:
+                if err is None and int(b.redo_np[0]) != 0:
                     raise RuntimeError("records still provisional after search_packed_end (a rank's search failed)")
             if err is not None:
                 raise err
