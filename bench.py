@@ -868,16 +868,33 @@ def run(args, wd, world, rank, local_rank):
             def hend(p):
                 searcher.step_packed_end(p)
 
+        piped_ends = []
+
         def run_piped(nsteps):
             pend = collections.deque()
             for i in range(nsteps):
                 pend.append(hbegin(i))
                 if len(pend) >= depth:
                     hend(pend.popleft())
+                    piped_ends.append(time.perf_counter())
             while pend:
                 hend(pend.popleft())
+                piped_ends.append(time.perf_counter())
         gc.collect()     # (in front of the warm batches: nothing idles the device between them and the timed ones)
-        run_piped(max(depth, min(args.warmup, 10)))
+        # Warm batches for at least 40 ms (every rank the same number: rank 0 decides): the first ~10 ms of host batches in flight
+        # after a stretch of HBM-resident work run at a third of the steady rate (BENCH_DEBUG_STEPS prints the completion intervals:
+        # 12 ms for the first batch, then 1.2; the copy engine / PCIe path wakes up) - with 5 warm batches a 20-batch region read
+        # 1.87 ms per batch where 200 batches read 1.23 (the driver-form lines of profiles/r06z*, r06zz*)
+        tw = time.perf_counter()
+        for _ in range(40):
+            run_piped(depth)
+            go = 1e3 * (time.perf_counter() - tw) < 40.0
+            if dist is not None:
+                flag = torch.tensor([1 if go else 0], device=ctl)
+                dist.broadcast(flag, 0)
+                go = bool(flag.item())
+            if not go:
+                break
         wd.kick("pipelined_host warm")
         redo_before = searcher.redo_batches if dist is not None else 0
         sync_all()
@@ -885,6 +902,9 @@ def run(args, wd, world, rank, local_rank):
         run_piped(args.pipelined_steps)
         sync_all()
         dtp = max_over_ranks(time.perf_counter() - tp)
+        if os.environ.get("BENCH_DEBUG_STEPS"):   # (diagnostics: completion-to-completion intervals of the timed batches)
+            ends = piped_ends[-args.pipelined_steps:]
+            print("pipelined_host batch intervals ms:", " ".join(f"{1e3 * (b_ - a_):.2f}" for a_, b_ in zip([tp] + ends[:-1], ends)), file=sys.stderr, flush=True)
         gc.collect()
         wd.kick("pipelined_host timed")
         # parity of the pipelined batches: the last `depth` batches' host results against a SERIAL step on the same queries
