@@ -866,6 +866,38 @@ def _plan_emits(m, n, k, nq, shadow):
     return out[1] & 0x10000
 
 
+def test_emitting_sample_repairs_with_three_batches_in_flight(oracle):
+    """The in-kernel repair reads the sample's per-cell floor values out of the search context's own scratch: three different
+    clustered batches in flight on one index (three contexts, three streams), twice over - every batch's answer is the oracle's and
+    the repairs of all of them are counted."""
+    import torch
+    m = pkg()
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 80_000, 64, 1024, 10
+    files = n // 8
+    base = _unit(rng, files, d)
+    rows = np.repeat(base, 8, axis=0) + 0.03 * rng.standard_normal((n, d)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    qs = [base[rng.choice(files, nq, replace=False)] + 0.01 * rng.standard_normal((nq, d)).astype(np.float32) for _ in range(3)]
+    ix = m.HipKnnIndex(d, dtype="bf16")
+    try:
+        ix.add(rows)
+        want = [oracle.batch_top_k(q, rows, k, dtype=1) for q in qs]
+        qp = [torch.from_numpy(q).pin_memory() for q in qs]
+        outs = [(torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory()) for _ in range(3)]
+        r0 = ix.sample_repairs()
+        for rnd in range(2):
+            pend = [ix.search_begin_pinned(qp[i], k, outs[i]) for i in range(3)]
+            for p in reversed(pend):                       # (any end order)
+                p.wait()
+            for i in range(3):
+                assert np.array_equal(outs[i][0].numpy().view(np.uint64), want[i][0]), (rnd, i)
+                assert np.array_equal(outs[i][1].numpy(), want[i][1]), (rnd, i)
+        assert ix.sample_repairs() - r0 > 6 * 100          # ~200 of 1024 queries per batch sit in sampled tiles
+    finally:
+        ix.close()
+
+
 def test_phase_times_of_the_mfma_pipeline(oracle):
     """cgv_set_profiling(3) + cgv_get_phase_times: HIP events at the phase boundaries of the MFMA pipeline, on the stream the batch
     runs on - conversion | first threshold | emitting launches | final + publish. What bench.py's N > 1 line prints per rank."""
